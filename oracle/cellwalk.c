@@ -1,0 +1,248 @@
+/* TEST INFRASTRUCTURE ONLY (oracle).  CPU statement of the polyhedral-cell variant of the
+ * reference's walk: the SAME plane-exit test, tolerances, inlet-face skip, hop/reflection
+ * caps and advect/reflect/move order as oracle/tetwalk.c (reference:
+ * third_party/RTXAdvect/query/ConvexQuery.cu:32-216, :239-436; cuda/particles.cu:316-373,
+ * :659-704; src/advect.H:96-161), applied to the polyMesh cells themselves instead of to the
+ * 12-tets-per-cell decomposition.  Because the reference's velocity is cell-constant
+ * (src/initCuda.H:106-108) both walks give the same positions whenever they agree on the
+ * containing cell; tests/test_oracle_cellwalk.py checks that against tetwalk.c / oracle/_ref.
+ *
+ * It exists so that the HIP kernels (which implement this formulation) can be compared
+ * BIT-EXACTLY at sizes where the tet walk is too slow, and as the "port" CPU baseline.
+ * Arithmetic contract shared with the kernels (written independently on both sides):
+ * fp64, explicit fma() in dot products / axpy, no other contraction (-ffp-contract=off),
+ * IEEE division, planes (unit inward normal n, offset d = n.Cf) per (cell, face-slot).
+ * Nothing under cudaparticlesfoam_amd/ may call, link or import this file.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define CW_TOL 1e-13
+#define CW_MAX_HOPS 50     /* ConvexQuery.cu:169 (tets there, cells here) */
+#define CW_MAX_REFLECT 5   /* ConvexQuery.cu:353 */
+#define CW_LOST (-1)       /* still at a wall after 5 reflections / left the domain: tetID -1 */
+#define CW_FROZEN (-2)     /* w == 0 in the reference (cuda/particles.cu:333-338) */
+
+typedef struct { double x, y, z; } v3;
+static inline v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline double dotf(v3 a, v3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+static inline v3 axpy(double s, v3 a, v3 b) { return V(fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)); }
+/* plain (un-fused) forms for the one-off host geometry */
+static inline double dotp(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 crossp(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+/* ------------------------------------------------------------------------------------------
+ * polyMesh -> CSR cell/face-slot tables.  Slot order = mesh.cells()[c] order
+ * (primitiveMesh::calcCells: owned faces ascending, then neighbour faces ascending).
+ *   planes[4*s..] = (nx, ny, nz, d): unit normal pointing INTO the cell, d = n . Cf
+ *   nbr[s]        = neighbour cell, or -(face+1) for a boundary face
+ * Face centre/area vector: triangle fan about the vertex average (OpenFOAM's
+ * primitiveMeshFaceCentresAndAreas scheme, restated; exact for planar faces).
+ * ------------------------------------------------------------------------------------------ */
+int cw_build(const double* points, int nPoints, const int* faceOff, const int* faceVerts, int nFaces,
+             const int* owner, const int* neighbour, int nInternal, int nCells,
+             int* cellOff /*nCells+1*/, double* planes /*4*ncf*/, int* nbr /*ncf*/) {
+    (void)nPoints;
+    int* cnt = (int*)calloc((size_t)nCells + 1, sizeof(int));
+    if (!cnt) return -1;
+    for (int f = 0; f < nFaces; ++f) cnt[owner[f]]++;
+    for (int f = 0; f < nInternal; ++f) cnt[neighbour[f]]++;
+    cellOff[0] = 0;
+    for (int c = 0; c < nCells; ++c) cellOff[c + 1] = cellOff[c] + cnt[c];
+    memset(cnt, 0, ((size_t)nCells + 1) * sizeof(int));
+    for (int pass = 0; pass < 2; ++pass) {
+        int nf = pass == 0 ? nFaces : nInternal;
+        for (int f = 0; f < nf; ++f) {
+            int c = pass == 0 ? owner[f] : neighbour[f];
+            int s = cellOff[c] + cnt[c]++;
+            int b = faceOff[f], nv = faceOff[f + 1] - faceOff[f];
+            v3 est = V(0, 0, 0);
+            for (int i = 0; i < nv; ++i) {
+                const double* p = points + 3 * faceVerts[b + i];
+                est = add(est, V(p[0], p[1], p[2]));
+            }
+            est = V(est.x / nv, est.y / nv, est.z / nv);
+            v3 sumN = V(0, 0, 0), sumAc = V(0, 0, 0);
+            double sumA = 0.0;
+            for (int i = 0; i < nv; ++i) {
+                const double* pp = points + 3 * faceVerts[b + i];
+                const double* qq = points + 3 * faceVerts[b + (i + 1 == nv ? 0 : i + 1)];
+                v3 p = V(pp[0], pp[1], pp[2]), q = V(qq[0], qq[1], qq[2]);
+                v3 c3 = add(add(p, q), est);
+                v3 nrm = crossp(sub(q, p), sub(est, p));
+                double a = sqrt(dotp(nrm, nrm));
+                sumN = add(sumN, nrm);
+                sumA += a;
+                sumAc = add(sumAc, V(a * c3.x, a * c3.y, a * c3.z));
+            }
+            v3 Cf = sumA > 0.0 ? V(sumAc.x / (3.0 * sumA), sumAc.y / (3.0 * sumA), sumAc.z / (3.0 * sumA)) : est;
+            double len = sqrt(dotp(sumN, sumN));
+            v3 n = V(sumN.x / len, sumN.y / len, sumN.z / len);   /* owner -> neighbour (outward for owner) */
+            if (pass == 0) n = V(-n.x, -n.y, -n.z);               /* inward for the owner */
+            planes[4 * s] = n.x; planes[4 * s + 1] = n.y; planes[4 * s + 2] = n.z;
+            planes[4 * s + 3] = dotp(n, Cf);
+            if (pass == 0) nbr[s] = f < nInternal ? neighbour[f] : -(f + 1);
+            else nbr[s] = owner[f];
+        }
+    }
+    free(cnt);
+    return cellOff[nCells];
+}
+
+/* One cell of the walk (traceIntet on a polyhedral cell).  `token` identifies the face we came
+ * in through: the previous cell id after a hop, the boundary code after a reflection. */
+static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const double* planes, const int* nbr,
+                         int token, int* outSlot) {
+    const v3 P0 = *Ps;
+    const v3 Pd = sub(Pe, P0);
+    int next = cur;
+    double dTmin = 1.1;
+    for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
+        v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
+        double fd = planes[4 * s + 3] - dotf(n, P0);       /* (Cf - P0).n, <= 0 inside */
+        double dT = fd / dotf(n, Pd);
+        if (isinf(dT)) dT = -1.0;
+        if (nbr[s] == token) continue;
+        if (fd < CW_TOL && dT > CW_TOL && dT <= 1.0 && dT < dTmin) {
+            dTmin = dT;
+            next = nbr[s];
+            *Ps = axpy(dT, Pd, P0);
+            *outSlot = s;
+        }
+    }
+    return next;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11 "Parallel random numbers: as easy as 1, 2, 3"; constants
+ * and known-answer vectors from the Random123 distribution, checked in tests/test_rng.py).
+ * Replaces the reference's per-particle cuRAND XORWOW state (cuda/particles.cu:524-575) with
+ * a stateless counter (global particle id, step) -- Brownian parity is statistical only.
+ * ------------------------------------------------------------------------------------------ */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+void cw_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    memcpy(out, c, sizeof(c));
+}
+/* three N(0,1) deviates for (particle gid, step): one Philox block, Box-Muller on 32-bit uniforms
+ * u = (w + 0.5) * 2^-32 in (0,1). */
+void cw_normal3(uint64_t gid, uint32_t step, uint32_t seed, double out[3]) {
+    uint32_t key[2] = {seed, 0x43504631u /* "CPF1" */};
+    uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0}, w[4];
+    cw_philox4x32_10(ctr, key, w);
+    const double s = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
+    double u0 = ((double)w[0] + 0.5) * s, u1 = ((double)w[1] + 0.5) * s;
+    double u2 = ((double)w[2] + 0.5) * s, u3 = ((double)w[3] + 0.5) * s;
+    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    out[0] = r0 * cos(twopi * u1);
+    out[1] = r0 * sin(twopi * u1);
+    out[2] = r1 * cos(twopi * u3);
+}
+
+typedef struct { long long hops, reflections, lost; } cw_stats;
+
+/* advect + locate + reflect + move for one particle (src/advect.H:96-161, D = 0) */
+static void step_one(int i, double* px, double* py, double* pz, int* cell, double* vel_out, double dt,
+                     const int* cellOff, const double* planes, const int* nbr, const double* U, cw_stats* st,
+                     double D, const int64_t* gid, uint32_t step, uint32_t seed) {
+    int cur = cell[i];
+    if (cur < 0) { if (cur == CW_LOST) cell[i] = CW_FROZEN; return; }
+    const v3 P = V(px[i], py[i], pz[i]);
+    v3 vel = V(U[3 * cur], U[3 * cur + 1], U[3 * cur + 2]);
+    const v3 Pn = axpy(dt, vel, P);
+    v3 disp = sub(Pn, P);                      /* disp = (P + dt*vel) - P, particles.cu:358-359 */
+    if (D > 0.0) {                             /* disp += xi*sqrt(2 D dt), particles.cu:560-569 */
+        double xi[3];
+        cw_normal3((uint64_t)(gid ? gid[i] : i), step, seed, xi);
+        disp = axpy(sqrt(2.00 * D * dt), V(xi[0], xi[1], xi[2]), disp);
+    }
+    v3 Pe = add(P, disp);
+    v3 Ps = P, Phit = P;
+    int token = INT_MIN, next = cur, outSlot = -1, reflected = 0;
+    for (int j = 0; j < CW_MAX_REFLECT; ++j) {
+        for (int h = 0; h < CW_MAX_HOPS; ++h) {
+            next = trace_in_cell(&Ps, Pe, cur, cellOff, planes, nbr, token, &outSlot);
+            st->hops++;
+            if (next == cur) break;
+            if (next < 0) break;
+            token = cur;
+            cur = next;
+        }
+        if (next >= 0) break;                  /* segment ends inside `next` (or hop cap reached) */
+        /* wall: mirror end point and velocity about the boundary face just hit */
+        Phit = Ps; reflected = 1; st->reflections++;
+        v3 n = V(planes[4 * outSlot], planes[4 * outSlot + 1], planes[4 * outSlot + 2]);
+        double sd = dotf(n, Pe) - planes[4 * outSlot + 3];
+        Pe = axpy(-2.0 * sd, n, Pe);
+        vel = axpy(-2.0 * dotf(n, vel), n, vel);
+        token = next;                          /* skip this boundary face when the walk resumes */
+    }
+    v3 Pnew;
+    if (reflected) Pnew = add(Phit, sub(Pe, Phit));   /* p = P_hit; disp = P_end - P_hit; p += disp */
+    else Pnew = add(P, disp);
+    px[i] = Pnew.x; py[i] = Pnew.y; pz[i] = Pnew.z;
+    if (next < 0) { next = CW_LOST; st->lost++; }
+    cell[i] = next;
+    if (vel_out) { vel_out[3 * i] = vel.x; vel_out[3 * i + 1] = vel.y; vel_out[3 * i + 2] = vel.z; }
+}
+
+void cw_step(double* px, double* py, double* pz, int* cell, double* vel_out, int n, double dt, int cycles,
+             const int* cellOff, const double* planes, const int* nbr, const double* U, int nthreads,
+             long long* stats /* [hops, reflections, lost] or NULL */,
+             double D, const int64_t* gid, uint32_t step0, uint32_t seed) {
+    long long H = 0, R = 0, L = 0;
+    for (int c = 0; c < cycles; ++c) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : H, R, L)
+        for (int i = 0; i < n; ++i) {
+            cw_stats st = {0, 0, 0};
+            step_one(i, px, py, pz, cell, vel_out, dt, cellOff, planes, nbr, U, &st, D, gid, step0 + (uint32_t)c, seed);
+            H += st.hops; R += st.reflections; L += st.lost;
+        }
+    }
+    if (stats) { stats[0] = H; stats[1] = R; stats[2] = L; }
+}
+
+/* Initial locate contract (query/RTQuery.cu:295-310: containing element id, < 0 if outside):
+ * the LOWEST cell id whose every face has (Cf - P).n <= 0; -1 if none.  Brute force. */
+void cw_locate_initial(const double* px, const double* py, const double* pz, int* cell, int n, int nCells,
+                       const int* cellOff, const double* planes, int nthreads) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        v3 P = V(px[i], py[i], pz[i]);
+        int found = -1;
+        for (int c = 0; c < nCells && found < 0; ++c) {
+            int inside = 1;
+            for (int s = cellOff[c]; s < cellOff[c + 1]; ++s) {
+                v3 nn = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
+                if (!(planes[4 * s + 3] - dotf(nn, P) <= 0.0)) { inside = 0; break; }
+            }
+            if (inside) found = c;
+        }
+        cell[i] = found;
+    }
+}
+
+int cw_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
