@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mparticle-steps/s of the fused advect+locate+reflect+move cycle on the
+pitzDaily mesh (12 225 cells), uniform U = (10,0,0) m/s, dt = 1e-4 s, D = 0, 1e7 fp64 particles per GPU
+seeded over the whole fluid domain (BASELINE.json configs[2]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one Lagrangian cycle of the whole cloud (one launch of the fused kernel per rank,
+plus the hand-off every --exchange-interval steps when N > 1).  Inputs are resident in HBM when the
+timed region starts.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PARTICLE_STEP = 56      # fp64 SoA: read x,y,z (24) + cell (4), write x,y,z (24) + cell (4)
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU (weak) / total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
+    ap.add_argument("--exchange-interval", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-sort", action="store_true")
+    return ap.parse_args()
+
+
+def seed_in_fluid(ctx, torch, n, box, seed, device):
+    """n points uniform in `box`, rejection-resampled until located in a cell."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    lo = torch.tensor(box[0], dtype=torch.float64, device=device)
+    ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
+    xs, ys, zs, cs = [], [], [], []
+    have = 0
+    while have < n:
+        m = int((n - have) * 1.35) + 1024
+        u = torch.rand((3, m), generator=g, dtype=torch.float64, device=device)
+        x = (lo[0] + u[0] * ext[0]).contiguous(); y = (lo[1] + u[1] * ext[1]).contiguous()
+        z = (lo[2] + u[2] * ext[2]).contiguous()
+        c = torch.empty(m, dtype=torch.int32, device=device)
+        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
+        torch.cuda.synchronize()
+        keep = c >= 0
+        xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
+        have += int(keep.sum())
+    cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
+    return cat(xs), cat(ys), cat(zs), cat(cs)
+
+
+def cpu_baseline(mesh, centres, U, seconds):
+    """The reference's own functions (oracle/_ref, kind "reference") -- or the C restatement of the same
+    algorithm (kind "port") -- timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from oracle.tetmesh import poly_to_tets
+    from cudaparticlesfoam_amd.cases import pitzdaily as pz
+    O.build()
+    cw = O.CellWalk()
+    if O.have_ref():
+        lib, kind = O.RefLib(), "reference"
+    else:
+        lib, kind = O.TetWalk(), "port"
+    pos, tets, tcell, tu = poly_to_tets(mesh, centres, U)
+    m = lib.tables(pos, tets, tu)
+    t = cw.build(mesh)
+    n = 200000
+    xyz = pz.uniform_points(4242, int(n * 1.4), *pz.DOMAIN_BOX)
+    cell = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    xyz = xyz[cell >= 0][:n]; cell = cell[cell >= 0][:n]
+    n = xyz.shape[0]
+    P = np.zeros((n, 4)); P[:, :3] = xyz; P[:, 3] = 1
+    ids = (cell * 12).astype(np.int32)
+    lib.bary_query(P, ids, m, lib.max_threads)
+    vels = np.zeros((n, 4)); disps = np.zeros((n, 4))
+    th = lib.max_threads
+    t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, 2, m, th); cal = (time.perf_counter() - t0) / 2
+    cycles = int(max(3, min(400, seconds / max(cal, 1e-6))))
+    t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, cycles, m, th); el = time.perf_counter() - t0
+    return dict(value=round(n * cycles / el / 1e6, 3), unit="Mparticle-steps/s", cores=int(th), kind=kind,
+                sample="%d particles x %d cycles, pitzDaily 146700-tet decomposition, uniform U, OpenMP over "
+                       "particles, %.1f s" % (n, cycles, el))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    import torch
+    import torch.distributed as dist
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import Context
+    from cudaparticlesfoam_amd.cases import pitzdaily as pz
+    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges, x_slab_renumbering
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- synthetic case: pitzDaily mesh renumbered into x-slabs (same mesh for every N)
+    mesh0 = pz.pitzdaily_mesh()
+    c0, _ = mesh0.cell_centres_volumes()
+    mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
+    centres, vols = mesh.cell_centres_volumes()
+    U = pz.uniform_u(mesh) if args.field == "uniform" else pz.analytic_step_u(mesh, centres)
+    cell_lo = slab_cell_ranges(vols, world)
+
+    ctx = Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_mesh(mesh)
+    ctx.set_velocity(U)
+
+    n_total = int(args.particles) * (world if args.scaling == "weak" else 1)
+    n_local = n_total // world
+    x, y, z, c = seed_in_fluid(ctx, torch, n_local, pz.DOMAIN_BOX, 1000 + rank, device)
+    gid = torch.arange(n_local, dtype=torch.int64, device=device) + rank * n_local
+    cloud = ShardedCloud(HipOps(ctx), cell_lo, int(n_local * 1.3) + 4096, device, rank, world,
+                         exchange_interval=args.exchange_interval)
+    cloud.set_particles(x, y, z, c, gid)
+    del x, y, z, c, gid
+    if world > 1:
+        cloud.exchange()                      # move every particle to its owner before timing
+    if not args.no_sort:
+        cloud.sort()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    dt = 1e-4
+    cloud.step(dt, args.warmup)
+    torch.cuda.synchronize(); barrier()
+    n_before = cloud.global_count()
+    ctx.timing_enable(True)
+    handed0 = cloud.handed_off
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    cloud.step(dt, args.steps)
+    torch.cuda.synchronize(); barrier()
+    el = time.perf_counter() - t0
+    launches, kernel_ms = ctx.timing_read()
+    ctx.timing_enable(False)
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    n_after = cloud.global_count()
+    counters = ctx.counters()
+
+    if rank == 0:
+        value = n_before * args.steps / el / 1e6
+        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        achieved = ALGO_BYTES_PER_PARTICLE_STEP * cloud.n / avg_kernel_s / 1e9 if launches else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mparticle-steps/s", "value": round(value, 2), "unit": "Mparticle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "pitzDaily 12225-cell polyMesh (blockMeshDict restated), %s U, dt 1e-4, D 0, "
+                                   "%d fp64 particles/GPU seeded over the fluid domain, all boundaries reflecting"
+                                   % ("uniform (10,0,0)" if args.field == "uniform" else "analytic step-flow", n_local),
+                       "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
+                       "exchange_interval": args.exchange_interval if world > 1 else None,
+                       "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
+                                                     if world > 1 else None),
+                       "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
+                       "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
+                       "sorted_by_cell": not args.no_sort},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "cpf::step_kernel<false,true,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
+                         "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * cloud.n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(mesh, centres, U, args.cpu_seconds)
+            except Exception as e:          # the checker being absent must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
+                                       "sample": "unavailable: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""ctypes binding of ``libcudaParticleAdvection.so`` -- exactly the symbols ``include/cpf.h`` declares.
+
+There is NO fallback: if the library is missing, or the box has no HIP device, the product
+path raises.  (The CPU restatements under ``oracle/`` are test infrastructure and are never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libcudaParticleAdvection.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "cpf.h")
+
+CPF_OK, CPF_ERR_ARG, CPF_ERR_STATE, CPF_ERR_MESH, CPF_ERR_HIP, CPF_ERR_NOMEM = range(6)
+CELL_LOST, CELL_FROZEN = -1, -2
+STEP_DEFAULT, STEP_NO_REFLECT, STEP_STORE_VEL, STEP_FUSE_CYCLES = 0, 1, 2, 4
+HANDOFF_DOUBLES = 5
+
+
+class CpfError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("cpf status %d: %s" % (status, message))
+        self.status = status
+
+
+class LibraryMissing(ImportError):
+    pass
+
+
+_vp, _i64, _i32, _u32, _dbl, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_int
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/cpf.h one to one
+SIGNATURES = {
+    "cpf_abi_version": (_int, []),
+    "cpf_create": (_int, [_int, C.POINTER(_ctx)]),
+    "cpf_destroy": (_int, [_ctx]),
+    "cpf_last_error": (C.c_char_p, [_ctx]),
+    "cpf_set_stream": (_int, [_ctx, _vp]),
+    "cpf_synchronize": (_int, [_ctx]),
+    "cpf_set_mesh": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
+    "cpf_set_mesh_l64": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
+    "cpf_mesh_info": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "cpf_get_mesh_tables": (_int, [_ctx, _vp, _vp, _vp]),
+    "cpf_set_velocity": (_int, [_ctx, _vp, _i64]),
+    "cpf_set_velocity_dev": (_int, [_ctx, _vp, _i64]),
+    "cpf_alloc_particles": (_int, [_ctx, _i64]),
+    "cpf_seed_box": (_int, [_ctx, _i64, _vp, _vp, _int]),
+    "cpf_set_particles": (_int, [_ctx, _i64, _vp, _vp]),
+    "cpf_locate_initial": (_int, [_ctx, C.POINTER(_i64)]),
+    "cpf_step": (_int, [_ctx, _dbl, _dbl, _int, C.c_uint]),
+    "cpf_sort_by_cell": (_int, [_ctx]),
+    "cpf_num_particles": (_int, [_ctx, C.POINTER(_i64)]),
+    "cpf_get_particles": (_int, [_ctx, _vp, _vp, _vp]),
+    "cpf_get_counters": (_int, [_ctx, _vp]),
+    "cpf_set_seed": (_int, [_ctx, _u32]),
+    "cpf_step_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _u32, _int, C.c_uint]),
+    "cpf_locate_initial_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),
+    "cpf_seed_box_dev": (_int, [_ctx, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int]),
+    "cpf_sort_by_cell_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "cpf_pack_leavers_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _int, _vp, _i64, _vp, _vp]),
+    "cpf_unpack_arrivals_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64]),
+    "cpf_timing_enable": (_int, [_ctx, _int]),
+    "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
+}
+
+_lib = None
+
+
+def header_symbols(path: str = HEADER_PATH):
+    """Function names declared in include/cpf.h (used by the symbol-export test)."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpf_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C cudaparticlesfoam_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library mismatch: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cpf_abi_version() != 1:
+        raise LibraryMissing("libcudaParticleAdvection.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, status: int) -> None:
+    if status != CPF_OK:
+        msg = lib.cpf_last_error(ctx)
+        raise CpfError(status, (msg or b"").decode("utf-8", "replace"))

@@ -1,0 +1,258 @@
+"""Python host side above the C-ABI.
+
+``Context`` is a thin object wrapper over ``include/cpf.h`` (numpy in / numpy out).
+``CudaParticles`` mirrors the reference's two header fragments -- the only "operator
+interface" the reference has for this path:
+
+* ``CudaParticles(mesh, U, dict)``        == ``#include "initCuda.H"`` (src/initCuda.H:33-205)
+* ``CudaParticles.advect(time, deltaT)``  == ``#include "advect.H"``   (src/advect.H:33-205)
+
+with the same dictionary keys and defaults (src/initCuda.H:50-57), the same
+``nCycles = max(ceil(deltaT/dt), 1)`` sub-cycling (src/advect.H:36-37) and the same
+output cadence (src/advect.H:166).  All compute happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU, one mesh, one (optional) context-owned particle cloud."""
+
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.cpf_create(device, C.byref(h))
+        if st != L.CPF_OK:
+            raise L.CpfError(st, (self.lib.cpf_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+        self.n_cells = 0
+
+    # -- plumbing
+    def _ck(self, st):
+        L.check(self.lib, self.h, st)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cpf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, hip_stream: int):
+        self._ck(self.lib.cpf_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._ck(self.lib.cpf_synchronize(self.h))
+
+    # -- mesh / velocity
+    def set_mesh(self, mesh):
+        """``mesh`` exposes points, face_offsets, face_verts, owner, neighbour, n_cells (cases.PolyMesh)."""
+        lab = np.int64 if np.asarray(mesh.owner).dtype == np.int64 else np.int32
+        pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+        fo = np.ascontiguousarray(mesh.face_offsets, dtype=lab)
+        fv = np.ascontiguousarray(mesh.face_verts, dtype=lab)
+        ow = np.ascontiguousarray(mesh.owner, dtype=lab)
+        ne = np.ascontiguousarray(mesh.neighbour, dtype=lab)
+        fn = self.lib.cpf_set_mesh_l64 if lab == np.int64 else self.lib.cpf_set_mesh
+        self._ck(fn(self.h, _ptr(pts), pts.shape[0], _ptr(fo), _ptr(fv), ow.shape[0], _ptr(ow), _ptr(ne), ne.shape[0],
+                    int(mesh.n_cells)))
+        self.n_cells = int(mesh.n_cells)
+
+    def mesh_info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.cpf_mesh_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_cells=a.value, n_slots=b.value, device_bytes=c.value)
+
+    def mesh_tables(self):
+        info = self.mesh_info()
+        off = np.empty(info["n_cells"] + 1, np.int32)
+        planes = np.empty((info["n_slots"], 4), np.float64)
+        nbr = np.empty(info["n_slots"], np.int32)
+        self._ck(self.lib.cpf_get_mesh_tables(self.h, _ptr(off), _ptr(planes), _ptr(nbr)))
+        return off, planes, nbr
+
+    def set_velocity(self, U):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        if U.ndim != 2 or U.shape[1] != 3:
+            raise ValueError("U must be (nCells, 3)")
+        self._ck(self.lib.cpf_set_velocity(self.h, _ptr(U), U.shape[0]))
+
+    def set_velocity_dev(self, ptr: int, n_cells: int):
+        self._ck(self.lib.cpf_set_velocity_dev(self.h, C.c_void_p(ptr), n_cells))
+
+    # -- context-owned cloud
+    def seed_box(self, n: int, lower, upper, order: int = 1):
+        lo = np.ascontiguousarray(lower, dtype=np.float64); hi = np.ascontiguousarray(upper, dtype=np.float64)
+        self._ck(self.lib.cpf_seed_box(self.h, int(n), _ptr(lo), _ptr(hi), order))
+
+    def set_particles(self, xyz, cell=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        c = None if cell is None else np.ascontiguousarray(cell, dtype=np.int32)
+        self._ck(self.lib.cpf_set_particles(self.h, xyz.shape[0], _ptr(xyz), _ptr(c)))
+
+    def locate_initial(self) -> int:
+        out = C.c_int64()
+        self._ck(self.lib.cpf_locate_initial(self.h, C.byref(out)))
+        return out.value
+
+    def step(self, dt: float, D: float = 0.0, n_cycles: int = 1, flags: int = 0):
+        self._ck(self.lib.cpf_step(self.h, dt, D, n_cycles, flags))
+
+    def sort_by_cell(self):
+        self._ck(self.lib.cpf_sort_by_cell(self.h))
+
+    @property
+    def n(self) -> int:
+        out = C.c_int64()
+        self._ck(self.lib.cpf_num_particles(self.h, C.byref(out)))
+        return out.value
+
+    def get_particles(self, want_vel: bool = False):
+        n = self.n
+        xyzw = np.empty((n, 4)); cell = np.empty(n, np.int32)
+        vel = np.empty((n, 4)) if want_vel else None
+        self._ck(self.lib.cpf_get_particles(self.h, _ptr(xyzw), _ptr(cell), _ptr(vel)))
+        return (xyzw, cell, vel) if want_vel else (xyzw, cell)
+
+    def counters(self) -> Dict[str, int]:
+        out = np.zeros(4, np.int64)
+        self._ck(self.lib.cpf_get_counters(self.h, _ptr(out)))
+        return dict(particle_steps=int(out[0]), cells_visited=int(out[1]), reflections=int(out[2]), lost=int(out[3]))
+
+    def set_seed(self, seed: int):
+        self._ck(self.lib.cpf_set_seed(self.h, seed & 0xFFFFFFFF))
+
+    # -- device-array level (pointers as ints, e.g. torch.Tensor.data_ptr())
+    def step_dev(self, x, y, z, cell, gid, vel, n, dt, D=0.0, step0=0, n_cycles=1, flags=0):
+        self._ck(self.lib.cpf_step_dev(self.h, x, y, z, cell, gid, vel, n, dt, D, step0, n_cycles, flags))
+
+    def locate_initial_dev(self, x, y, z, cell, n):
+        self._ck(self.lib.cpf_locate_initial_dev(self.h, x, y, z, cell, n))
+
+    def seed_box_dev(self, x, y, z, first, n, lower, upper, order=1):
+        lo = np.ascontiguousarray(lower, dtype=np.float64); hi = np.ascontiguousarray(upper, dtype=np.float64)
+        self._ck(self.lib.cpf_seed_box_dev(self.h, x, y, z, first, n, _ptr(lo), _ptr(hi), order))
+
+    def sort_by_cell_dev(self, x, y, z, cell, gid, n):
+        self._ck(self.lib.cpf_sort_by_cell_dev(self.h, x, y, z, cell, gid, n))
+
+    def pack_leavers_dev(self, x, y, z, cell, gid, n, cell_lo, n_ranks, my_rank, sendbuf, send_cap, counts, n_stay):
+        self._ck(self.lib.cpf_pack_leavers_dev(self.h, x, y, z, cell, gid, n, cell_lo, n_ranks, my_rank, sendbuf,
+                                               send_cap, counts, n_stay))
+
+    def unpack_arrivals_dev(self, x, y, z, cell, gid, n_stay, recvbuf, n_recv):
+        self._ck(self.lib.cpf_unpack_arrivals_dev(self.h, x, y, z, cell, gid, n_stay, recvbuf, n_recv))
+
+    def timing_enable(self, on: bool = True):
+        self._ck(self.lib.cpf_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        a, b = C.c_int64(), C.c_double()
+        self._ck(self.lib.cpf_timing_read(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+# ------------------------------------------------------------------------------------------------
+# the fragments' call surface
+# ------------------------------------------------------------------------------------------------
+DICT_DEFAULTS = dict(                       # src/initCuda.H:49-57 (getOrDefault values)
+    seedingBox=((0.0, 0.0, 0.0), (30.0, 30.0, 30.0)), numParticles=1000, startTime=0.0, endTime=1e05,
+    dt=1e-4, diffusionCoeff=5.7e-6, saveInterval=10)
+
+
+class CudaParticles:
+    """What ``initCuda.H`` sets up and ``advect.H`` advances, for one solver process.
+
+    ``writer(step, xyzw, vel, cell)`` is called with the cadence of
+    ``writeParticles2VTU`` (frame 0 at init, then ``step % saveInterval == 0`` or at
+    ``endTime``, src/initCuda.H:201, src/advect.H:166-169).
+    """
+
+    def __init__(self, mesh, U, particle_dict: Optional[dict] = None, device: int = 0,
+                 writer: Optional[Callable] = None, positions: Optional[np.ndarray] = None, seed_order: int = 1):
+        d = dict(DICT_DEFAULTS)
+        d.update(particle_dict or {})
+        self.numParticles = int(d["numParticles"])
+        self.particleStartTime = float(d["startTime"])
+        self.particleEndTime = float(d["endTime"])
+        self.dt = float(d["dt"])
+        self.diffusionCoeff = float(d["diffusionCoeff"])
+        self.saveInterval = int(d["saveInterval"])
+        self.seedingBox = d["seedingBox"]
+        # hard-coded switches of the fragment (src/initCuda.H:64-72)
+        self.usingAdvection = True
+        self.usingBrownianMotion = True
+        self.reflectWall = True
+        self.step = 0
+        self.writer = writer
+        self.ctx = Context(device)
+        self.ctx.set_mesh(mesh)
+        self.ctx.set_velocity(U)
+        if positions is not None:            # parity runs inject positions
+            self.ctx.set_particles(positions)
+            self.numParticles = int(np.asarray(positions).shape[0])
+        else:
+            lo, hi = self.seedingBox
+            self.ctx.seed_box(self.numParticles, lo, hi, seed_order)
+        self.outOfDomain = self.ctx.locate_initial()       # RTQuery + cudaReportParticles
+        self.ctx.sort_by_cell()
+        if self.writer is not None:
+            self._write(0)
+
+    def _flags(self, store_vel: bool) -> int:
+        f = 0
+        if not self.reflectWall:
+            f |= L.STEP_NO_REFLECT
+        if store_vel:
+            f |= L.STEP_STORE_VEL
+        return f
+
+    def _write(self, frame: int):
+        xyzw, cell, vel = self.ctx.get_particles(want_vel=True)
+        self.writer(frame, xyzw, vel, cell)
+
+    def advect(self, run_time_value: float, delta_t: float, U=None) -> int:
+        """One ``#include "advect.H"``: returns the number of Lagrangian cycles done."""
+        if not (self.particleStartTime <= run_time_value <= self.particleEndTime):     # advect.H:33
+            return 0
+        n_cycles = max(int(math.ceil(delta_t / self.dt)), 1)                           # advect.H:36
+        cycle_dt = delta_t / n_cycles                                                  # advect.H:37
+        if U is not None:                                                              # advect.H:44-57
+            self.ctx.set_velocity(U)
+        D = self.diffusionCoeff if self.usingBrownianMotion else 0.0
+        for _ in range(n_cycles):                                                      # advect.H:86
+            will_write = self.writer is not None and (
+                self.step % self.saveInterval == 0 or run_time_value == self.particleEndTime)
+            self.ctx.step(cycle_dt, D, 1, self._flags(will_write))
+            if will_write:                                                             # advect.H:166-169
+                self._write(self.step + 1)
+            self.step += 1                                                             # advect.H:182
+        return n_cycles
+
+    def particles(self):
+        return self.ctx.get_particles()
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,516 @@
+// C-ABI layer of libcudaParticleAdvection.so: context, device memory, call-order checks, errors.
+// Every entry point declared in include/cpf.h is defined here; kernels live in cpf_kernels.hip
+// and cpf_handoff.hip, the host-side mesh ingest in cpf_mesh.cpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "cpf.h"
+#include "cpf_device.h"
+#include "cpf_internal.h"
+
+struct cpf_context {
+    int device = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    mutable std::string err;
+    // mesh
+    bool haveMesh = false, haveU = false;
+    cpf::HostTables host;
+    int32_t* d_cellOff = nullptr;
+    double4* d_planes = nullptr;
+    int32_t* d_nbr = nullptr;
+    double4* d_U = nullptr;
+    double* d_U3 = nullptr;     // staging for host uploads
+    int32_t* d_binOff = nullptr;
+    int32_t* d_binCells = nullptr;
+    size_t meshBytes = 0;
+    // owned cloud
+    int64_t cap = 0, n = 0;
+    double *x = nullptr, *y = nullptr, *z = nullptr, *vel = nullptr;
+    int32_t* cell = nullptr;
+    int64_t* gid = nullptr;
+    bool located = false;
+    // scratch
+    void* scratch = nullptr;
+    size_t scratchBytes = 0;
+    // counters / rng
+    unsigned long long* d_counters = nullptr;   // steps, hops, reflections, lost, + 1 spare
+    uint32_t seed = 1591593751u;                // cuda/particles.cu:544
+    uint32_t stepCounter = 0;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> eventPool;
+};
+
+namespace {
+
+std::string g_createError = "";
+std::mutex g_mutex;
+
+int fail(const cpf_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else { std::lock_guard<std::mutex> lk(g_mutex); g_createError = msg; }
+    return code;
+}
+
+#define CPF_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(ctx, CPF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+#define CPF_REQUIRE(ctx, cond, code, msg) \
+    do { if (!(cond)) return fail(ctx, code, msg); } while (0)
+
+template <typename T>
+void freeDev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+cpf::MeshView meshView(const cpf_context* c) {
+    cpf::MeshView m;
+    m.cellOff = c->d_cellOff; m.planes = c->d_planes; m.nbr = c->d_nbr; m.U = c->d_U;
+    m.nCells = (int32_t)c->host.nCells;
+    return m;
+}
+cpf::GridView gridView(const cpf_context* c) {
+    cpf::GridView g;
+    for (int k = 0; k < 3; ++k) {
+        g.origin[k] = c->host.origin[k]; g.invBin[k] = c->host.invBin[k];
+        g.lo[k] = c->host.lo[k]; g.hi[k] = c->host.hi[k]; g.dims[k] = c->host.dims[k];
+    }
+    g.binOff = c->d_binOff; g.binCells = c->d_binCells;
+    return g;
+}
+
+int ensureScratch(cpf_context* ctx, size_t bytes) {
+    if (bytes <= ctx->scratchBytes) return CPF_OK;
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeDev(ctx->scratch);
+    ctx->scratchBytes = 0;
+    CPF_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratchBytes = bytes;
+    return CPF_OK;
+}
+
+int sortEndBit(const cpf_context* ctx) {
+    int bits = 1;
+    while (((int64_t)1 << bits) < ctx->host.nCells + 2) ++bits;   // keeps -1/-2 (all-ones low bits) at the tail
+    return std::min(bits, 32);
+}
+
+void freeMesh(cpf_context* c) {
+    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3);
+    freeDev(c->d_binOff); freeDev(c->d_binCells);
+    c->haveMesh = c->haveU = false; c->meshBytes = 0;
+}
+void freeCloud(cpf_context* c) {
+    freeDev(c->x); freeDev(c->y); freeDev(c->z); freeDev(c->vel); freeDev(c->cell); freeDev(c->gid);
+    c->cap = c->n = 0; c->located = false;
+}
+
+template <typename Label>
+int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const Label* faceOffsets,
+                const Label* faceVerts, int64_t nFaces, const Label* owner, const Label* neighbour,
+                int64_t nInternal, int64_t nCells) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, points && faceOffsets && faceVerts && owner && (neighbour || nInternal == 0), CPF_ERR_ARG,
+                "cpf_set_mesh: null array");
+    cpf::HostTables t;
+    std::string why = cpf::build_tables<Label>(points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour,
+                                               nInternal, nCells, t);
+    if (!why.empty()) return fail(ctx, CPF_ERR_MESH, "cpf_set_mesh: " + why);
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeMesh(ctx);
+    ctx->host = std::move(t);
+    const cpf::HostTables& h = ctx->host;
+    auto up = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc((void**)&dptr, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        ctx->meshBytes += bytes;
+        return hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    CPF_HIP(ctx, up(ctx->d_cellOff, h.cellOff.data(), h.cellOff.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_planes, h.planes.data(), h.planes.size() * 8));
+    CPF_HIP(ctx, up(ctx->d_nbr, h.nbr.data(), h.nbr.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_binOff, h.binOff.data(), h.binOff.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_binCells, h.binCells.data(), h.binCells.size() * 4));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U, (size_t)nCells * sizeof(double4)));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U3, (size_t)nCells * 3 * sizeof(double)));
+    CPF_HIP(ctx, hipMemset(ctx->d_U, 0, (size_t)nCells * sizeof(double4)));
+    ctx->meshBytes += (size_t)nCells * (sizeof(double4) + 24);
+    ctx->haveMesh = true;
+    ctx->located = false;
+    return CPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpf_abi_version(void) { return CPF_ABI_VERSION; }
+
+int cpf_create(int device, cpf_context** out) {
+    if (!out) return fail(nullptr, CPF_ERR_ARG, "cpf_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, CPF_ERR_HIP,
+                    std::string("cpf_create: no HIP device available (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= count) return fail(nullptr, CPF_ERR_ARG, "cpf_create: device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, CPF_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    cpf_context* ctx = new (std::nothrow) cpf_context();
+    if (!ctx) return fail(nullptr, CPF_ERR_NOMEM, "cpf_create: out of host memory");
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        std::string m = std::string("cpf_create: ") + hipGetErrorString(e);
+        if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+        delete ctx;
+        return fail(nullptr, CPF_ERR_HIP, m);
+    }
+    ctx->stream = ctx->ownStream;
+    *out = ctx;
+    return CPF_OK;
+}
+
+int cpf_destroy(cpf_context* ctx) {
+    if (!ctx) return CPF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    freeMesh(ctx); freeCloud(ctx);
+    freeDev(ctx->scratch); freeDev(ctx->d_counters);
+    for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+    return CPF_OK;
+}
+
+const char* cpf_last_error(const cpf_context* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_mutex);
+    return g_createError.c_str();
+}
+
+int cpf_set_stream(cpf_context* ctx, void* hip_stream) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
+    return CPF_OK;
+}
+
+int cpf_synchronize(cpf_context* ctx) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPF_OK;
+}
+
+int cpf_set_mesh(cpf_context* ctx, const double* points, int64_t nPoints, const int32_t* faceOffsets,
+                 const int32_t* faceVerts, int64_t nFaces, const int32_t* owner, const int32_t* neighbour,
+                 int64_t nInternal, int64_t nCells) {
+    return setMeshImpl<int32_t>(ctx, points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour, nInternal,
+                                nCells);
+}
+int cpf_set_mesh_l64(cpf_context* ctx, const double* points, int64_t nPoints, const int64_t* faceOffsets,
+                     const int64_t* faceVerts, int64_t nFaces, const int64_t* owner, const int64_t* neighbour,
+                     int64_t nInternal, int64_t nCells) {
+    return setMeshImpl<int64_t>(ctx, points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour, nInternal,
+                                nCells);
+}
+
+int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nSlots, int64_t* deviceBytes) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_mesh_info: no mesh set");
+    if (nCells) *nCells = ctx->host.nCells;
+    if (nSlots) *nSlots = ctx->host.nSlots;
+    if (deviceBytes) *deviceBytes = (int64_t)ctx->meshBytes;
+    return CPF_OK;
+}
+
+int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes, int32_t* nbr) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_get_mesh_tables: no mesh set");
+    const cpf::HostTables& h = ctx->host;
+    if (cellOff) std::memcpy(cellOff, h.cellOff.data(), h.cellOff.size() * 4);
+    if (planes) std::memcpy(planes, h.planes.data(), h.planes.size() * 8);
+    if (nbr) std::memcpy(nbr, h.nbr.data(), h.nbr.size() * 4);
+    return CPF_OK;
+}
+
+int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_velocity: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, U && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity: U is null or nCells differs from the mesh");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->d_U3, U, (size_t)nCells * 24, hipMemcpyHostToDevice, ctx->stream));
+    CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, ctx->d_U3, ctx->d_U, nCells));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // U may be pageable host memory owned by the caller
+    ctx->haveU = true;
+    return CPF_OK;
+}
+
+int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_velocity_dev: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, dU && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity_dev: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, dU, ctx->d_U, nCells));
+    ctx->haveU = true;
+    return CPF_OK;
+}
+
+int cpf_alloc_particles(cpf_context* ctx, int64_t capacity) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, capacity > 0 && capacity < ((int64_t)1 << 31), CPF_ERR_ARG, "cpf_alloc_particles: capacity must be in (0, 2^31)");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeCloud(ctx);
+    const size_t c = (size_t)capacity;
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->x, c * 8));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->y, c * 8));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->z, c * 8));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->vel, c * 24));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->cell, c * 4));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->gid, c * 8));
+    CPF_HIP(ctx, hipMemsetAsync(ctx->vel, 0, c * 24, ctx->stream));          // src/initCuda.H:148-149
+    CPF_HIP(ctx, hipMemsetAsync(ctx->cell, 0xFF, c * 4, ctx->stream));       // -1, src/initCuda.H:145
+    ctx->cap = capacity;
+    return CPF_OK;
+}
+
+int cpf_seed_box(cpf_context* ctx, int64_t n, const double lower[3], const double upper[3], int order) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, lower && upper && n > 0, CPF_ERR_ARG, "cpf_seed_box: bad arguments");
+    if (ctx->cap < n) { int r = cpf_alloc_particles(ctx, n); if (r) return r; }
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_seed_box(ctx->stream, ctx->x, ctx->y, ctx->z, 0, n, lower, upper, order));
+    CPF_HIP(ctx, cpf::launch_iota64(ctx->stream, ctx->gid, n, 0));
+    CPF_HIP(ctx, hipMemsetAsync(ctx->cell, 0xFF, (size_t)n * 4, ctx->stream));
+    ctx->n = n; ctx->located = false;
+    return CPF_OK;
+}
+
+int cpf_set_particles(cpf_context* ctx, int64_t n, const double* xyz, const int32_t* cell) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, xyz && n > 0, CPF_ERR_ARG, "cpf_set_particles: bad arguments");
+    if (ctx->cap < n) { int r = cpf_alloc_particles(ctx, n); if (r) return r; }
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    int r = ensureScratch(ctx, (size_t)n * 24);
+    if (r) return r;
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->scratch, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    CPF_HIP(ctx, cpf::launch_unpack_xyz(ctx->stream, (const double*)ctx->scratch, ctx->x, ctx->y, ctx->z, n));
+    CPF_HIP(ctx, cpf::launch_iota64(ctx->stream, ctx->gid, n, 0));
+    if (cell) CPF_HIP(ctx, hipMemcpyAsync(ctx->cell, cell, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    else CPF_HIP(ctx, hipMemsetAsync(ctx->cell, 0xFF, (size_t)n * 4, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n = n; ctx->located = cell != nullptr;
+    return CPF_OK;
+}
+
+int cpf_locate_initial_dev(cpf_context* ctx, const double* x, const double* y, const double* z, int32_t* cell,
+                           int64_t n) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_locate_initial: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, n >= 0 && (n == 0 || (x && y && z && cell)), CPF_ERR_ARG, "cpf_locate_initial: null array");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_locate_initial(ctx->stream, x, y, z, cell, n, meshView(ctx), gridView(ctx)));
+    return CPF_OK;
+}
+
+int cpf_locate_initial(cpf_context* ctx, int64_t* nOutside) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->n > 0, CPF_ERR_STATE, "cpf_locate_initial: no particles (seed or set them first)");
+    int r = cpf_locate_initial_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->n);
+    if (r) return r;
+    ctx->located = true;
+    if (nOutside) {
+        unsigned long long* cnt = ctx->d_counters + 4;
+        CPF_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+        CPF_HIP(ctx, cpf::launch_count_negative(ctx->stream, ctx->cell, ctx->n, cnt));
+        unsigned long long h = 0;
+        CPF_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *nOutside = (int64_t)h;
+    }
+    return CPF_OK;
+}
+
+int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, const int64_t* gid, double* vel,
+                 int64_t n, double dt, double D, uint32_t step0, int nCycles, unsigned flags) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_step: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, ctx->haveU, CPF_ERR_STATE, "cpf_step: call cpf_set_velocity first");
+    CPF_REQUIRE(ctx, n >= 0 && nCycles >= 0, CPF_ERR_ARG, "cpf_step: negative count");
+    CPF_REQUIRE(ctx, n == 0 || (x && y && z && cell), CPF_ERR_ARG, "cpf_step: null particle array");
+    CPF_REQUIRE(ctx, std::isfinite(dt) && std::isfinite(D) && D >= 0.0, CPF_ERR_ARG, "cpf_step: dt/D not finite or D < 0");
+    const bool storeVel = (flags & CPF_STEP_STORE_VEL) != 0;
+    CPF_REQUIRE(ctx, !storeVel || vel, CPF_ERR_ARG, "cpf_step: CPF_STEP_STORE_VEL needs a vel array");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    const bool reflect = (flags & CPF_STEP_NO_REFLECT) == 0;
+    const cpf::MeshView m = meshView(ctx);
+    const bool fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
+    const int nLaunch = fuse ? (nCycles > 0 ? 1 : 0) : nCycles;
+    const int cycPerLaunch = fuse ? nCycles : 1;
+    for (int c = 0; c < nLaunch; ++c) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->timing) {
+            auto take = [&](hipEvent_t& ev) -> hipError_t {
+                if (!ctx->eventPool.empty()) { ev = ctx->eventPool.back(); ctx->eventPool.pop_back(); return hipSuccess; }
+                return hipEventCreate(&ev);
+            };
+            CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
+            CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        }
+        CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
+                                      reflect, storeVel, m, ctx->d_counters));
+        if (ctx->timing) {
+            CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            ctx->events.emplace_back(e0, e1);
+        }
+    }
+    return CPF_OK;
+}
+
+int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->n > 0, CPF_ERR_STATE, "cpf_step: no particles");
+    CPF_REQUIRE(ctx, ctx->located, CPF_ERR_STATE, "cpf_step: particles have no cells yet (call cpf_locate_initial)");
+    int r = cpf_step_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel, ctx->n, dt, D, ctx->stepCounter,
+                         nCycles, flags);
+    if (r == CPF_OK) ctx->stepCounter += (uint32_t)nCycles;
+    return r;
+}
+
+int cpf_seed_box_dev(cpf_context* ctx, double* x, double* y, double* z, int64_t first, int64_t n,
+                     const double lower[3], const double upper[3], int order) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n >= 0 && first >= 0 && lower && upper && (n == 0 || (x && y && z)), CPF_ERR_ARG, "cpf_seed_box_dev: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_seed_box(ctx->stream, x, y, z, first, n, lower, upper, order));
+    return CPF_OK;
+}
+
+int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_sort_by_cell: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (x && y && z && cell)), CPF_ERR_ARG, "cpf_sort_by_cell: bad arguments");
+    if (n <= 1) return CPF_OK;
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    const int endBit = sortEndBit(ctx);
+    int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
+    if (r) return r;
+    CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, n, endBit, ctx->scratch, ctx->scratchBytes));
+    return CPF_OK;
+}
+
+int cpf_sort_by_cell(cpf_context* ctx) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->n > 0 && ctx->located, CPF_ERR_STATE, "cpf_sort_by_cell: no located particles");
+    return cpf_sort_by_cell_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n);
+}
+
+int cpf_num_particles(const cpf_context* ctx, int64_t* n) {
+    CPF_REQUIRE(ctx, ctx && n, CPF_ERR_ARG, "null argument");
+    *n = ctx->n;
+    return CPF_OK;
+}
+
+int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->n > 0, CPF_ERR_STATE, "cpf_get_particles: no particles");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    int r = ensureScratch(ctx, al(n * 32) + al(n * 4) + al(n * 32));
+    if (r) return r;
+    char* p = (char*)ctx->scratch;
+    double* dX = (double*)p; p += al(n * 32);
+    int32_t* dC = (int32_t*)p; p += al(n * 4);
+    double* dV = (double*)p;
+    CPF_HIP(ctx, cpf::launch_pack_by_gid(ctx->stream, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel,
+                                         xyzw ? dX : nullptr, cell ? dC : nullptr, vel ? dV : nullptr, ctx->n));
+    if (xyzw) CPF_HIP(ctx, hipMemcpyAsync(xyzw, dX, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (cell) CPF_HIP(ctx, hipMemcpyAsync(cell, dC, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (vel) CPF_HIP(ctx, hipMemcpyAsync(vel, dV, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPF_OK;
+}
+
+int cpf_get_counters(cpf_context* ctx, int64_t out[4]) {
+    CPF_REQUIRE(ctx, ctx && out, CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[4];
+    CPF_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k) out[k] = (int64_t)h[k];
+    return CPF_OK;
+}
+
+int cpf_set_seed(cpf_context* ctx, uint32_t seed) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    ctx->seed = seed;
+    return CPF_OK;
+}
+
+int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
+                         const int32_t* cellLo_dev, int nRanks, int myRank, double* sendbuf, int64_t sendCapacity,
+                         int64_t* counts_dev, int64_t* nStay_dev) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && nRanks >= 1 && nRanks <= 16 && myRank >= 0 && myRank < nRanks,
+                CPF_ERR_ARG, "cpf_pack_leavers_dev: bad sizes (1..16 ranks)");
+    CPF_REQUIRE(ctx, cellLo_dev && counts_dev && nStay_dev && (sendbuf || sendCapacity == 0) && (n == 0 || (x && y && z && cell)),
+                CPF_ERR_ARG, "cpf_pack_leavers_dev: null array");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    int r = ensureScratch(ctx, cpf::handoff_scratch_bytes(n, nRanks));
+    if (r) return r;
+    CPF_HIP(ctx, cpf::pack_leavers(ctx->stream, x, y, z, cell, gid, n, cellLo_dev, nRanks, myRank, sendbuf,
+                                   sendCapacity, counts_dev, nStay_dev, ctx->scratch, ctx->scratchBytes));
+    return CPF_OK;
+}
+
+int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
+                            int64_t nStay, const double* recvbuf, int64_t nRecv) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, nStay >= 0 && nRecv >= 0 && (nRecv == 0 || (x && y && z && cell && recvbuf)), CPF_ERR_ARG,
+                "cpf_unpack_arrivals_dev: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::unpack_arrivals(ctx->stream, x, y, z, cell, gid, nStay, recvbuf, nRecv));
+    return CPF_OK;
+}
+
+int cpf_timing_enable(cpf_context* ctx, int on) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    ctx->timing = on != 0;
+    return CPF_OK;
+}
+
+int cpf_timing_read(cpf_context* ctx, int64_t* launches, double* total_ms) {
+    CPF_REQUIRE(ctx, ctx && launches && total_ms, CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (auto& p : ctx->events) {
+        float ms = 0.f;
+        CPF_HIP(ctx, hipEventElapsedTime(&ms, p.first, p.second));
+        tot += (double)ms;
+        ctx->eventPool.push_back(p.first); ctx->eventPool.push_back(p.second);
+    }
+    *launches = (int64_t)ctx->events.size();
+    *total_ms = tot;
+    ctx->events.clear();
+    return CPF_OK;
+}
+
+}  // extern "C"

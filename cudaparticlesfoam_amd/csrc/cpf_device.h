@@ -1,0 +1,56 @@
+// Device-side views and launcher declarations shared by the kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cpf.h"
+
+namespace cpf {
+
+constexpr int kBlock = 256;   // 4 waves of 64
+
+// Mesh as the kernels see it (all arrays resident in HBM, L2-resident for tutorial-size meshes)
+struct MeshView {
+    const int32_t* cellOff;   // [nCells+1]
+    const double4* planes;    // [nSlots]   (nx, ny, nz, d), unit normal into the cell
+    const int32_t* nbr;       // [nSlots]
+    const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
+    int32_t nCells;
+};
+
+struct GridView {
+    double origin[3], invBin[3], lo[3], hi[3];
+    int32_t dims[3];
+    const int32_t* binOff;
+    const int32_t* binCells;
+};
+
+hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                       double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters);
+hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
+                                 int64_t n, const MeshView& m, const GridView& g);
+hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,
+                           const double lower[3], const double upper[3], int order);
+hipError_t launch_iota64(hipStream_t st, int64_t* p, int64_t n, int64_t first);
+hipError_t launch_unpack_xyz(hipStream_t st, const double* xyz, double* x, double* y, double* z, int64_t n);
+hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                              const int64_t* gid, const double* vel, double* xyzw, int32_t* cellOut, double* velOut,
+                              int64_t n);
+hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out);
+hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
+
+size_t sort_scratch_bytes(int64_t n, int endBit);
+hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
+                        int endBit, void* scratch, size_t scratchBytes);
+
+// multi-GPU hand-off (cpf_handoff.hip)
+size_t handoff_scratch_bytes(int64_t n, int nRanks);
+hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
+                        const int32_t* cellLo, int nRanks, int myRank, double* sendbuf, int64_t sendCapacity,
+                        int64_t* counts, int64_t* nStay, void* scratch, size_t scratchBytes);
+hipError_t unpack_arrivals(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
+                           int64_t nStay, const double* recvbuf, int64_t nRecv);
+
+}  // namespace cpf

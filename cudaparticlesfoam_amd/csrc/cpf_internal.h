@@ -1,0 +1,34 @@
+// Internal declarations shared by the host-side mesh ingest and the HIP translation unit.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace cpf {
+
+// Host-built connectivity, laid out exactly as it is uploaded (DESIGN.md "Data layout in HBM").
+struct HostTables {
+    int64_t nCells = 0, nSlots = 0;
+    std::vector<int32_t> cellOff;   // [nCells+1]   CSR offsets, slot order = mesh.cells()[c]
+    std::vector<double> planes;     // [nSlots][4]  unit normal INTO the cell, d = n . faceCentre
+    std::vector<int32_t> nbr;       // [nSlots]     neighbour cell, or -(face+1) on the boundary
+    // uniform bin grid over the mesh bounding box for the initial locate
+    double origin[3] = {0, 0, 0}, invBin[3] = {0, 0, 0}, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int32_t dims[3] = {1, 1, 1};
+    std::vector<int32_t> binOff;    // [nBins+1]
+    std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
+    int32_t maxCellFaces = 0;
+};
+
+// polyMesh -> HostTables.  Returns empty string on success, else the reason (CPF_ERR_MESH).
+template <typename Label>
+std::string build_tables(const double* points, int64_t nPoints, const Label* faceOff, const Label* faceVerts,
+                         int64_t nFaces, const Label* owner, const Label* neighbour, int64_t nInternal,
+                         int64_t nCells, HostTables& out);
+
+extern template std::string build_tables<int32_t>(const double*, int64_t, const int32_t*, const int32_t*, int64_t,
+                                                  const int32_t*, const int32_t*, int64_t, int64_t, HostTables&);
+extern template std::string build_tables<int64_t>(const double*, int64_t, const int64_t*, const int64_t*, int64_t,
+                                                  const int64_t*, const int64_t*, int64_t, int64_t, HostTables&);
+
+}  // namespace cpf

@@ -1,0 +1,417 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the per-timestep particle loop, and their launchers.
+//
+// One fused kernel per Lagrangian cycle replaces the reference's five launches + five device
+// syncs (src/advect.H:96-161): advect -> Brownian kick -> locate (plane-exit walk) -> wall
+// reflect -> move.  The walk runs on the polyMesh cells themselves (CSR face slots with
+// precomputed inward planes), not on a 12-tets-per-cell decomposition, and needs no BVH.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): fp64 like the reference (cuda/common.h:26);
+// dot products and axpy use explicit fma(), nothing else may be contracted (-ffp-contract=off),
+// divisions are IEEE.  tests/ compare bit-for-bit with an independent CPU statement.
+#include "cpf_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace cpf {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+
+__device__ __forceinline__ double dot3(const double4& n, const D3& v) {
+    return fma(n.z, v.z, fma(n.y, v.y, n.x * v.x));
+}
+__device__ __forceinline__ double dot3(const D3& n, const D3& v) {
+    return fma(n.z, v.z, fma(n.y, v.y, n.x * v.x));
+}
+__device__ __forceinline__ D3 axpy(double s, const D3& a, const D3& b) {
+    return {fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)};
+}
+
+constexpr double kTol = 1e-13;     // query/ConvexQuery.cu:42
+constexpr int kMaxHops = 50;       // query/ConvexQuery.cu:169
+constexpr int kMaxReflect = 5;     // query/ConvexQuery.cu:353
+
+// One cell of the walk: traceIntet (query/ConvexQuery.cu:32-131) on a polyhedral cell.
+// Exit through the face slot with the smallest admissible dT in (tol, 1]; the slot we came in
+// through (nbr == token) is skipped.  Returns the next cell (== cur: segment ends here; < 0:
+// boundary code) and advances S to the exit point.
+__device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const MeshView& m, int token,
+                                             int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur;
+    double dTmin = 1.1;
+    const int s0 = m.cellOff[cur], s1 = m.cellOff[cur + 1];
+    for (int s = s0; s < s1; ++s) {
+        const double4 pl = m.planes[s];
+        const double fd = pl.w - dot3(pl, P0);          // (Cf - P0).n  (<= 0 inside)
+        double dT = fd / dot3(pl, Pd);
+        if (__builtin_isinf(dT)) dT = -1.0;             // segment parallel to the face
+        const int nb = m.nbr[s];
+        if (nb == token) continue;
+        if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) {
+            dTmin = dT;
+            next = nb;
+            S = axpy(dT, Pd, P0);
+            outSlot = s;
+        }
+    }
+    return next;
+}
+
+// Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
+// 48-byte-per-particle cuRAND XORWOW state of cuda/particles.cu:524-575 with nothing at all.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ D3 normal3(uint64_t gid, uint32_t step, uint32_t seed) {
+    uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0u};
+    philox4x32_10(c, seed, 0x43504631u);
+    const double s = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
+    const double u0 = ((double)c[0] + 0.5) * s, u1 = ((double)c[1] + 0.5) * s;
+    const double u2 = ((double)c[2] + 0.5) * s, u3 = ((double)c[3] + 0.5) * s;
+    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    double sn, cs;
+    sincos(twopi * u1, &sn, &cs);
+    return {r0 * cs, r0 * sn, r1 * cos(twopi * u3)};
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused step kernel: one thread per particle, nCyc cycles per launch (1 = the reference's
+// per-cycle structure; >1 keeps the particle in registers between cycles)
+// ------------------------------------------------------------------------------------------------
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, double* __restrict__ y,
+                                                      double* __restrict__ z, int32_t* __restrict__ cell,
+                                                      const int64_t* __restrict__ gid, double* __restrict__ vel,
+                                                      int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
+                                                      uint32_t seed, MeshView m,
+                                                      unsigned long long* __restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned nSteps = 0, nHops = 0, nRefl = 0, nLost = 0;
+    if (i < n) {
+        int cur = cell[i];
+        if (cur >= 0) {
+            D3 P = {x[i], y[i], z[i]};
+            D3 v = {0, 0, 0};
+            const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
+            for (int c = 0; c < nCyc; ++c) {
+                if (cur < 0) { cur = CPF_CELL_FROZEN; break; }   // lost in the previous cycle: w = 0
+                ++nSteps;
+                // ---- advect (cuda/particles.cu:355-362): disp = (P + dt*U[cell]) - P
+                const double4 u = m.U[cur];
+                v = {u.x, u.y, u.z};
+                const D3 Pn = axpy(dt, v, P);
+                D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                if (BROWNIAN) {                                  // particles.cu:560-569
+                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+                    disp = axpy(sigma, xi, disp);
+                }
+                // ---- locate + reflect (ConvexQuery.cu:135-216, :320-436)
+                D3 E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                D3 S = P, hit = P;
+                int token = INT32_MIN, next = cur, outSlot = 0;
+                bool reflected = false;
+                for (int j = 0; j < kMaxReflect; ++j) {
+                    for (int h = 0; h < kMaxHops; ++h) {
+                        next = trace_in_cell(S, E, cur, m, token, outSlot);
+                        ++nHops;
+                        if (next == cur || next < 0) break;
+                        token = cur;
+                        cur = next;
+                    }
+                    if (next >= 0 || !REFLECT) break;
+                    // wall: mirror end point and velocity about the boundary face (ConvexQuery.cu:286-309)
+                    hit = S; reflected = true; ++nRefl;
+                    const double4 pl = m.planes[outSlot];
+                    const D3 nn = {pl.x, pl.y, pl.z};
+                    const double sd = dot3(pl, E) - pl.w;
+                    E = axpy(-2.0 * sd, nn, E);
+                    v = axpy(-2.0 * dot3(pl, v), nn, v);
+                    token = next;
+                }
+                // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit
+                if (reflected) P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
+                else P = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                if (next < 0) { next = CPF_CELL_LOST; ++nLost; }
+                cur = next;
+            }
+            x[i] = P.x; y[i] = P.y; z[i] = P.z;
+            cell[i] = cur;
+            if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
+        } else if (cur == CPF_CELL_LOST) {
+            cell[i] = CPF_CELL_FROZEN;
+        }
+    }
+    // block-level counter reduction: 4 global atomics per block
+    __shared__ unsigned sCnt[4];
+    if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    nSteps = wave_sum(nSteps); nHops = wave_sum(nHops); nRefl = wave_sum(nRefl); nLost = wave_sum(nLost);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sCnt[0], nSteps); atomicAdd(&sCnt[1], nHops);
+        atomicAdd(&sCnt[2], nRefl); atomicAdd(&sCnt[3], nLost);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && sCnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
+}
+
+template <bool B, bool R>
+static void launch_step_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
+                           const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
+                           int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
+    if (storeVel)
+        hipLaunchKernelGGL((step_kernel<B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
+                           step0, nCyc, seed, m, counters);
+    else
+        hipLaunchKernelGGL((step_kernel<B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
+                           step0, nCyc, seed, m, counters);
+}
+
+hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                       double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    const bool brown = D > 0.0;
+    const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
+    if (brown) {
+        if (reflect) launch_step_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+        else launch_step_sv<true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    } else {
+        if (reflect) launch_step_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+        else launch_step_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// initial locate: bin grid + point-in-convex-cell plane test (replaces OptiX query + baryQuery,
+// query/RTQuery.cu:295-310).  Lowest-numbered containing cell wins (bins list cells ascending).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void locate_initial_kernel(const double* __restrict__ x,
+                                                                const double* __restrict__ y,
+                                                                const double* __restrict__ z,
+                                                                int32_t* __restrict__ cell, int64_t n, MeshView m,
+                                                                GridView g) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const D3 P = {x[i], y[i], z[i]};
+    int found = CPF_CELL_LOST;
+    const bool inBox = P.x >= g.lo[0] && P.x <= g.hi[0] && P.y >= g.lo[1] && P.y <= g.hi[1] && P.z >= g.lo[2] &&
+                       P.z <= g.hi[2];
+    if (inBox) {
+        int b[3];
+        const double pv[3] = {P.x, P.y, P.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            long long q = (long long)floor((pv[k] - g.origin[k]) * g.invBin[k]);
+            q = q < 0 ? 0 : (q > g.dims[k] - 1 ? g.dims[k] - 1 : q);
+            b[k] = (int)q;
+        }
+        const int64_t bin = ((int64_t)b[2] * g.dims[1] + b[1]) * g.dims[0] + b[0];
+        for (int k = g.binOff[bin]; k < g.binOff[bin + 1] && found < 0; ++k) {
+            const int c = g.binCells[k];
+            bool inside = true;
+            for (int s = m.cellOff[c]; s < m.cellOff[c + 1]; ++s) {
+                const double4 pl = m.planes[s];
+                if (!(pl.w - dot3(pl, P) <= 0.0)) { inside = false; break; }
+            }
+            if (inside) found = c;
+        }
+    }
+    cell[i] = found;
+}
+
+hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
+                                 int64_t n, const MeshView& m, const GridView& g) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(locate_initial_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y,
+                       z, cell, n, m, g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeding: cudaInitParticles (cuda/particles.cu:78-108) + LCG<16> (owl/common/math/random.h:56-91)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void seed_box_kernel(double* __restrict__ x, double* __restrict__ y,
+                                                          double* __restrict__ z, int64_t first, int64_t n,
+                                                          D3 lower, D3 size, int order) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const int64_t id = first + k;
+    uint32_t v0 = (uint32_t)(id % 128), v1 = (uint32_t)(id / 128), s0 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    uint32_t state = v0;
+    float r[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        state = 1664525u * state + 1013904223u;
+        r[q] = ldexpf((float)state, -32);
+    }
+    if (order) { const float t = r[0]; r[0] = r[2]; r[2] = t; }
+    x[k] = lower.x + (double)r[0] * size.x;
+    y[k] = lower.y + (double)r[1] * size.y;
+    z[k] = lower.z + (double)r[2] * size.z;
+}
+
+hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,
+                           const double lower[3], const double upper[3], int order) {
+    if (n <= 0) return hipSuccess;
+    const D3 lo = {lower[0], lower[1], lower[2]};
+    const D3 sz = {upper[0] - lower[0], upper[1] - lower[1], upper[2] - lower[2]};
+    hipLaunchKernelGGL(seed_box_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y, z,
+                       first, n, lo, sz, order);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void iota_kernel(int32_t* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+__global__ void iota64_kernel(int64_t* p, int64_t n, int64_t first) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = first + i;
+}
+template <typename T>
+__global__ void gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const int32_t* __restrict__ perm,
+                              int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+// AoS <-> SoA conversion for the reference-shaped accessors (Particle = double4)
+__global__ void unpack_xyz_kernel(const double* __restrict__ xyz, double* x, double* y, double* z, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { x[i] = xyz[3 * i]; y[i] = xyz[3 * i + 1]; z[i] = xyz[3 * i + 2]; }
+}
+// scatter back to original-id order: out[gid] = (x,y,z,w)
+__global__ void pack_by_gid_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                   const double* __restrict__ z, const int32_t* __restrict__ cell,
+                                   const int64_t* __restrict__ gid, const double* __restrict__ vel,
+                                   double* __restrict__ xyzw, int32_t* __restrict__ cellOut,
+                                   double* __restrict__ velOut, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t g = gid[i];
+    const int32_t c = cell[i];
+    if (xyzw) {
+        xyzw[4 * g] = x[i]; xyzw[4 * g + 1] = y[i]; xyzw[4 * g + 2] = z[i];
+        xyzw[4 * g + 3] = (c == CPF_CELL_FROZEN) ? 0.0 : 1.0;
+    }
+    if (cellOut) cellOut[g] = c;
+    if (velOut) {
+        velOut[4 * g] = vel ? vel[3 * i] : 0.0; velOut[4 * g + 1] = vel ? vel[3 * i + 1] : 0.0;
+        velOut[4 * g + 2] = vel ? vel[3 * i + 2] : 0.0; velOut[4 * g + 3] = -1.0;   // particles.cu:361
+    }
+}
+__global__ void u3_to_u4_kernel(const double* __restrict__ u3, double4* __restrict__ u4, int64_t nCells) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c < nCells) u4[c] = make_double4(u3[3 * c], u3[3 * c + 1], u3[3 * c + 2], 0.0);
+}
+__global__ void count_negative_kernel(const int32_t* __restrict__ cell, int64_t n, unsigned long long* out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned v = (i < n && cell[i] < 0) ? 1u : 0u;
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, (unsigned long long)v);
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+hipError_t launch_iota64(hipStream_t st, int64_t* p, int64_t n, int64_t first) {
+    if (n > 0) hipLaunchKernelGGL(iota64_kernel, grid_for(n), dim3(kBlock), 0, st, p, n, first);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_xyz(hipStream_t st, const double* xyz, double* x, double* y, double* z, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(unpack_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, xyz, x, y, z, n);
+    return hipGetLastError();
+}
+hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                              const int64_t* gid, const double* vel, double* xyzw, int32_t* cellOut, double* velOut,
+                              int64_t n) {
+    if (n > 0)
+        hipLaunchKernelGGL(pack_by_gid_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, vel, xyzw, cellOut,
+                           velOut, n);
+    return hipGetLastError();
+}
+hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(u3_to_u4_kernel, grid_for(nCells), dim3(kBlock), 0, st, u3, u4, nCells);
+    return hipGetLastError();
+}
+hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out) {
+    if (n > 0) hipLaunchKernelGGL(count_negative_kernel, grid_for(n), dim3(kBlock), 0, st, cell, n, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort by cell: radix sort (cell, index) pairs on the low bits only, then gather every array.
+// Stable and deterministic, so the order of particles is reproducible run to run.
+// ------------------------------------------------------------------------------------------------
+size_t sort_scratch_bytes(int64_t n, int endBit) {
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                       (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
+    // keys out + iota + perm + one 8-byte staging array, each 256-B aligned
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(tmp) + al(4 * (size_t)n) * 3 + al(8 * (size_t)n);
+}
+
+hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
+                        int endBit, void* scratch, size_t scratchBytes) {
+    if (n <= 1) return hipSuccess;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t tmpBytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                       (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
+    char* p = (char*)scratch;
+    void* tmp = p; p += al(tmpBytes);
+    uint32_t* keysOut = (uint32_t*)p; p += al(4 * (size_t)n);
+    int32_t* idx = (int32_t*)p; p += al(4 * (size_t)n);
+    int32_t* perm = (int32_t*)p; p += al(4 * (size_t)n);
+    double* stage = (double*)p; p += al(8 * (size_t)n);
+    if ((size_t)(p - (char*)scratch) > scratchBytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(kBlock), 0, st, idx, n);
+    // negative ids (lost/frozen) compare as huge unsigned keys and end up at the tail: sort all 32 bits
+    // only when some are negative would be an optimisation; endBit covers [0, nCells) and the sign bit
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, (const uint32_t*)cell, keysOut, idx, perm, (int)n,
+                                                      0, endBit, st);
+    if (e != hipSuccess) return e;
+    double* arrs[3] = {x, y, z};
+    for (double* a : arrs) {
+        hipLaunchKernelGGL((gather_kernel<double>), grid_for(n), dim3(kBlock), 0, st, a, stage, perm, n);
+        e = hipMemcpyAsync(a, stage, 8 * (size_t)n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    if (gid) {
+        hipLaunchKernelGGL((gather_kernel<int64_t>), grid_for(n), dim3(kBlock), 0, st, gid, (int64_t*)stage, perm, n);
+        e = hipMemcpyAsync(gid, stage, 8 * (size_t)n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    e = hipMemcpyAsync(cell, keysOut, 4 * (size_t)n, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace cpf

@@ -1,0 +1,191 @@
+// Host-side mesh ingest: OpenFOAM polyMesh arrays -> CSR cell/face-slot planes + locate grid.
+//
+// Replaces, for this path, what the reference's init fragment does on the host before any
+// kernel runs: the polyMeshTetDecomposition loop (src/initCuda.H:86-110), the std::map face
+// table HostTetMesh::getBoundaryMesh (third_party/RTXAdvect/cuda/HostTetMesh.h:307-430) and the
+// OptiX BVH build (src/initCuda.H:132-139).  No tets, no BVH: cells keep their own faces.
+//
+// Compiled with -ffp-contract=off: the plane coefficients must not depend on how a host
+// compiler chooses to fuse multiply-adds (tests compare them with an independent build).
+#include "cpf_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace cpf {
+namespace {
+
+struct Vec { double x, y, z; };
+inline Vec operator+(Vec a, Vec b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec operator-(Vec a, Vec b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline double dot(Vec a, Vec b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec cross(Vec a, Vec b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline Vec at(const double* p, int64_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+// Unit normal (owner -> neighbour) and centre of one face: triangle fan about the vertex
+// average, area-weighted centre (the scheme of OpenFOAM's face centres/areas; exact for planar
+// faces, best-fit plane through the centre otherwise).
+template <typename Label>
+bool face_plane(const double* pts, const Label* verts, int nv, Vec& n, Vec& centre) {
+    Vec est{0, 0, 0};
+    for (int i = 0; i < nv; ++i) est = est + at(pts, verts[i]);
+    est = {est.x / nv, est.y / nv, est.z / nv};
+    Vec sumN{0, 0, 0}, sumAc{0, 0, 0};
+    double sumA = 0.0;
+    for (int i = 0; i < nv; ++i) {
+        Vec p = at(pts, verts[i]), q = at(pts, verts[i + 1 == nv ? 0 : i + 1]);
+        Vec c3 = (p + q) + est;
+        Vec nrm = cross(q - p, est - p);
+        double a = std::sqrt(dot(nrm, nrm));
+        sumN = sumN + nrm;
+        sumA += a;
+        sumAc = sumAc + Vec{a * c3.x, a * c3.y, a * c3.z};
+    }
+    centre = sumA > 0.0 ? Vec{sumAc.x / (3.0 * sumA), sumAc.y / (3.0 * sumA), sumAc.z / (3.0 * sumA)} : est;
+    double len = std::sqrt(dot(sumN, sumN));
+    if (!(len > 0.0)) return false;
+    n = {sumN.x / len, sumN.y / len, sumN.z / len};
+    return true;
+}
+
+}  // namespace
+
+template <typename Label>
+std::string build_tables(const double* points, int64_t nPoints, const Label* faceOff, const Label* faceVerts,
+                         int64_t nFaces, const Label* owner, const Label* neighbour, int64_t nInternal,
+                         int64_t nCells, HostTables& out) {
+    if (nCells <= 0 || nFaces <= 0 || nPoints <= 0) return "empty mesh";
+    if (nInternal < 0 || nInternal > nFaces) return "nInternal out of range";
+    if (nCells > INT32_MAX - 2 || nFaces > INT32_MAX - 2) return "mesh too large for 32-bit cell/face ids";
+    if (faceOff[0] != 0) return "faceOffsets[0] != 0";
+    for (int64_t f = 0; f < nFaces; ++f) {
+        int64_t nv = (int64_t)faceOff[f + 1] - (int64_t)faceOff[f];
+        if (nv < 3) return "face " + std::to_string(f) + " has fewer than 3 vertices";
+        if (owner[f] < 0 || owner[f] >= nCells) return "owner[" + std::to_string(f) + "] out of range";
+        if (f < nInternal && (neighbour[f] < 0 || neighbour[f] >= nCells))
+            return "neighbour[" + std::to_string(f) + "] out of range";
+        if (f < nInternal && neighbour[f] == owner[f]) return "face " + std::to_string(f) + " has owner == neighbour";
+    }
+    const int64_t nVertsTotal = faceOff[nFaces];
+    for (int64_t i = 0; i < nVertsTotal; ++i)
+        if (faceVerts[i] < 0 || faceVerts[i] >= nPoints) return "face vertex id out of range";
+
+    out = HostTables();
+    out.nCells = nCells;
+    out.nSlots = nFaces + nInternal;
+    if (out.nSlots > INT32_MAX - 2) return "too many cell-face slots";
+    out.cellOff.assign((size_t)nCells + 1, 0);
+    std::vector<int32_t> fill((size_t)nCells, 0);
+    for (int64_t f = 0; f < nFaces; ++f) out.cellOff[(size_t)owner[f] + 1]++;
+    for (int64_t f = 0; f < nInternal; ++f) out.cellOff[(size_t)neighbour[f] + 1]++;
+    for (int64_t c = 0; c < nCells; ++c) {
+        int32_t k = out.cellOff[(size_t)c + 1];
+        if (k < 4) return "cell " + std::to_string(c) + " has fewer than 4 faces";
+        out.maxCellFaces = std::max(out.maxCellFaces, k);
+        out.cellOff[(size_t)c + 1] += out.cellOff[(size_t)c];
+    }
+    out.planes.resize((size_t)out.nSlots * 4);
+    out.nbr.resize((size_t)out.nSlots);
+    // cell AABBs for the locate grid, gathered while we touch every face anyway
+    std::vector<double> bmin((size_t)nCells * 3, 1e300), bmax((size_t)nCells * 3, -1e300);
+    auto grow = [&](int64_t c, const Label* v, int nv) {
+        for (int i = 0; i < nv; ++i)
+            for (int k = 0; k < 3; ++k) {
+                double val = points[3 * (int64_t)v[i] + k];
+                bmin[3 * c + k] = std::min(bmin[3 * c + k], val);
+                bmax[3 * c + k] = std::max(bmax[3 * c + k], val);
+            }
+    };
+    // slot order = mesh.cells()[c]: owned faces ascending, then neighbour faces ascending
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t nf = pass == 0 ? nFaces : nInternal;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int64_t c = pass == 0 ? owner[f] : neighbour[f];
+            const int64_t s = out.cellOff[(size_t)c] + fill[(size_t)c]++;
+            const Label* v = faceVerts + faceOff[f];
+            const int nv = (int)(faceOff[f + 1] - faceOff[f]);
+            Vec n, cf;
+            if (!face_plane(points, v, nv, n, cf)) return "face " + std::to_string(f) + " has zero area";
+            if (pass == 0) n = {-n.x, -n.y, -n.z};   // into the owner
+            out.planes[4 * s + 0] = n.x;
+            out.planes[4 * s + 1] = n.y;
+            out.planes[4 * s + 2] = n.z;
+            out.planes[4 * s + 3] = dot(n, cf);
+            out.nbr[(size_t)s] = pass == 0 ? (f < nInternal ? (int32_t)neighbour[f] : (int32_t)(-(f + 1)))
+                                           : (int32_t)owner[f];
+            grow(c, v, nv);
+        }
+    }
+
+    // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)
+    for (int k = 0; k < 3; ++k) { out.lo[k] = 1e300; out.hi[k] = -1e300; }
+    for (int64_t p = 0; p < nPoints; ++p)
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] = std::min(out.lo[k], points[3 * p + k]);
+            out.hi[k] = std::max(out.hi[k], points[3 * p + k]);
+        }
+    double ext[3], vol = 1.0, diag = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        ext[k] = out.hi[k] - out.lo[k];
+        diag += ext[k] * ext[k];
+    }
+    diag = std::sqrt(diag);
+    const double pad = 1e-9 * diag;
+    for (int k = 0; k < 3; ++k) {
+        ext[k] = std::max(ext[k], 1e-12 * diag) + 2 * pad;
+        out.origin[k] = out.lo[k] - pad;
+        vol *= ext[k];
+    }
+    const double h = std::cbrt(vol / (double)nCells);
+    int64_t nBins = 1;
+    for (int k = 0; k < 3; ++k) {
+        int64_t d = (int64_t)std::floor(ext[k] / h);
+        d = std::max<int64_t>(1, std::min<int64_t>(d, 2048));
+        out.dims[k] = (int32_t)d;
+        nBins *= d;
+    }
+    while (nBins > 8 * nCells + 64) {   // keep the table small on very anisotropic boxes
+        int kmax = 0;
+        for (int k = 1; k < 3; ++k) if (out.dims[k] > out.dims[kmax]) kmax = k;
+        nBins /= out.dims[kmax];
+        out.dims[kmax] = std::max(1, out.dims[kmax] / 2);
+        nBins *= out.dims[kmax];
+    }
+    for (int k = 0; k < 3; ++k) out.invBin[k] = (double)out.dims[k] / ext[k];
+    auto binOf = [&](double v, int k) {
+        int64_t b = (int64_t)std::floor((v - out.origin[k]) * out.invBin[k]);
+        return (int32_t)std::max<int64_t>(0, std::min<int64_t>(b, out.dims[k] - 1));
+    };
+    out.binOff.assign((size_t)nBins + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int32_t> cursor;
+        if (pass == 1) {
+            for (int64_t b = 0; b < nBins; ++b) out.binOff[(size_t)b + 1] += out.binOff[(size_t)b];
+            out.binCells.resize((size_t)out.binOff[(size_t)nBins]);
+            cursor.assign(out.binOff.begin(), out.binOff.end() - 1);
+        }
+        for (int64_t c = 0; c < nCells; ++c) {
+            int32_t b0[3], b1[3];
+            for (int k = 0; k < 3; ++k) {
+                b0[k] = binOf(bmin[3 * c + k] - pad, k);
+                b1[k] = binOf(bmax[3 * c + k] + pad, k);
+            }
+            for (int32_t kz = b0[2]; kz <= b1[2]; ++kz)
+                for (int32_t ky = b0[1]; ky <= b1[1]; ++ky)
+                    for (int32_t kx = b0[0]; kx <= b1[0]; ++kx) {
+                        size_t b = ((size_t)kz * out.dims[1] + ky) * out.dims[0] + kx;
+                        if (pass == 0) out.binOff[b + 1]++;
+                        else out.binCells[(size_t)cursor[b]++] = (int32_t)c;
+                    }
+        }
+    }
+    return std::string();
+}
+
+template std::string build_tables<int32_t>(const double*, int64_t, const int32_t*, const int32_t*, int64_t,
+                                           const int32_t*, const int32_t*, int64_t, int64_t, HostTables&);
+template std::string build_tables<int64_t>(const double*, int64_t, const int64_t*, const int64_t*, int64_t,
+                                           const int64_t*, const int64_t*, int64_t, int64_t, HostTables&);
+
+}  // namespace cpf

@@ -1,0 +1,175 @@
+/* cpf.h -- C-ABI of libcudaParticleAdvection.so (MI355X / gfx950 build).
+ *
+ * Drop-in boundary for the per-timestep particle advect+locate loop of
+ * simzero/cudaParticlesFoam.  The reference has no C interface: its OpenFOAM solvers
+ * #include two header fragments (src/initCuda.H, src/advect.H) that call C++ functions of
+ * `namespace advect` in libcudaParticleAdvection (declared in third_party/RTXAdvect/
+ * cuda/common.h, query/ConvexQuery.h, query/RTQuery.h) with raw CUDA device pointers.
+ * Each entry point below names the reference interface it replaces (paths relative to the
+ * reference root).  Header-only C++ shims with the reference's own names sit on top of this
+ * ABI in cudaparticlesfoam_amd/compat/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all functions return a cpf_status (0 = ok) and never
+ *     exit() the process (the reference's cudaCheck does, cuda/cudaHelpers.cuh:32-40);
+ *     cpf_last_error() gives the message.
+ *   - "host" pointers are ordinary memory; "dev" pointers are HIP device memory.
+ *   - labels are 32-bit (OpenFOAM WM_LABEL_SIZE=32); *_l64 variants take 64-bit labels.
+ *   - particle state is fp64 (reference: Particle = double4, cuda/common.h:26).
+ *   - cell ids: >= 0 containing cell; CPF_CELL_LOST (-1) left the domain / still on a wall
+ *     after 5 reflections (reference tetID -1); CPF_CELL_FROZEN (-2) == reference w = 0
+ *     (cuda/particles.cu:333-338).  The reference's tetID maps to cell = tetID / 12
+ *     (src/initCuda.H:64,99-105).
+ */
+#ifndef CPF_H
+#define CPF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPF_ABI_VERSION 1
+#define CPF_CELL_LOST (-1)
+#define CPF_CELL_FROZEN (-2)
+
+typedef struct cpf_context cpf_context;
+
+typedef enum cpf_status {
+    CPF_OK = 0,
+    CPF_ERR_ARG = 1,    /* null / out-of-range argument */
+    CPF_ERR_STATE = 2,  /* call order: mesh / velocity / particles not set yet */
+    CPF_ERR_MESH = 3,   /* inconsistent polyMesh (owner/neighbour/face lists) */
+    CPF_ERR_HIP = 4,    /* HIP runtime error (no device, allocation, launch) */
+    CPF_ERR_NOMEM = 5
+} cpf_status;
+
+/* flags for cpf_step / cpf_step_device */
+#define CPF_STEP_DEFAULT 0u
+#define CPF_STEP_NO_REFLECT 1u    /* reflectWall=false (src/initCuda.H:67): wall hit => CPF_CELL_LOST */
+#define CPF_STEP_STORE_VEL 2u     /* also write per-particle velocity (d_particle_vels, for the VTU writer) */
+#define CPF_STEP_FUSE_CYCLES 4u   /* run all nCycles inside ONE launch, particle state kept in registers
+                                     (legal because U is frozen during the loop, src/advect.H:86) */
+
+/* ---------------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------------- */
+int cpf_abi_version(void);
+/* hipSetDevice(device) + stream/event creation.  Replaces the implicit CUDA context of the
+ * reference (single GPU, default stream: SURVEY.md fact 4). */
+int cpf_create(int device, cpf_context** out);
+int cpf_destroy(cpf_context* ctx);
+/* message of the last failing call on ctx (ctx == NULL: last cpf_create failure). Never NULL. */
+const char* cpf_last_error(const cpf_context* ctx);
+/* Run all subsequent work on a caller-owned hipStream_t (e.g. the framework's current stream);
+ * NULL restores the context's own stream. */
+int cpf_set_stream(cpf_context* ctx, void* hip_stream);
+int cpf_synchronize(cpf_context* ctx);   /* replaces cudaDeviceSynchronize() after every wrapper */
+
+/* ---------------------------------------------------------------------------------------------
+ * mesh + velocity
+ * ------------------------------------------------------------------------------------------- */
+/* Hand over the polyMesh.  Replaces src/initCuda.H:76-130 (polyMeshTetDecomposition loop,
+ * HostTetMesh::getBoundaryMesh -- cuda/HostTetMesh.h:307-430 --, DeviceTetMesh::upload --
+ * cuda/DeviceTetMesh.cuh:59-72) and the OptiX BVH build (src/initCuda.H:132-139).
+ *   points      [nPoints][3]   mesh.points()            (zero-copy from pointField)
+ *   faceOffsets [nFaces+1], faceVerts [faceOffsets[nFaces]]   mesh.faces() flattened
+ *   owner [nFaces], neighbour [nInternal]               mesh.faceOwner()/faceNeighbour()
+ * Builds on the host: CSR cell -> face-slot table in mesh.cells() order, per-slot inward unit
+ * plane (n, d) and neighbour id, a uniform bin grid for the initial locate; uploads them. */
+int cpf_set_mesh(cpf_context* ctx, const double* points, int64_t nPoints, const int32_t* faceOffsets,
+                 const int32_t* faceVerts, int64_t nFaces, const int32_t* owner, const int32_t* neighbour,
+                 int64_t nInternal, int64_t nCells);
+int cpf_set_mesh_l64(cpf_context* ctx, const double* points, int64_t nPoints, const int64_t* faceOffsets,
+                     const int64_t* faceVerts, int64_t nFaces, const int64_t* owner, const int64_t* neighbour,
+                     int64_t nInternal, int64_t nCells);
+int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nCellFaceSlots, int64_t* deviceBytes);
+/* Copy the host-built tables back out (tests: compared against the oracle's own build). Any
+ * pointer may be NULL.  cellOff[nCells+1], planes[slots][4], nbr[slots]. */
+int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes, int32_t* nbr);
+
+/* Cell-constant velocity U[nCells][3] (host, zero-copy from U.primitiveField()).  Replaces the
+ * 12x replication loop + cudaUpdateVelocity of src/advect.H:44-57 (cuda/particles.cu:718-749):
+ * nCells*24 B cross PCIe instead of 12*nCells*24 B. */
+int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells);
+/* same from device memory (async on the context stream) */
+int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells);
+
+/* ---------------------------------------------------------------------------------------------
+ * context-owned particle cloud (what the fragments use)
+ * ------------------------------------------------------------------------------------------- */
+/* cudaMalloc block of src/initCuda.H:141-150 */
+int cpf_alloc_particles(cpf_context* ctx, int64_t capacity);
+/* cudaInitParticles (cuda/particles.cu:78-108): LCG<16> seeded (i%128, i/128), three draws,
+ * pos = lower + r * (upper - lower), w = 1.  The reference leaves the draw->axis assignment to
+ * unspecified argument evaluation order; order=0: x,y,z = draws 1,2,3; order=1: draws 3,2,1. */
+int cpf_seed_box(cpf_context* ctx, int64_t n, const double lower[3], const double upper[3], int order);
+/* inject positions (host [n][3]) and optionally cells (host [n], NULL = unknown, run locate). */
+int cpf_set_particles(cpf_context* ctx, int64_t n, const double* xyz, const int32_t* cell);
+/* Initial point location.  Replaces RTQuery(OptixQuery&, DeviceTetMesh, double4*, int*, int)
+ * (query/RTQuery.cu:295-310: OptiX ray query + baryQuery fix-up) and cudaReportParticles
+ * (cuda/particles.cu:763-775).  Contract: cell = lowest-numbered cell whose every face plane has
+ * the point on its inner side, CPF_CELL_LOST if none.  nOutside (nullable) = #particles outside. */
+int cpf_locate_initial(cpf_context* ctx, int64_t* nOutside);
+/* nCycles Lagrangian sub-steps of length dt: the loop body of src/advect.H:86-184 in the
+ * ConvexPoly build = cudaAdvect (particles.cu:403-448) -> cudaBrownianMotion (:577-599) ->
+ * convexTetQuery (query/ConvexQuery.cu:218-234) -> convexWallReflect (:438-458) ->
+ * cudaMoveParticles (particles.cu:706-716), fused into one kernel launch per cycle.
+ * D = diffusionCoeff (0 adds exactly nothing, as in the reference). */
+int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags);
+/* Reorder the cloud by containing cell (coalesced mesh reads); ids travel with the particles. */
+int cpf_sort_by_cell(cpf_context* ctx);
+int cpf_num_particles(const cpf_context* ctx, int64_t* n);
+/* D2H for output, in ORIGINAL particle-id order.  Replaces the cudaMemcpy block of
+ * writeParticles2VTU (cuda/utils.cpp:144-283).  xyzw [n][4] (w = 1 active, 0 frozen),
+ * cell [n], vel [n][4] (w = -1 like cuda/particles.cu:361); any may be NULL. */
+int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel);
+/* cumulative counters since creation: particle-steps done, cells visited, wall reflections, lost */
+int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
+int cpf_set_seed(cpf_context* ctx, uint32_t seed);   /* Brownian stream; default 1591593751 (particles.cu:544) */
+
+/* ---------------------------------------------------------------------------------------------
+ * device-array level (framework hosts that own the particle arrays, multi-GPU sharding)
+ * SoA fp64 positions x,y,z [n]; cell [n] int32; gid [n] int64 global particle id (nullable:
+ * gid = index); vel [n][3] (nullable unless CPF_STEP_STORE_VEL).
+ * ------------------------------------------------------------------------------------------- */
+int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                 double* vel, int64_t n, double dt, double D, uint32_t step0, int nCycles, unsigned flags);
+int cpf_locate_initial_dev(cpf_context* ctx, const double* x, const double* y, const double* z,
+                           int32_t* cell, int64_t n);
+/* cudaInitParticles on caller arrays; particle ids first..first+n-1 (sharded seeding) */
+int cpf_seed_box_dev(cpf_context* ctx, double* x, double* y, double* z, int64_t first, int64_t n,
+                     const double lower[3], const double upper[3], int order);
+/* perm[n] (int32 scratch, out): stable order by cell; arrays are permuted in place via tmp
+ * buffers owned by the context. */
+int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
+                         int64_t n);
+/* Multi-GPU hand-off (no reference counterpart: SURVEY.md 8e).  Rank r owns cells
+ * [cellLo[r], cellLo[r+1]).  Partitions the n particles into stay / leave: stayers are
+ * left in / moved into [0, nStay) (holes left by leavers are filled from the tail, so only
+ * O(leavers) particles move; order is not preserved), leavers are written, grouped by destination
+ * rank and in index order, into sendbuf as records of CPF_HANDOFF_DOUBLES doubles (x, y, z, cell-as-double,
+ * gid-as-double).  counts[nRanks] (device int64) = records per destination; nStay (device).
+ * Lost/frozen particles stay where they are. */
+#define CPF_HANDOFF_DOUBLES 5
+int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
+                         int64_t n, const int32_t* cellLo_dev, int nRanks, int myRank, double* sendbuf,
+                         int64_t sendCapacity, int64_t* counts_dev, int64_t* nStay_dev);
+/* append nRecv received records at index nStay.. of the arrays */
+int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
+                            int64_t nStay, const double* recvbuf, int64_t nRecv);
+
+/* ---------------------------------------------------------------------------------------------
+ * measurement
+ * ------------------------------------------------------------------------------------------- */
+/* When enabled, every step-kernel launch is bracketed by a hipEvent pair on the launch stream. */
+int cpf_timing_enable(cpf_context* ctx, int on);
+/* Drains the recorded pairs: number of launches and their summed device time in ms. */
+int cpf_timing_read(cpf_context* ctx, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPF_H */

@@ -1,0 +1,77 @@
+"""CPU: the synthetic inputs (mesh generators) have the topology the reference's tutorial dicts imply."""
+import numpy as np
+
+
+def test_pitzdaily_counts_and_patches(pitz):
+    pz, mesh = pitz["pz"], pitz["mesh"]
+    assert (mesh.n_cells, mesh.n_points, mesh.n_faces, mesh.n_internal) == (pz.N_CELLS, pz.N_POINTS, pz.N_FACES,
+                                                                            pz.N_INTERNAL)
+    sizes = {name: size for name, _, _, size in mesh.patches}
+    assert sizes == pz.PATCH_SIZES
+    starts = [s for _, _, s, _ in mesh.patches]
+    assert starts[0] == mesh.n_internal and starts == sorted(starts)
+
+
+def test_pitzdaily_geometry(pitz):
+    mesh, c, v = pitz["mesh"], pitz["centres"], pitz["vols"]
+    assert v.min() > 0
+    assert abs(v.sum() - (20.6 * 25.4 + 206 * 50.8 + 84 * (50.8 + 33.2) / 2) * 1e-9) < 1e-15
+    fc, fa = mesh.face_centres_areas()
+    nI = mesh.n_internal
+    assert (((fc - c[mesh.owner]) * fa).sum(1) > 0).all()           # normals point out of the owner
+    assert (((c[mesh.neighbour] - fc[:nI]) * fa[:nI]).sum(1) > 0).all()
+    assert (mesh.owner[:nI] < mesh.neighbour).all()                   # upper-triangular order
+    key = mesh.owner[:nI].astype(np.int64) * mesh.n_cells + mesh.neighbour
+    assert (np.diff(key) > 0).all()
+    off, cf = mesh.cell_faces()
+    assert (np.diff(off) == 6).all()
+    # mesh.cells() order: owned faces ascending, then neighbour faces ascending
+    for cidx in (0, 17, 5000, mesh.n_cells - 1):
+        f = cf[off[cidx]:off[cidx + 1]]
+        owned = f[mesh.owner[f] == cidx]
+        other = f[mesh.owner[f] != cidx]
+        assert np.array_equal(f, np.concatenate([np.sort(owned), np.sort(other)]))
+        assert (mesh.neighbour[other] == cidx).all()
+
+
+def test_grading_rule():
+    from cudaparticlesfoam_amd.cases import line_divide
+    from cudaparticlesfoam_amd.cases.pitzdaily import NEG_Y, POS_Y, POS_YR
+    lam = line_divide(30, POS_Y)
+    assert lam[0] == 0 and lam[-1] == 1 and (np.diff(lam) > 0).all()
+    # section cell counts 11/8/11 at length fractions 0.2/0.4/0.4
+    assert abs(lam[11] - 0.2) < 1e-15 and abs(lam[19] - 0.6) < 1e-15
+    d = np.diff(lam[:12])
+    assert abs(d[-1] / d[0] - 2.0) < 1e-12                             # expansion ratio of section 1
+    lam = line_divide(27, NEG_Y)
+    assert abs(lam[15] - 2.0 / 3.0) < 1e-15
+    lam = line_divide(30, POS_YR)
+    assert abs(lam[15] - 2.0 / 3.0) < 1e-15
+    lam = line_divide(18, 0.5)
+    d = np.diff(lam)
+    assert abs(d[-1] / d[0] - 0.5) < 1e-12
+
+
+def test_box_mesh_and_renumbering():
+    from cudaparticlesfoam_amd.cases import box_mesh
+    from cudaparticlesfoam_amd.parallel import slab_cell_ranges, x_slab_renumbering
+    m = box_mesh(5, 4, 3)
+    assert (m.n_cells, m.n_points, m.n_faces) == (60, 6 * 5 * 4, 3 * 60 + 5 * 4 + 5 * 3 + 4 * 3)
+    c, v = m.cell_centres_volumes()
+    assert np.allclose(v, 1.0)
+    r = m.renumber_cells(x_slab_renumbering(c))
+    c2, v2 = r.cell_centres_volumes()
+    assert (np.diff(c2[:, 0]) >= -1e-12).all() and np.allclose(np.sort(c2, 0), np.sort(c, 0))
+    nI = r.n_internal
+    assert (r.owner[:nI] < r.neighbour).all()
+    fc, fa = r.face_centres_areas()
+    assert (((fc - c2[r.owner]) * fa).sum(1) > 0).all()
+    lo = slab_cell_ranges(v2, 4)
+    assert lo[0] == 0 and lo[-1] == 60 and (np.diff(lo) == 15).all()
+
+
+def test_analytic_field_respects_walk_cap(pitz):
+    U = pitz["U_analytic"]
+    speed = np.linalg.norm(U, axis=1)
+    assert speed.max() * 1e-4 < 2e-3           # < ~4 cells per Lagrangian sub-step (50-tet cap)
+    assert (U[:, 2] == 0).all()
