@@ -63,6 +63,21 @@ SIGNATURES = {
     "cpf_sort_by_cell_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64]),
     "cpf_pack_leavers_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _int, _vp, _i64, _vp, _vp]),
     "cpf_unpack_arrivals_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64]),
+    "cpf_dev_alloc": (_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
+    "cpf_dev_free": (_int, [_ctx, _vp]),
+    "cpf_dev_memset": (_int, [_ctx, _vp, _int, C.c_size_t]),
+    "cpf_copy_to_device": (_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "cpf_copy_to_host": (_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "cpf_stage_seed_box": (_int, [_ctx, _vp, _i64, _vp, _vp, _int]),
+    "cpf_stage_locate_initial": (_int, [_ctx, _vp, _vp, _i64]),
+    "cpf_stage_count_outside": (_int, [_ctx, _vp, _i64, C.POINTER(_i64)]),
+    "cpf_stage_advect": (_int, [_ctx, _vp, _vp, _vp, _vp, _dbl, _i64]),
+    "cpf_stage_brownian": (_int, [_ctx, _vp, _vp, _dbl, _i64, _dbl, _u32]),
+    "cpf_stage_locate": (_int, [_ctx, _vp, _vp, _vp, _i64]),
+    "cpf_stage_reflect": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),
+    "cpf_stage_move": (_int, [_ctx, _vp, _vp, _i64]),
+    "cpf_write_vtu": (_int, [_ctx, C.c_char_p, C.POINTER(_dbl)]),
+    "cpf_write_vtu_arrays": (_int, [C.c_char_p, _i64, _vp, _vp, _vp, C.POINTER(_dbl)]),
     "cpf_timing_enable": (_int, [_ctx, _int]),
     "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
 }

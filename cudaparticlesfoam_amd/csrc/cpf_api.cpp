@@ -490,6 +490,124 @@ int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, i
     return CPF_OK;
 }
 
+// ---- device memory helpers ------------------------------------------------------------------
+int cpf_dev_alloc(cpf_context* ctx, size_t bytes, void** out) {
+    CPF_REQUIRE(ctx, ctx && out, CPF_ERR_ARG, "null argument");
+    *out = nullptr;
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipMalloc(out, std::max<size_t>(bytes, 16)));
+    return CPF_OK;
+}
+int cpf_dev_free(cpf_context* ctx, void* ptr) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    if (!ptr) return CPF_OK;
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CPF_HIP(ctx, hipFree(ptr));
+    return CPF_OK;
+}
+int cpf_dev_memset(cpf_context* ctx, void* ptr, int value, size_t bytes) {
+    CPF_REQUIRE(ctx, ctx && (ptr || bytes == 0), CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) CPF_HIP(ctx, hipMemsetAsync(ptr, value, bytes, ctx->stream));
+    return CPF_OK;
+}
+int cpf_copy_to_device(cpf_context* ctx, void* dst, const void* src, size_t bytes) {
+    CPF_REQUIRE(ctx, ctx && ((dst && src) || bytes == 0), CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) {
+        CPF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CPF_OK;
+}
+int cpf_copy_to_host(cpf_context* ctx, void* dst, const void* src, size_t bytes) {
+    CPF_REQUIRE(ctx, ctx && ((dst && src) || bytes == 0), CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) {
+        CPF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CPF_OK;
+}
+
+// ---- stage-by-stage entry points (reference layouts) --------------------------------------------
+#define CPF_STAGE_PRE(name, needU)                                                                      \
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");                                                 \
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, name ": call cpf_set_mesh first");                   \
+    CPF_REQUIRE(ctx, !(needU) || ctx->haveU, CPF_ERR_STATE, name ": call cpf_set_velocity first");      \
+    CPF_REQUIRE(ctx, n >= 0, CPF_ERR_ARG, name ": negative particle count");                            \
+    CPF_HIP(ctx, hipSetDevice(ctx->device))
+
+int cpf_stage_seed_box(cpf_context* ctx, double* particles, int64_t n, const double lower[3], const double upper[3],
+                       int order) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n >= 0 && lower && upper && (particles || n == 0), CPF_ERR_ARG, "cpf_stage_seed_box: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    int r = ensureScratch(ctx, (size_t)std::max<int64_t>(n, 1) * 24);
+    if (r) return r;
+    double* x = (double*)ctx->scratch; double* y = x + n; double* z = y + n;
+    CPF_HIP(ctx, cpf::launch_seed_box(ctx->stream, x, y, z, 0, n, lower, upper, order));
+    CPF_HIP(ctx, cpf::launch_soa_to_aos(ctx->stream, x, y, z, particles, n));
+    return CPF_OK;
+}
+int cpf_stage_locate_initial(cpf_context* ctx, const double* particles, int32_t* ids, int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_locate_initial", false);
+    CPF_REQUIRE(ctx, n == 0 || (particles && ids), CPF_ERR_ARG, "cpf_stage_locate_initial: null array");
+    int r = ensureScratch(ctx, (size_t)std::max<int64_t>(n, 1) * 24);
+    if (r) return r;
+    double* x = (double*)ctx->scratch; double* y = x + n; double* z = y + n;
+    CPF_HIP(ctx, cpf::launch_aos_to_soa(ctx->stream, particles, x, y, z, n));
+    CPF_HIP(ctx, cpf::launch_locate_initial(ctx->stream, x, y, z, ids, n, meshView(ctx), gridView(ctx)));
+    return CPF_OK;
+}
+int cpf_stage_count_outside(cpf_context* ctx, const int32_t* ids, int64_t n, int64_t* nNegative) {
+    CPF_REQUIRE(ctx, ctx && nNegative && (ids || n == 0) && n >= 0, CPF_ERR_ARG, "cpf_stage_count_outside: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* cnt = ctx->d_counters + 4;
+    CPF_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    CPF_HIP(ctx, cpf::launch_count_negative(ctx->stream, ids, n, cnt));
+    unsigned long long h = 0;
+    CPF_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *nNegative = (int64_t)h;
+    return CPF_OK;
+}
+int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps, double dt,
+                     int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_advect", true);
+    CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect: null array");
+    CPF_HIP(ctx, cpf::launch_stage_advect(ctx->stream, particles, ids, vels, disps, dt, n, meshView(ctx)));
+    return CPF_OK;
+}
+int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,
+                       uint32_t step) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n >= 0 && (n == 0 || (particles && disps)) && D >= 0.0, CPF_ERR_ARG, "cpf_stage_brownian: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_stage_brownian(ctx->stream, particles, disps, dt, n, D, step, ctx->seed));
+    return CPF_OK;
+}
+int cpf_stage_locate(cpf_context* ctx, const double* particles, const double* disps, int32_t* ids, int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_locate", false);
+    CPF_REQUIRE(ctx, n == 0 || (particles && disps && ids), CPF_ERR_ARG, "cpf_stage_locate: null array");
+    CPF_HIP(ctx, cpf::launch_stage_locate(ctx->stream, particles, disps, ids, n, meshView(ctx)));
+    return CPF_OK;
+}
+int cpf_stage_reflect(cpf_context* ctx, int32_t* ids, double* particles, double* vels, double* disps, int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_reflect", false);
+    CPF_REQUIRE(ctx, n == 0 || (particles && disps && ids && vels), CPF_ERR_ARG, "cpf_stage_reflect: null array");
+    CPF_HIP(ctx, cpf::launch_stage_reflect(ctx->stream, ids, particles, vels, disps, n, meshView(ctx)));
+    return CPF_OK;
+}
+int cpf_stage_move(cpf_context* ctx, double* particles, double* disps, int64_t n) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n >= 0 && (n == 0 || (particles && disps)), CPF_ERR_ARG, "cpf_stage_move: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::launch_stage_move(ctx->stream, particles, disps, n));
+    return CPF_OK;
+}
+
 int cpf_timing_enable(cpf_context* ctx, int on) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     ctx->timing = on != 0;

@@ -41,6 +41,19 @@ hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, 
 hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out);
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
 
+// stage-by-stage kernels on the reference's AoS layouts
+hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
+                               int64_t n, const MeshView& m);
+hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,
+                                 uint32_t step, uint32_t seed);
+hipError_t launch_stage_locate(hipStream_t st, const double* P, const double* disps, int32_t* ids, int64_t n,
+                               const MeshView& m);
+hipError_t launch_stage_reflect(hipStream_t st, int32_t* ids, double* P, double* vels, double* disps, int64_t n,
+                                const MeshView& m);
+hipError_t launch_stage_move(hipStream_t st, double* P, double* disps, int64_t n);
+hipError_t launch_aos_to_soa(hipStream_t st, const double* P, double* x, double* y, double* z, int64_t n);
+hipError_t launch_soa_to_aos(hipStream_t st, const double* x, const double* y, const double* z, double* P, int64_t n);
+
 size_t sort_scratch_bytes(int64_t n, int endBit);
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
                         int endBit, void* scratch, size_t scratchBytes);

@@ -201,6 +201,159 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage-by-stage kernels on the REFERENCE's own array layouts (Particle = double4 AoS, vec4d
+// disps / vels, int ids), one per wrapper of third_party/RTXAdvect/cuda/common.h and
+// query/ConvexQuery.h, for hosts that keep the reference's five-call cycle (compat shims).
+// ids are cell ids here (reference: tet ids, cell = tet / 12); the wall encoding between
+// locate and reflect is the reference's: -(cell at the START of the step + 1).
+// The fused step_kernel above is the same arithmetic in the same order (tests assert equality).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void stage_advect_kernel(double4* __restrict__ P, const int32_t* __restrict__ ids,
+                                                              double4* __restrict__ vels, double4* __restrict__ disps,
+                                                              double dt, int64_t n, MeshView m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double4 p = P[i];
+    if (!p.w) return;
+    const int id = ids[i];
+    if (id < 0) { p.w = 0.0; P[i] = p; return; }                 // particles.cu:333-338
+    const double4 u = m.U[id];
+    const D3 v = {u.x, u.y, u.z}, Pp = {p.x, p.y, p.z};
+    const D3 Pn = axpy(dt, v, Pp);
+    vels[i] = make_double4(v.x, v.y, v.z, -1.0);
+    disps[i] = make_double4(Pn.x - Pp.x, Pn.y - Pp.y, Pn.z - Pp.z, -1.0);
+}
+
+__global__ __launch_bounds__(kBlock) void stage_brownian_kernel(const double4* __restrict__ P,
+                                                                double4* __restrict__ disps, double sigma, int64_t n,
+                                                                uint32_t step, uint32_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (!P[i].w) return;
+    double4 d = disps[i];
+    const D3 r = axpy(sigma, normal3((uint64_t)i, step, seed), D3{d.x, d.y, d.z});
+    disps[i] = make_double4(r.x, r.y, r.z, d.w);
+}
+
+__global__ __launch_bounds__(kBlock) void stage_locate_kernel(const double4* __restrict__ P,
+                                                              const double4* __restrict__ disps,
+                                                              int32_t* __restrict__ ids, int64_t n, MeshView m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = P[i];
+    if (!p.w) return;
+    const int start = ids[i];
+    if (start < 0) return;
+    const double4 d = disps[i];
+    const D3 E = {p.x + d.x, p.y + d.y, p.z + d.z};
+    D3 S = {p.x, p.y, p.z};
+    int cur = start, next = start, token = INT32_MIN, outSlot = 0;
+    for (int h = 0; h < kMaxHops; ++h) {
+        next = trace_in_cell(S, E, cur, m, token, outSlot);
+        if (next == cur || next < 0) break;
+        token = cur;
+        cur = next;
+    }
+    ids[i] = next < 0 ? -(start + 1) : next;                      // ConvexQuery.cu:204-215
+}
+
+__global__ __launch_bounds__(kBlock) void stage_reflect_kernel(int32_t* __restrict__ ids, double4* __restrict__ P,
+                                                               double4* __restrict__ vels, double4* __restrict__ disps,
+                                                               int64_t n, MeshView m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double4 p = P[i];
+    if (!p.w) return;
+    const int id = ids[i];
+    if (id >= 0) return;                                          // only particles that hit a wall
+    double4 d = disps[i], vv = vels[i];
+    D3 S = {p.x, p.y, p.z};
+    D3 E = {p.x + d.x, p.y + d.y, p.z + d.z};
+    D3 v = {vv.x, vv.y, vv.z};
+    D3 hit = {-1.0, -1.0, -1.0};                                  // ConvexQuery.cu:352
+    int cur = -id - 1, next = cur, token = INT32_MIN, outSlot = 0;
+    for (int j = 0; j < kMaxReflect; ++j) {
+        for (int h = 0; h < kMaxHops; ++h) {
+            next = trace_in_cell(S, E, cur, m, token, outSlot);
+            if (next == cur || next < 0) break;
+            token = cur;
+            cur = next;
+        }
+        if (next >= 0) break;
+        hit = S;
+        const double4 pl = m.planes[outSlot];
+        const D3 nn = {pl.x, pl.y, pl.z};
+        const double sd = dot3(pl, E) - pl.w;
+        E = axpy(-2.0 * sd, nn, E);
+        v = axpy(-2.0 * dot3(pl, v), nn, v);
+        token = next;
+    }
+    P[i] = make_double4(hit.x, hit.y, hit.z, p.w);
+    disps[i] = make_double4(E.x - hit.x, E.y - hit.y, E.z - hit.z, d.w);
+    vels[i] = make_double4(v.x, v.y, v.z, vv.w);
+    ids[i] = next < 0 ? CPF_CELL_LOST : next;
+}
+
+__global__ __launch_bounds__(kBlock) void stage_move_kernel(double4* __restrict__ P, double4* __restrict__ disps,
+                                                            int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double4 p = P[i];
+    if (!p.w) return;
+    double4 d = disps[i];
+    p.x += d.x; p.y += d.y; p.z += d.z;
+    d.x = 0.0; d.y = 0.0; d.z = 0.0;
+    P[i] = p; disps[i] = d;
+}
+
+__global__ __launch_bounds__(kBlock) void aos_to_soa_kernel(const double4* __restrict__ P, double* x, double* y,
+                                                            double* z, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { const double4 p = P[i]; x[i] = p.x; y[i] = p.y; z[i] = p.z; }
+}
+__global__ __launch_bounds__(kBlock) void soa_to_aos_kernel(const double* x, const double* y, const double* z,
+                                                            double4* __restrict__ P, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) P[i] = make_double4(x[i], y[i], z[i], 1.0);
+}
+
+static inline dim3 grid_of(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
+                               int64_t n, const MeshView& m) {
+    if (n > 0) hipLaunchKernelGGL(stage_advect_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels, (double4*)disps, dt, n, m);
+    return hipGetLastError();
+}
+hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,
+                                 uint32_t step, uint32_t seed) {
+    if (n > 0 && D > 0.0)
+        hipLaunchKernelGGL(stage_brownian_kernel, grid_of(n), dim3(kBlock), 0, st, (const double4*)P, (double4*)disps, sqrt(2.00 * D * dt), n, step, seed);
+    return hipGetLastError();
+}
+hipError_t launch_stage_locate(hipStream_t st, const double* P, const double* disps, int32_t* ids, int64_t n,
+                               const MeshView& m) {
+    if (n > 0) hipLaunchKernelGGL(stage_locate_kernel, grid_of(n), dim3(kBlock), 0, st, (const double4*)P, (const double4*)disps, ids, n, m);
+    return hipGetLastError();
+}
+hipError_t launch_stage_reflect(hipStream_t st, int32_t* ids, double* P, double* vels, double* disps, int64_t n,
+                                const MeshView& m) {
+    if (n > 0) hipLaunchKernelGGL(stage_reflect_kernel, grid_of(n), dim3(kBlock), 0, st, ids, (double4*)P, (double4*)vels, (double4*)disps, n, m);
+    return hipGetLastError();
+}
+hipError_t launch_stage_move(hipStream_t st, double* P, double* disps, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(stage_move_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, (double4*)disps, n);
+    return hipGetLastError();
+}
+hipError_t launch_aos_to_soa(hipStream_t st, const double* P, double* x, double* y, double* z, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(aos_to_soa_kernel, grid_of(n), dim3(kBlock), 0, st, (const double4*)P, x, y, z, n);
+    return hipGetLastError();
+}
+hipError_t launch_soa_to_aos(hipStream_t st, const double* x, const double* y, const double* z, double* P, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(soa_to_aos_kernel, grid_of(n), dim3(kBlock), 0, st, x, y, z, (double4*)P, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // initial locate: bin grid + point-in-convex-cell plane test (replaces OptiX query + baryQuery,
 // query/RTQuery.cu:295-310).  Lowest-numbered containing cell wins (bins list cells ascending).
 // ------------------------------------------------------------------------------------------------

@@ -162,6 +162,50 @@ int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, i
                             int64_t nStay, const double* recvbuf, int64_t nRecv);
 
 /* ---------------------------------------------------------------------------------------------
+ * stage-by-stage entry points on the REFERENCE's array layouts, for hosts that keep the
+ * reference's five-call cycle (the compat shims advect::cudaAdvect(...) etc. forward here).
+ * particles/disps/vels: device [n][4] doubles (Particle / vec4d), ids: device int32 [n] holding
+ * CELL ids (reference: tet ids).  Between locate and reflect a wall hit is encoded exactly like
+ * the reference: ids[i] = -(cell at the start of the step + 1).
+ * ------------------------------------------------------------------------------------------- */
+/* device memory helpers so a C++ host needs no HIP headers (the reference's fragments call
+ * cudaMalloc/cudaMemset/cudaMemcpy directly, src/initCuda.H:141-150) */
+int cpf_dev_alloc(cpf_context* ctx, size_t bytes, void** out);
+int cpf_dev_free(cpf_context* ctx, void* ptr);
+int cpf_dev_memset(cpf_context* ctx, void* ptr, int value, size_t bytes);
+int cpf_copy_to_device(cpf_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int cpf_copy_to_host(cpf_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* cudaInitParticles (cuda/particles.cu:100-108) */
+int cpf_stage_seed_box(cpf_context* ctx, double* particles, int64_t n, const double lower[3], const double upper[3],
+                       int order);
+/* RTQuery(OptixQuery&, DeviceTetMesh, double4*, int*, int) (query/RTQuery.cu:295-310) */
+int cpf_stage_locate_initial(cpf_context* ctx, const double* particles, int32_t* ids, int64_t n);
+/* cudaReportParticles (cuda/particles.cu:763-775): number of negative ids */
+int cpf_stage_count_outside(cpf_context* ctx, const int32_t* ids, int64_t n, int64_t* nNegative);
+/* cudaAdvect, "TetVelocity" mode (cuda/particles.cu:403-448 -> :316-373) */
+int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps, double dt,
+                     int64_t n);
+/* cudaBrownianMotion (cuda/particles.cu:577-599); step selects the counter-based stream */
+int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,
+                       uint32_t step);
+/* convexTetQuery (query/ConvexQuery.cu:218-234) */
+int cpf_stage_locate(cpf_context* ctx, const double* particles, const double* disps, int32_t* ids, int64_t n);
+/* convexWallReflect (query/ConvexQuery.cu:438-458) */
+int cpf_stage_reflect(cpf_context* ctx, int32_t* ids, double* particles, double* vels, double* disps, int64_t n);
+/* cudaMoveParticles (cuda/particles.cu:706-716) */
+int cpf_stage_move(cpf_context* ctx, double* particles, double* disps, int64_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * output (the next component either side of the path: SURVEY.md 8f #1)
+ * ------------------------------------------------------------------------------------------- */
+/* writeParticles2VTU (cuda/utils.cpp:144-283): D2H of the context-owned cloud in particle-id
+ * order + ASCII particle_%04d.vtu layout.  totalKE (nullable) = "System Kinetic Energy". */
+int cpf_write_vtu(cpf_context* ctx, const char* path, double* totalKE);
+/* same formatter on host arrays: xyzw [n][4], cell [n], vel [n][4] */
+int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const int32_t* cell, const double* vel,
+                         double* totalKE);
+
+/* ---------------------------------------------------------------------------------------------
  * measurement
  * ------------------------------------------------------------------------------------------- */
 /* When enabled, every step-kernel launch is bracketed by a hipEvent pair on the launch stream. */

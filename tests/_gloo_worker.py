@@ -1,0 +1,55 @@
+"""Worker for tests/test_parallel_gloo.py: one rank of a world_size-N gloo job on CPU."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cudaparticlesfoam_amd.cases import box_mesh                           # noqa: E402
+from cudaparticlesfoam_amd.parallel import ShardedCloud, slab_cell_ranges, x_slab_renumbering  # noqa: E402
+from fake_ops import FakeOps                                                  # noqa: E402
+from oracle import oracle as O                                                # noqa: E402
+
+
+def main():
+    out_path, interval = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    m0 = box_mesh(12, 5, 4)
+    c0, _ = m0.cell_centres_volumes()
+    mesh = m0.renumber_cells(x_slab_renumbering(c0))
+    centres, vols = mesh.cell_centres_volumes()
+    rng = np.random.default_rng(5)
+    U = rng.normal(size=(mesh.n_cells, 3)) + np.array([1.5, 0, 0])
+    cw = O.CellWalk(); t = cw.build(mesh)
+    n_total = 6000
+    xyz = np.random.default_rng(8).uniform([0, 0, 0], [12, 5, 4], size=(n_total, 3))
+    cell_lo = slab_cell_ranges(vols, world)
+    # every rank starts with an arbitrary slice of the cloud (NOT its own slab): first exchange fixes that
+    mine = np.arange(rank, n_total, world)
+    cloud = ShardedCloud(FakeOps(cw, t, U), cell_lo, n_total + 16, torch.device("cpu"), rank, world,
+                         send_fraction=1.0, exchange_interval=interval)
+    cloud.set_particles(torch.from_numpy(xyz[mine, 0].copy()), torch.from_numpy(xyz[mine, 1].copy()),
+                        torch.from_numpy(xyz[mine, 2].copy()), None, torch.from_numpy(mine.astype(np.int64)))
+    cloud.exchange()
+    g, x, y, z, c = cloud.gather_to_numpy()
+    owned_ok = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
+    total0 = cloud.global_count()
+    cloud.step(0.2, 30)
+    if interval > 1:
+        cloud.exchange()
+    total1 = cloud.global_count()
+    g, x, y, z, c = cloud.gather_to_numpy()
+    owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
+    np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
+             total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""CPU: the host-side mirror of initCuda.H / advect.H (dictionary keys, sub-cycling, output cadence),
+with the C-ABI context replaced by a recorder (no compute, no GPU)."""
+import math
+
+import numpy as np
+import pytest
+
+
+class RecorderContext:
+    def __init__(self, device=0):
+        self.calls = []
+
+    def set_mesh(self, mesh): self.calls.append(("set_mesh",))
+    def set_velocity(self, U): self.calls.append(("set_velocity", np.asarray(U).shape))
+    def seed_box(self, n, lo, hi, order=1): self.calls.append(("seed_box", n, tuple(lo), tuple(hi), order))
+    def set_particles(self, xyz, cell=None): self.calls.append(("set_particles", np.asarray(xyz).shape[0]))
+    def locate_initial(self): self.calls.append(("locate_initial",)); return 3
+    def sort_by_cell(self): self.calls.append(("sort",))
+    def step(self, dt, D, n, flags): self.calls.append(("step", dt, D, n, flags))
+    def get_particles(self, want_vel=False):
+        z = np.zeros((2, 4))
+        return (z, np.zeros(2, np.int32), z) if want_vel else (z, np.zeros(2, np.int32))
+    def close(self): pass
+
+
+@pytest.fixture
+def api(monkeypatch):
+    from cudaparticlesfoam_amd import api as A
+    monkeypatch.setattr(A, "Context", RecorderContext)
+    return A
+
+
+def test_dictionary_defaults_match_the_fragment(api):
+    p = api.CudaParticles(mesh=None, U=np.zeros((4, 3)))
+    # src/initCuda.H:49-57
+    assert (p.numParticles, p.particleStartTime, p.particleEndTime, p.dt, p.diffusionCoeff, p.saveInterval) == \
+        (1000, 0.0, 1e05, 1e-4, 5.7e-6, 10)
+    assert p.seedingBox == ((0.0, 0.0, 0.0), (30.0, 30.0, 30.0))
+    kinds = [c[0] for c in p.ctx.calls]
+    assert kinds == ["set_mesh", "set_velocity", "seed_box", "locate_initial", "sort"]
+    assert p.outOfDomain == 3
+
+
+def test_subcycling_and_output_cadence(api):
+    from cudaparticlesfoam_amd import _lib as L
+    frames = []
+    d = dict(numParticles=1e5, dt=1e-4, saveInterval=10, startTime=282, endTime=382, diffusionCoeff=1.5e-5,
+             seedingBox=((-0.02, 0.025, 1e-4), (0.0, 0.0, -1e-4)))           # tutorial dict
+    p = api.CudaParticles(None, np.zeros((4, 3)), d, writer=lambda f, *a: frames.append(f))
+    assert frames == [0]                                                       # frame 0 at init (initCuda.H:201)
+    assert p.advect(100.0, 0.1) == 0                                           # outside [startTime, endTime]
+    n = p.advect(300.0, 0.1)
+    assert n == max(math.ceil(0.1 / 1e-4), 1) == 1000                          # advect.H:36
+    steps = [c for c in p.ctx.calls if c[0] == "step"]
+    assert len(steps) == 1000 and all(abs(c[1] - 0.1 / 1000) < 1e-18 and c[2] == 1.5e-5 and c[3] == 1 for c in steps)
+    assert frames[1:] == [s + 1 for s in range(0, 1000, 10)]                   # step % saveInterval == 0 -> step+1
+    assert [c[4] for c in steps[:11]] == [L.STEP_STORE_VEL] + [0] * 9 + [L.STEP_STORE_VEL]
+    assert p.step == 1000
+    # deltaT smaller than dt: one cycle of length deltaT
+    p2 = api.CudaParticles(None, np.zeros((4, 3)), dict(dt=1e-3))
+    assert p2.advect(0.0, 2.5e-4) == 1
+    assert [c for c in p2.ctx.calls if c[0] == "step"][0][1] == 2.5e-4
+
+
+def test_velocity_refresh_and_injected_positions(api):
+    p = api.CudaParticles(None, np.zeros((4, 3)), positions=np.zeros((7, 3)))
+    assert p.numParticles == 7 and ("set_particles", 7) in p.ctx.calls
+    p.advect(0.0, 1e-4, U=np.ones((4, 3)))
+    assert [c[0] for c in p.ctx.calls].count("set_velocity") == 2              # advect.H:44-57: U re-upload
