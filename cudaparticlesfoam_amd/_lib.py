@@ -57,6 +57,7 @@ SIGNATURES = {
     "cpf_get_particles": (_int, [_ctx, _vp, _vp, _vp]),
     "cpf_get_counters": (_int, [_ctx, _vp]),
     "cpf_set_seed": (_int, [_ctx, _u32]),
+    "cpf_set_option": (_int, [_ctx, C.c_char_p, _dbl]),
     "cpf_step_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _u32, _int, C.c_uint]),
     "cpf_locate_initial_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),
     "cpf_seed_box_dev": (_int, [_ctx, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int]),

@@ -141,6 +141,9 @@ class Context:
         self._ck(self.lib.cpf_get_counters(self.h, _ptr(out)))
         return dict(particle_steps=int(out[0]), cells_visited=int(out[1]), reflections=int(out[2]), lost=int(out[3]))
 
+    def set_option(self, key: str, value: float):
+        self._ck(self.lib.cpf_set_option(self.h, key.encode(), float(value)))
+
     def set_seed(self, seed: int):
         self._ck(self.lib.cpf_set_seed(self.h, seed & 0xFFFFFFFF))
 

@@ -43,6 +43,7 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;   // steps, hops, reflections, lost, + 1 spare
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
+    int stepVariant = 2;                        // cpf_set_option("step_variant"): 0 generic CSR, 1 fixed, 2 fixed+scalar
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -77,6 +78,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     cpf::MeshView m;
     m.cellOff = c->d_cellOff; m.planes = c->d_planes; m.nbr = c->d_nbr; m.U = c->d_U;
     m.nCells = (int32_t)c->host.nCells;
+    m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6) ? 1 : 0;
     return m;
 }
 cpf::GridView gridView(const cpf_context* c) {
@@ -374,7 +376,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                      reflect, storeVel, m, ctx->d_counters));
+                                      reflect, storeVel, m, ctx->d_counters, ctx->stepVariant));
         if (ctx->timing) {
             CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             ctx->events.emplace_back(e0, e1);
@@ -456,6 +458,17 @@ int cpf_get_counters(cpf_context* ctx, int64_t out[4]) {
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; ++k) out[k] = (int64_t)h[k];
     return CPF_OK;
+}
+
+int cpf_set_option(cpf_context* ctx, const char* key, double value) {
+    CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
+    const std::string k(key);
+    if (k == "step_variant") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1 || value == 2, CPF_ERR_ARG, "step_variant must be 0, 1 or 2");
+        ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    return fail(ctx, CPF_ERR_ARG, "cpf_set_option: unknown key '" + k + "'");
 }
 
 int cpf_set_seed(cpf_context* ctx, uint32_t seed) {

@@ -17,6 +17,7 @@ struct MeshView {
     const int32_t* nbr;       // [nSlots]
     const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
     int32_t nCells;
+    int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s)
 };
 
 struct GridView {
@@ -28,7 +29,7 @@ struct GridView {
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters);
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant);
 hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
                                  int64_t n, const MeshView& m, const GridView& g);
 hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,

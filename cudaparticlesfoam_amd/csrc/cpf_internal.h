@@ -17,7 +17,7 @@ struct HostTables {
     int32_t dims[3] = {1, 1, 1};
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
-    int32_t maxCellFaces = 0;
+    int32_t maxCellFaces = 0, minCellFaces = 0;
 };
 
 // polyMesh -> HostTables.  Returns empty string on success, else the reason (CPF_ERR_MESH).

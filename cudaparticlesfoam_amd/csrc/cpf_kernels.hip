@@ -61,6 +61,66 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
     return next;
 }
 
+// Same test for meshes whose cells all have NF faces (every mesh the reference can run is all-hex,
+// src/initCuda.H:64): slot s of cell c is 6c+s, loads are issued back to back, and the IEEE
+// division is only executed for faces that can still be accepted.  The pre-filter is EXACT, not
+// approximate: with fd and den of equal sign, fl(fd/den) <= 1  <=>  |fd| <= |den| (1 is
+// representable and rounding is monotone; |fd| > |den| gives a quotient >= 1 + 2^-52), a zero or
+// opposite-sign pair can never give dT > tol, and den == 0 / NaN fall out of every comparison
+// exactly like the isinf -> -1 substitution of ConvexQuery.cu:89.
+// `pl`/`nb` may be wave-uniform pointers (scalar loads, one fetch per wave) or per-lane ones.
+template <int NF>
+__device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const double4* __restrict__ pl,
+                                           const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    double fd[NF], den[NF];
+    int b[NF];
+#pragma unroll
+    for (int s = 0; s < NF; ++s) {
+        const double4 p = pl[s];
+        fd[s] = p.w - dot3(p, P0);
+        den[s] = dot3(p, Pd);
+        b[s] = nb[s];
+    }
+    int next = cur;
+    double dTmin = 1.1;
+#pragma unroll
+    for (int s = 0; s < NF; ++s) {
+        // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
+        // NaNs that slip through give dT = 0 / NaN and fail dT > tol below, as in the reference
+        const bool reach = (fabs(fd[s]) <= fabs(den[s])) && ((__double2hiint(fd[s]) ^ __double2hiint(den[s])) >= 0);
+        if (reach && fd[s] < kTol && b[s] != token) {
+            const double dT = fd[s] / den[s];
+            if (dT > kTol && dT < dTmin) {
+                dTmin = dT;
+                next = b[s];
+                S = axpy(dT, Pd, P0);
+                outSlot = slotBase + s;
+            }
+        }
+    }
+    return next;
+}
+
+// step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
+enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2 };
+
+template <int VARIANT>
+__device__ __forceinline__ int trace_dispatch(D3& S, const D3& E, int cur, const MeshView& m, int token,
+                                              int& outSlot) {
+    if (VARIANT == kVariantGeneric) return trace_in_cell(S, E, cur, m, token, outSlot);
+    if (VARIANT == kVariantFixedScalar) {
+        // particles are kept sorted by cell, so most waves sit in ONE cell for their first visit:
+        // fetch that cell's planes once per wave through the scalar cache instead of 64 times
+        const int ucur = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != ucur) == 0ull)
+            return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token, outSlot,
+                                  6 * ucur);
+    }
+    return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot, 6 * cur);
+}
+
 // Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
 // 48-byte-per-particle cuRAND XORWOW state of cuda/particles.cu:524-575 with nothing at all.
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -95,7 +155,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 // fused step kernel: one thread per particle, nCyc cycles per launch (1 = the reference's
 // per-cycle structure; >1 keeps the particle in registers between cycles)
 // ------------------------------------------------------------------------------------------------
-template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+template <int VARIANT, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
 __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, double* __restrict__ y,
                                                       double* __restrict__ z, int32_t* __restrict__ cell,
                                                       const int64_t* __restrict__ gid, double* __restrict__ vel,
@@ -129,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
                 bool reflected = false;
                 for (int j = 0; j < kMaxReflect; ++j) {
                     for (int h = 0; h < kMaxHops; ++h) {
-                        next = trace_in_cell(S, E, cur, m, token, outSlot);
+                        next = trace_dispatch<VARIANT>(S, E, cur, m, token, outSlot);
                         ++nHops;
                         if (next == cur || next < 0) break;
                         token = cur;
@@ -171,31 +231,49 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
     if (threadIdx.x < 4 && sCnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
 }
 
-template <bool B, bool R>
+template <int V, bool B, bool R>
 static void launch_step_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
                            const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
                            int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
     if (storeVel)
-        hipLaunchKernelGGL((step_kernel<B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
-                           step0, nCyc, seed, m, counters);
+        hipLaunchKernelGGL((step_kernel<V, B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
+                           sigma, step0, nCyc, seed, m, counters);
     else
-        hipLaunchKernelGGL((step_kernel<B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
-                           step0, nCyc, seed, m, counters);
+        hipLaunchKernelGGL((step_kernel<V, B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
+                           sigma, step0, nCyc, seed, m, counters);
+}
+
+template <int V>
+static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hipStream_t st, double* x, double* y,
+                          double* z, int32_t* cell, const int64_t* gid, double* vel, int64_t n, double dt,
+                          double sigma, uint32_t step0, int nCyc, uint32_t seed, const MeshView& m,
+                          unsigned long long* counters) {
+    if (brown) {
+        if (reflect) launch_step_sv<V, true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+        else launch_step_sv<V, true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    } else {
+        if (reflect) launch_step_sv<V, false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+        else launch_step_sv<V, false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    }
 }
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters) {
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
-    if (brown) {
-        if (reflect) launch_step_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-        else launch_step_sv<true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-    } else {
-        if (reflect) launch_step_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-        else launch_step_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    if (!m.allHex) variant = kVariantGeneric;                 // fixed-slot variants need 6 faces per cell
+    switch (variant) {
+        case kVariantFixed:
+            launch_step_v<kVariantFixed>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            break;
+        case kVariantFixedScalar:
+            launch_step_v<kVariantFixedScalar>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            break;
+        default:
+            launch_step_v<kVariantGeneric>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
     }
     return hipGetLastError();
 }

@@ -83,6 +83,7 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         int32_t k = out.cellOff[(size_t)c + 1];
         if (k < 4) return "cell " + std::to_string(c) + " has fewer than 4 faces";
         out.maxCellFaces = std::max(out.maxCellFaces, k);
+        out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
         out.cellOff[(size_t)c + 1] += out.cellOff[(size_t)c];
     }
     out.planes.resize((size_t)out.nSlots * 4);

@@ -128,7 +128,10 @@ int cpf_num_particles(const cpf_context* ctx, int64_t* n);
 int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel);
 /* cumulative counters since creation: particle-steps done, cells visited, wall reflections, lost */
 int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
-int cpf_set_seed(cpf_context* ctx, uint32_t seed);   /* Brownian stream; default 1591593751 (particles.cu:544) */
+int cpf_set_seed(cpf_context* ctx, uint32_t seed);
+/* tuning knobs, never semantics: "step_variant" = 0 generic CSR walk, 1 all-hex fixed-slot walk,
+ * 2 (default) fixed-slot walk with wave-uniform scalar plane fetches; all bit-identical. */
+int cpf_set_option(cpf_context* ctx, const char* key, double value);   /* Brownian stream; default 1591593751 (particles.cu:544) */
 
 /* ---------------------------------------------------------------------------------------------
  * device-array level (framework hosts that own the particle arrays, multi-GPU sharding)

@@ -208,13 +208,13 @@ void cw_step(double* px, double* py, double* pz, int* cell, double* vel_out, int
              long long* stats /* [hops, reflections, lost] or NULL */,
              double D, const int64_t* gid, uint32_t step0, uint32_t seed) {
     long long H = 0, R = 0, L = 0;
-    for (int c = 0; c < cycles; ++c) {
+    /* particles are independent: all cycles of one particle back to back, one parallel region */
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : H, R, L)
-        for (int i = 0; i < n; ++i) {
-            cw_stats st = {0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        cw_stats st = {0, 0, 0};
+        for (int c = 0; c < cycles; ++c)
             step_one(i, px, py, pz, cell, vel_out, dt, cellOff, planes, nbr, U, &st, D, gid, step0 + (uint32_t)c, seed);
-            H += st.hops; R += st.reflections; L += st.lost;
-        }
+        H += st.hops; R += st.reflections; L += st.lost;
     }
     if (stats) { stats[0] = H; stats[1] = R; stats[2] = L; }
 }

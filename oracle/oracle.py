@@ -38,6 +38,13 @@ def build(force: bool = False) -> None:
         subprocess.run(["make", "-C", HERE, "-s"] + (["-B"] if force else []), check=True)
 
 
+def usable_threads(hw_threads: int) -> int:
+    """Threads the TESTS use: capped (default 16, env CPF_ORACLE_THREADS).  GPU boxes report hundreds of
+    hardware threads that the container may only get a slice of; an oversubscribed OpenMP team crawls."""
+    cap = int(os.environ.get("CPF_ORACLE_THREADS", "16"))
+    return max(1, min(int(hw_threads), cap))
+
+
 def have_ref() -> bool:
     return os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect.so"))
 
@@ -67,7 +74,8 @@ class _TetApi:
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = C.CDLL(path)
-        self.max_threads = getattr(self.lib, self.prefix + "max_threads")()
+        self.hw_threads = getattr(self.lib, self.prefix + "max_threads")()
+        self.max_threads = usable_threads(self.hw_threads)
 
     # ---- face table
     def face_table(self, positions, tets):
@@ -197,7 +205,8 @@ class CellWalk:
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
         L.cw_normal3.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _dp]
-        self.max_threads = L.cw_max_threads()
+        self.hw_threads = L.cw_max_threads()
+        self.max_threads = usable_threads(self.hw_threads)
 
     def build(self, mesh) -> CellTables:
         ncf = int(mesh.n_faces + mesh.n_internal)

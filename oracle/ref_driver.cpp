@@ -169,18 +169,25 @@ void ref_bary_query_disp(double* particles, double* disps, int* tetIDs, int n, c
     });
 }
 
-// One full Lagrangian cycle in the reference's order (src/advect.H:96-161, ConvexPoly build,
-// Brownian term omitted == diffusionCoeff 0 which adds exactly 0, cuda/particles.cu:564-569),
-// repeated `cycles` times.  Used for golden vectors and as the "reference" CPU baseline.
+// Full Lagrangian cycles in the reference's order (src/advect.H:96-161, ConvexPoly build,
+// Brownian term omitted == diffusionCoeff 0 which adds exactly 0, cuda/particles.cu:564-569).
+// Each "thread" (particle) runs its four kernels `cycles` times back to back: particles are
+// independent, so this equals the kernel-by-kernel order and needs a single parallel region.
+// Used for golden vectors and as the "reference" CPU baseline.
 void ref_cycles(double* particles, int* tetIDs, double* vels, double* disps, double dt, int n, int cycles,
                 const int* indices, const double* positions, const double* tetVel, const int* tetfacets,
                 const int* facets, const int* faceinfos, int nthreads) {
-    for (int c = 0; c < cycles; ++c) {
-        ref_advect(particles, tetIDs, vels, disps, dt, n, indices, positions, tetVel, nthreads);
-        ref_locate(particles, tetIDs, disps, n, indices, positions, tetfacets, facets, faceinfos, nthreads);
-        ref_reflect(particles, tetIDs, disps, vels, n, indices, positions, tetfacets, facets, faceinfos, nthreads);
-        ref_move(particles, disps, tetIDs, n, nthreads);
-    }
+    launch(n, nthreads, [&] {
+        for (int c = 0; c < cycles; ++c) {
+            particleAdvectKernelTetVel((Particle*)particles, tetIDs, (vec4d*)vels, (vec4d*)disps, dt, n,
+                                       (vec4i*)indices, (vec3d*)positions, (vec3d*)tetVel);
+            particleLocator((double4*)particles, tetIDs, (vec4d*)disps, n, (vec4i*)indices, (vec3d*)positions,
+                            (vec4i*)tetfacets, (vec4i*)facets, (FaceInfo*)faceinfos);
+            convexReflector((double4*)particles, tetIDs, (vec4d*)disps, (vec4d*)vels, n, (vec4i*)indices,
+                            (vec3d*)positions, (vec4i*)tetfacets, (vec4i*)facets, (FaceInfo*)faceinfos);
+            particleMoveKernel((Particle*)particles, (vec4d*)disps, tetIDs, n);
+        }
+    });
 }
 
 int ref_max_threads(void) {

@@ -52,16 +52,22 @@ def test_initial_locate_matches_bruteforce(setup):
     assert n_out == int((ref < 0).sum()) and 0 < n_out < n
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
-def test_step_bit_exact_vs_cellwalk(setup, field):
+def test_step_bit_exact_vs_cellwalk(setup, field, variant):
+    """Every kernel variant (generic CSR walk, all-hex fixed-slot walk, fixed-slot + wave-uniform scalar
+    plane fetches) against the CPU statement, bit for bit, sorted and unsorted particle order."""
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     U = setup["pitz"][field]
     n = 100000
     xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=99)
+    ctx.set_option("step_variant", variant)
     ctx.set_velocity(U)
     ctx.set_particles(xyz)
     ctx.locate_initial()
     _, cell0 = ctx.get_particles()
+    if variant == 2:
+        ctx.sort_by_cell()                 # the scalar path only triggers on cell-coherent waves
     x, y, z = (xyz[:, k].copy() for k in range(3))
     c = cell0.copy()
     done = 0
@@ -80,6 +86,7 @@ def test_step_bit_exact_vs_cellwalk(setup, field):
     assert c1["cells_visited"] - c0["cells_visited"] == hops
     assert c1["reflections"] - c0["reflections"] == refl
     assert refl > 0   # the case does exercise wall reflection
+    ctx.set_option("step_variant", 2)
 
 
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): times the step-kernel variants on the bench workload and checks that every
+variant gives bit-identical particles.  python tools/sweep.py [--particles 1e7] [--steps 30] [--field uniform]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--particles", type=float, default=1e7)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--field", default="uniform")
+    ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--unsorted", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import bench
+    from cudaparticlesfoam_amd.api import Context
+    from cudaparticlesfoam_amd.cases import pitzdaily as pz
+    from cudaparticlesfoam_amd.parallel import x_slab_renumbering
+    dev = torch.device("cuda", 0)
+    mesh0 = pz.pitzdaily_mesh(); c0, _ = mesh0.cell_centres_volumes()
+    mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
+    centres, _ = mesh.cell_centres_volumes()
+    U = pz.uniform_u(mesh) if args.field == "uniform" else pz.analytic_step_u(mesh, centres)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_mesh(mesh); ctx.set_velocity(U)
+    n = int(args.particles)
+    x0, y0, z0, c0 = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+    g0 = torch.arange(n, dtype=torch.int64, device=dev)
+    if not args.unsorted:
+        ctx.sort_by_cell_dev(x0.data_ptr(), y0.data_ptr(), z0.data_ptr(), c0.data_ptr(), g0.data_ptr(), n)
+    torch.cuda.synchronize()
+    ref = None
+    rows = []
+    for v in [int(s) for s in args.variants.split(",")]:
+        ctx.set_option("step_variant", v)
+        x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
+        p = lambda t: t.data_ptr()   # noqa: E731
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, args.warmup, 0)
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, args.warmup, args.steps, 0)
+        launches, ms = ctx.timing_read()
+        ctx.timing_enable(False)
+        avg = ms / launches
+        same = None
+        if ref is None:
+            ref = (x, y, z, c)
+        else:
+            same = bool(torch.equal(x, ref[0]) and torch.equal(y, ref[1]) and torch.equal(z, ref[2]) and torch.equal(c, ref[3]))
+        rows.append(dict(variant=v, kernel_ms=round(avg, 4), gps=round(n / avg / 1e6, 2), gbs=round(56 * n / avg / 1e6, 1),
+                         identical_to_first=same))
+        print(json.dumps(rows[-1]), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
