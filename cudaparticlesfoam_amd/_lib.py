@@ -40,6 +40,7 @@ SIGNATURES = {
     "cpf_destroy": (_int, [_ctx]),
     "cpf_last_error": (C.c_char_p, [_ctx]),
     "cpf_set_stream": (_int, [_ctx, _vp]),
+    "cpf_use_own_stream": (_int, [_ctx]),
     "cpf_synchronize": (_int, [_ctx]),
     "cpf_set_mesh": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
     "cpf_set_mesh_l64": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),

@@ -63,6 +63,9 @@ class Context:
     def set_stream(self, hip_stream: int):
         self._ck(self.lib.cpf_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def use_own_stream(self):
+        self._ck(self.lib.cpf_use_own_stream(self.h))
+
     def synchronize(self):
         self._ck(self.lib.cpf_synchronize(self.h))
 

@@ -209,7 +209,14 @@ const char* cpf_last_error(const cpf_context* ctx) {
 int cpf_set_stream(cpf_context* ctx, void* hip_stream) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
+    ctx->stream = (hipStream_t)hip_stream;      // NULL == HIP's default stream, a valid choice
+    return CPF_OK;
+}
+
+int cpf_use_own_stream(cpf_context* ctx) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->ownStream;
     return CPF_OK;
 }
 

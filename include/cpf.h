@@ -63,9 +63,11 @@ int cpf_create(int device, cpf_context** out);
 int cpf_destroy(cpf_context* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last cpf_create failure). Never NULL. */
 const char* cpf_last_error(const cpf_context* ctx);
-/* Run all subsequent work on a caller-owned hipStream_t (e.g. the framework's current stream);
- * NULL restores the context's own stream. */
+/* Run all subsequent work on a caller-owned hipStream_t (e.g. the framework's current stream).
+ * NULL is a valid handle: HIP's default (null) stream.  cpf_use_own_stream() goes back to the
+ * context's private non-blocking stream (the default after cpf_create). */
 int cpf_set_stream(cpf_context* ctx, void* hip_stream);
+int cpf_use_own_stream(cpf_context* ctx);
 int cpf_synchronize(cpf_context* ctx);   /* replaces cudaDeviceSynchronize() after every wrapper */
 
 /* ---------------------------------------------------------------------------------------------
