@@ -40,7 +40,9 @@ struct cpf_context {
     void* scratch = nullptr;
     size_t scratchBytes = 0;
     // counters / rng
-    unsigned long long* d_counters = nullptr;   // steps, hops, reflections, lost, + 1 spare
+    // [kCounterSlots][4] = steps, hops, reflections, lost, sharded by block id (one hot word would
+    // serialise every block of every launch on a single L2 atomic unit), then 4 scratch words
+    unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
     int stepVariant = 2;                        // cpf_set_option("step_variant"): 0 generic CSR, 1 fixed, 2 fixed+scalar
@@ -174,8 +176,8 @@ int cpf_create(int device, cpf_context** out) {
     if (!ctx) return fail(nullptr, CPF_ERR_NOMEM, "cpf_create: out of host memory");
     ctx->device = device;
     e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         std::string m = std::string("cpf_create: ") + hipGetErrorString(e);
         if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -345,7 +347,7 @@ int cpf_locate_initial(cpf_context* ctx, int64_t* nOutside) {
     if (r) return r;
     ctx->located = true;
     if (nOutside) {
-        unsigned long long* cnt = ctx->d_counters + 4;
+        unsigned long long* cnt = ctx->d_counters + cpf::kCounterSlots * 4;
         CPF_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
         CPF_HIP(ctx, cpf::launch_count_negative(ctx->stream, ctx->cell, ctx->n, cnt));
         unsigned long long h = 0;
@@ -460,10 +462,14 @@ int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel
 int cpf_get_counters(cpf_context* ctx, int64_t out[4]) {
     CPF_REQUIRE(ctx, ctx && out, CPF_ERR_ARG, "null argument");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long h[4];
-    CPF_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h((size_t)cpf::kCounterSlots * 4);
+    CPF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->d_counters, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 4; ++k) out[k] = (int64_t)h[k];
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long sum = 0;
+        for (int s = 0; s < cpf::kCounterSlots; ++s) sum += h[(size_t)s * 4 + k];
+        out[k] = (int64_t)sum;
+    }
     return CPF_OK;
 }
 
@@ -584,7 +590,7 @@ int cpf_stage_locate_initial(cpf_context* ctx, const double* particles, int32_t*
 int cpf_stage_count_outside(cpf_context* ctx, const int32_t* ids, int64_t n, int64_t* nNegative) {
     CPF_REQUIRE(ctx, ctx && nNegative && (ids || n == 0) && n >= 0, CPF_ERR_ARG, "cpf_stage_count_outside: bad arguments");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long* cnt = ctx->d_counters + 4;
+    unsigned long long* cnt = ctx->d_counters + cpf::kCounterSlots * 4;
     CPF_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
     CPF_HIP(ctx, cpf::launch_count_negative(ctx->stream, ids, n, cnt));
     unsigned long long h = 0;

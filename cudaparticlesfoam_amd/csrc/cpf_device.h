@@ -9,6 +9,7 @@
 namespace cpf {
 
 constexpr int kBlock = 256;   // 4 waves of 64
+constexpr int kCounterSlots = 1024;   // statistics counters are sharded over this many 32-byte slots
 
 // Mesh as the kernels see it (all arrays resident in HBM, L2-resident for tutorial-size meshes)
 struct MeshView {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
             cell[i] = CPF_CELL_FROZEN;
         }
     }
-    // block-level counter reduction: 4 global atomics per block
+    // block-level counter reduction: 4 global atomics per block, sharded over kCounterSlots slots
     __shared__ unsigned sCnt[4];
     if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
     __syncthreads();
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
         atomicAdd(&sCnt[2], nRefl); atomicAdd(&sCnt[3], nLost);
     }
     __syncthreads();
-    if (threadIdx.x < 4 && sCnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
+    if (threadIdx.x < 4 && sCnt[threadIdx.x])
+        atomicAdd(&counters[(blockIdx.x & (kCounterSlots - 1)) * 4 + threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
 }
 
 template <int V, bool B, bool R>

@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch bundles its own HIP runtime: it must be the FIRST HIP runtime loaded into the process,
+    # otherwise (libcudaParticleAdvection.so loaded first -> /opt/rocm's runtime) torch finds no GPU
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
