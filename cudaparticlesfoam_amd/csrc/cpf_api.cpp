@@ -27,6 +27,7 @@ struct cpf_context {
     int32_t* d_nbr = nullptr;
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
+    double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes)
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;
     size_t meshBytes = 0;
@@ -45,7 +46,9 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
-    int stepVariant = 2;                        // cpf_set_option("step_variant"): 0 generic CSR, 1 fixed, 2 fixed+scalar
+    int pfBlocks = 256 * 6;                     // persistent-grid size of variant 4 ("pf_blocks")
+    bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
+    int stepVariant = 5;                        // cpf_set_option("step_variant"), see include/cpf.h
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -79,6 +82,7 @@ void freeDev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 cpf::MeshView meshView(const cpf_context* c) {
     cpf::MeshView m;
     m.cellOff = c->d_cellOff; m.planes = c->d_planes; m.nbr = c->d_nbr; m.U = c->d_U;
+    m.cellRec = c->d_cellRec;
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6) ? 1 : 0;
     return m;
@@ -110,7 +114,7 @@ int sortEndBit(const cpf_context* ctx) {
 }
 
 void freeMesh(cpf_context* c) {
-    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3);
+    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec);
     freeDev(c->d_binOff); freeDev(c->d_binCells);
     c->haveMesh = c->haveU = false; c->meshBytes = 0;
 }
@@ -149,6 +153,12 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U, (size_t)nCells * sizeof(double4)));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U3, (size_t)nCells * 3 * sizeof(double)));
     CPF_HIP(ctx, hipMemset(ctx->d_U, 0, (size_t)nCells * sizeof(double4)));
+    if (ctx->host.minCellFaces == 6 && ctx->host.maxCellFaces == 6) {
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
+        CPF_HIP(ctx, cpf::launch_build_cell_records(ctx->stream, ctx->d_planes, ctx->d_nbr, ctx->d_U, ctx->d_cellRec, nCells));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->meshBytes += (size_t)nCells * 256;
+    }
     ctx->meshBytes += (size_t)nCells * (sizeof(double4) + 24);
     ctx->haveMesh = true;
     ctx->located = false;
@@ -267,6 +277,7 @@ int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_U3, U, (size_t)nCells * 24, hipMemcpyHostToDevice, ctx->stream));
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, ctx->d_U3, ctx->d_U, nCells));
+    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, nCells));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // U may be pageable host memory owned by the caller
     ctx->haveU = true;
     return CPF_OK;
@@ -278,6 +289,7 @@ int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells) {
     CPF_REQUIRE(ctx, dU && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity_dev: bad arguments");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, dU, ctx->d_U, nCells));
+    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, nCells));
     ctx->haveU = true;
     return CPF_OK;
 }
@@ -372,7 +384,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     const bool reflect = (flags & CPF_STEP_NO_REFLECT) == 0;
     const cpf::MeshView m = meshView(ctx);
     const bool fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
-    const int nLaunch = fuse ? (nCycles > 0 ? 1 : 0) : nCycles;
+    const int nLaunch = fuse ? 1 : nCycles;   // fused with nCycles == 0: load+store only (bandwidth calibration)
     const int cycPerLaunch = fuse ? nCycles : 1;
     for (int c = 0; c < nLaunch; ++c) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -385,7 +397,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                      reflect, storeVel, m, ctx->d_counters, ctx->stepVariant));
+                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
+                                      ctx->pfBlocks));
         if (ctx->timing) {
             CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             ctx->events.emplace_back(e0, e1);
@@ -477,8 +490,17 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
     const std::string k(key);
     if (k == "step_variant") {
-        CPF_REQUIRE(ctx, value == 0 || value == 1 || value == 2, CPF_ERR_ARG, "step_variant must be 0, 1 or 2");
+        CPF_REQUIRE(ctx, value >= 0 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..5");
         ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    if (k == "stats") {
+        ctx->stats = value != 0;
+        return CPF_OK;
+    }
+    if (k == "pf_blocks") {
+        CPF_REQUIRE(ctx, value >= 1 && value <= 65536, CPF_ERR_ARG, "pf_blocks must be in [1, 65536]");
+        ctx->pfBlocks = (int)value;
         return CPF_OK;
     }
     return fail(ctx, CPF_ERR_ARG, "cpf_set_option: unknown key '" + k + "'");

@@ -17,6 +17,7 @@ struct MeshView {
     const double4* planes;    // [nSlots]   (nx, ny, nz, d), unit normal into the cell
     const int32_t* nbr;       // [nSlots]
     const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
+    const double4* cellRec;   // [nCells][8] packed 256-B records (all-hex meshes only, else null)
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s)
 };
@@ -30,7 +31,8 @@ struct GridView {
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant);
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
+                       int pfBlocks);
 hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
                                  int64_t n, const MeshView& m, const GridView& g);
 hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,
@@ -41,6 +43,9 @@ hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, 
                               const int64_t* gid, const double* vel, double* xyzw, int32_t* cellOut, double* velOut,
                               int64_t n);
 hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out);
+hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,
+                                     double4* rec, int64_t nCells);
+hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells);
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
 
 // stage-by-stage kernels on the reference's AoS layouts

@@ -12,6 +12,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 namespace cpf {
 
 // ------------------------------------------------------------------------------------------------
@@ -24,6 +26,10 @@ __device__ __forceinline__ double dot3(const double4& n, const D3& v) {
 }
 __device__ __forceinline__ double dot3(const D3& n, const D3& v) {
     return fma(n.z, v.z, fma(n.y, v.y, n.x * v.x));
+}
+// signed plane distance (Cf - P).n = d - n.P as one fma chain (<= 0 on the inner side of the face)
+__device__ __forceinline__ double plane_dist(const double4& pl, const D3& P) {
+    return fma(-pl.z, P.z, fma(-pl.y, P.y, fma(-pl.x, P.x, pl.w)));
 }
 __device__ __forceinline__ D3 axpy(double s, const D3& a, const D3& b) {
     return {fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)};
@@ -46,7 +52,7 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
     const int s0 = m.cellOff[cur], s1 = m.cellOff[cur + 1];
     for (int s = s0; s < s1; ++s) {
         const double4 pl = m.planes[s];
-        const double fd = pl.w - dot3(pl, P0);          // (Cf - P0).n  (<= 0 inside)
+        const double fd = plane_dist(pl, P0);           // (Cf - P0).n  (<= 0 inside)
         double dT = fd / dot3(pl, Pd);
         if (__builtin_isinf(dT)) dT = -1.0;             // segment parallel to the face
         const int nb = m.nbr[s];
@@ -74,52 +80,90 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
                                            const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
-    double fd[NF], den[NF];
-    int b[NF];
-#pragma unroll
-    for (int s = 0; s < NF; ++s) {
-        const double4 p = pl[s];
-        fd[s] = p.w - dot3(p, P0);
-        den[s] = dot3(p, Pd);
-        b[s] = nb[s];
-    }
-    int next = cur;
+    int next = cur, best = -1;
     double dTmin = 1.1;
 #pragma unroll
     for (int s = 0; s < NF; ++s) {
+        const double4 p = pl[s];
+        const double den = dot3(p, Pd);
+        // no lane of the wave moves across this face's plane (den == +-0 exactly, e.g. the front/back
+        // faces of a one-cell-thick mesh, or wall-parallel faces in aligned flow): dT would be +-inf
+        // (-> -1) or NaN, never accepted (ConvexQuery.cu:86-95), so the face costs nothing more
+        if (__ballot(den != 0.0) == 0ull) continue;
+        const int bs = nb[s];
+        const double fd = plane_dist(p, P0);
         // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
         // NaNs that slip through give dT = 0 / NaN and fail dT > tol below, as in the reference
-        const bool reach = (fabs(fd[s]) <= fabs(den[s])) && ((__double2hiint(fd[s]) ^ __double2hiint(den[s])) >= 0);
-        if (reach && fd[s] < kTol && b[s] != token) {
-            const double dT = fd[s] / den[s];
-            if (dT > kTol && dT < dTmin) {
-                dTmin = dT;
-                next = b[s];
-                S = axpy(dT, Pd, P0);
-                outSlot = slotBase + s;
+        const bool reach = (fabs(fd) <= fabs(den)) && ((__double2hiint(fd) ^ __double2hiint(den)) >= 0);
+        const bool cand = reach && fd < kTol && bs != token;
+        // wave-uniform skip: hipcc would otherwise if-convert and run the ~12-instruction IEEE division for
+        // every face of every lane; most faces have no candidate lane at all
+        if (__ballot(cand) != 0ull) {
+            if (cand) {
+                const double dT = fd / den;
+                if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
             }
         }
+    }
+    if (best >= 0) {                   // exit point of the LAST accepted face == the smallest dT
+        S = axpy(dTmin, Pd, P0);
+        outSlot = slotBase + best;
     }
     return next;
 }
 
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
-enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2 };
+enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantLds = 3, kVariantPrefetch = 4,
+       kVariantCoop = 5 };
 
+// Where a walk gets its mesh data from.  Every tracer runs the same arithmetic in the same order.
 template <int VARIANT>
-__device__ __forceinline__ int trace_dispatch(D3& S, const D3& E, int cur, const MeshView& m, int token,
-                                              int& outSlot) {
-    if (VARIANT == kVariantGeneric) return trace_in_cell(S, E, cur, m, token, outSlot);
-    if (VARIANT == kVariantFixedScalar) {
-        // particles are kept sorted by cell, so most waves sit in ONE cell for their first visit:
-        // fetch that cell's planes once per wave through the scalar cache instead of 64 times
-        const int ucur = __builtin_amdgcn_readfirstlane(cur);
-        if (__ballot(cur != ucur) == 0ull)
-            return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token, outSlot,
-                                  6 * ucur);
+struct GlobalTracer {
+    const MeshView& m;
+    __device__ __forceinline__ int trace(D3& S, const D3& E, int cur, int token, int& outSlot) const {
+        if (VARIANT == kVariantGeneric) return trace_in_cell(S, E, cur, m, token, outSlot);
+        if (VARIANT == kVariantFixedScalar) {
+            // particles are kept sorted by cell, so most waves sit in ONE cell for their first visit:
+            // fetch that cell's planes once per wave through the scalar cache instead of 64 times
+            const int ucur = __builtin_amdgcn_readfirstlane(cur);
+            if (__ballot(cur != ucur) == 0ull)
+                return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token,
+                                      outSlot, 6 * ucur);
+        }
+        return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
+                              6 * cur);
     }
-    return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot, 6 * cur);
-}
+    __device__ __forceinline__ double4 velocity(int cur) const { return m.U[cur]; }
+};
+
+// LDS-staged tracer: the block copies the face planes, neighbour ids and velocities of a window of
+// kWin consecutive cells around its particles into LDS once (coalesced 16-byte loads), and every
+// visit inside the window is served by ds_read_b128 (same-cell lanes broadcast) instead of a
+// 64-address gather through the vector-memory path.  Cells outside the window use global loads.
+constexpr int kWin = 128;    // cells staged per block: 128 * (6*32 + 6*4 + 32) B = 31 KiB
+constexpr int kBack = 40;    // of which this many lie below the block's smallest cell id
+struct StagedCells {
+    double4 planes[kWin * 6];
+    double4 U[kWin];
+    int32_t nbr[kWin * 6];
+};
+struct LdsTracer {
+    const MeshView& m;
+    const StagedCells* sm;
+    int base, cnt;
+    __device__ __forceinline__ int trace(D3& S, const D3& E, int cur, int token, int& outSlot) const {
+        const int r = cur - base;
+        if ((unsigned)r < (unsigned)cnt)
+            return trace_fixed<6>(S, E, cur, sm->planes + 6 * r, sm->nbr + 6 * r, token, outSlot, 6 * cur);
+        return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
+                              6 * cur);
+    }
+    __device__ __forceinline__ double4 velocity(int cur) const {
+        const int r = cur - base;
+        if ((unsigned)r < (unsigned)cnt) return sm->U[r];
+        return m.U[cur];
+    }
+};
 
 // Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
 // 48-byte-per-particle cuRAND XORWOW state of cuda/particles.cu:524-575 with nothing at all.
@@ -152,9 +196,73 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused step kernel: one thread per particle, nCyc cycles per launch (1 = the reference's
-// per-cycle structure; >1 keeps the particle in registers between cycles)
+// fused step: one thread per particle, nCyc cycles per launch (1 = the reference's per-cycle
+// structure; >1 keeps the particle in registers between cycles)
 // ------------------------------------------------------------------------------------------------
+struct StepStats { unsigned steps, hops, refl, lost; };
+
+template <class TRACER, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView& m, D3& P, int& cur, D3& v,
+                                                uint64_t id, double dt, double sigma, uint32_t step0, int nCyc,
+                                                uint32_t seed, StepStats& st) {
+    for (int c = 0; c < nCyc; ++c) {
+        if (cur < 0) { cur = CPF_CELL_FROZEN; break; }           // lost in the previous cycle: w = 0
+        ++st.steps;
+        // ---- advect (cuda/particles.cu:355-362): disp = (P + dt*U[cell]) - P
+        const double4 u = tr.velocity(cur);
+        v = {u.x, u.y, u.z};
+        const D3 Pn = axpy(dt, v, P);
+        D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+        if (BROWNIAN) {                                          // particles.cu:560-569
+            const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+            disp = axpy(sigma, xi, disp);
+        }
+        // ---- locate + reflect (ConvexQuery.cu:135-216, :320-436)
+        D3 E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+        D3 S = P, hit = P;
+        int token = INT32_MIN, next = cur, outSlot = 0;
+        bool reflected = false;
+        for (int j = 0; j < kMaxReflect; ++j) {
+            for (int h = 0; h < kMaxHops; ++h) {
+                next = tr.trace(S, E, cur, token, outSlot);
+                ++st.hops;
+                if (next == cur || next < 0) break;
+                token = cur;
+                cur = next;
+            }
+            if (next >= 0 || !REFLECT) break;
+            // wall: mirror end point and velocity about the boundary face (ConvexQuery.cu:286-309)
+            hit = S; reflected = true; ++st.refl;
+            const double4 pl = m.planes[outSlot];
+            const D3 nn = {pl.x, pl.y, pl.z};
+            const double sd = dot3(pl, E) - pl.w;
+            E = axpy(-2.0 * sd, nn, E);
+            v = axpy(-2.0 * dot3(pl, v), nn, v);
+            token = next;
+        }
+        // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit
+        if (reflected) P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
+        else P = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+        if (next < 0) { next = CPF_CELL_LOST; ++st.lost; }
+        cur = next;
+    }
+}
+
+// block-level counter reduction: 4 global atomics per block, sharded over kCounterSlots slots
+__device__ __forceinline__ void flush_stats(StepStats st, unsigned long long* __restrict__ counters, unsigned* sCnt) {
+    if (counters == nullptr) return;             // statistics switched off (cpf_set_option "stats" 0)
+    if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    st.steps = wave_sum(st.steps); st.hops = wave_sum(st.hops); st.refl = wave_sum(st.refl); st.lost = wave_sum(st.lost);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sCnt[0], st.steps); atomicAdd(&sCnt[1], st.hops);
+        atomicAdd(&sCnt[2], st.refl); atomicAdd(&sCnt[3], st.lost);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && sCnt[threadIdx.x])
+        atomicAdd(&counters[(blockIdx.x & (kCounterSlots - 1)) * 4 + threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
+}
+
 template <int VARIANT, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
 __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, double* __restrict__ y,
                                                       double* __restrict__ z, int32_t* __restrict__ cell,
@@ -163,54 +271,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
                                                       uint32_t seed, MeshView m,
                                                       unsigned long long* __restrict__ counters) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    unsigned nSteps = 0, nHops = 0, nRefl = 0, nLost = 0;
+    StepStats st = {0, 0, 0, 0};
     if (i < n) {
         int cur = cell[i];
         if (cur >= 0) {
             D3 P = {x[i], y[i], z[i]};
             D3 v = {0, 0, 0};
             const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
-            for (int c = 0; c < nCyc; ++c) {
-                if (cur < 0) { cur = CPF_CELL_FROZEN; break; }   // lost in the previous cycle: w = 0
-                ++nSteps;
-                // ---- advect (cuda/particles.cu:355-362): disp = (P + dt*U[cell]) - P
-                const double4 u = m.U[cur];
-                v = {u.x, u.y, u.z};
-                const D3 Pn = axpy(dt, v, P);
-                D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
-                if (BROWNIAN) {                                  // particles.cu:560-569
-                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
-                    disp = axpy(sigma, xi, disp);
-                }
-                // ---- locate + reflect (ConvexQuery.cu:135-216, :320-436)
-                D3 E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
-                D3 S = P, hit = P;
-                int token = INT32_MIN, next = cur, outSlot = 0;
-                bool reflected = false;
-                for (int j = 0; j < kMaxReflect; ++j) {
-                    for (int h = 0; h < kMaxHops; ++h) {
-                        next = trace_dispatch<VARIANT>(S, E, cur, m, token, outSlot);
-                        ++nHops;
-                        if (next == cur || next < 0) break;
-                        token = cur;
-                        cur = next;
-                    }
-                    if (next >= 0 || !REFLECT) break;
-                    // wall: mirror end point and velocity about the boundary face (ConvexQuery.cu:286-309)
-                    hit = S; reflected = true; ++nRefl;
-                    const double4 pl = m.planes[outSlot];
-                    const D3 nn = {pl.x, pl.y, pl.z};
-                    const double sd = dot3(pl, E) - pl.w;
-                    E = axpy(-2.0 * sd, nn, E);
-                    v = axpy(-2.0 * dot3(pl, v), nn, v);
-                    token = next;
-                }
-                // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit
-                if (reflected) P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
-                else P = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
-                if (next < 0) { next = CPF_CELL_LOST; ++nLost; }
-                cur = next;
-            }
+            const GlobalTracer<VARIANT> tr{m};
+            particle_cycles<GlobalTracer<VARIANT>, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0,
+                                                                                 nCyc, seed, st);
             x[i] = P.x; y[i] = P.y; z[i] = P.z;
             cell[i] = cur;
             if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
@@ -218,18 +288,242 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
             cell[i] = CPF_CELL_FROZEN;
         }
     }
-    // block-level counter reduction: 4 global atomics per block, sharded over kCounterSlots slots
     __shared__ unsigned sCnt[4];
-    if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
+    flush_stats(st, counters, sCnt);
+}
+
+// Persistent, software-pipelined variant: a fixed grid (a few blocks per CU) strides over the cloud and
+// each thread issues the loads of its NEXT particle before it walks the current one, so the HBM
+// round trip of the streaming state overlaps the walk instead of preceding it.
+template <int VARIANT, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__global__ __launch_bounds__(kBlock) void step_kernel_pf(double* __restrict__ x, double* __restrict__ y,
+                                                         double* __restrict__ z, int32_t* __restrict__ cell,
+                                                         const int64_t* __restrict__ gid, double* __restrict__ vel,
+                                                         int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
+                                                         uint32_t seed, MeshView m,
+                                                         unsigned long long* __restrict__ counters) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    StepStats st = {0, 0, 0, 0};
+    const GlobalTracer<VARIANT> tr{m};
+    int cNext = CPF_CELL_FROZEN;
+    D3 pNext = {0, 0, 0};
+    if (i < n) { cNext = cell[i]; pNext = {x[i], y[i], z[i]}; }
+    for (; i < n; i += stride) {
+        int cur = cNext;
+        D3 P = pNext;
+        const int64_t j = i + stride;
+        if (j < n) { cNext = cell[j]; pNext = {x[j], y[j], z[j]}; }      // in flight during the walk below
+        if (cur >= 0) {
+            D3 v = {0, 0, 0};
+            const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
+            particle_cycles<GlobalTracer<VARIANT>, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0,
+                                                                                 nCyc, seed, st);
+            x[i] = P.x; y[i] = P.y; z[i] = P.z;
+            cell[i] = cur;
+            if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
+        } else if (cur == CPF_CELL_LOST) {
+            cell[i] = CPF_CELL_FROZEN;
+        }
+    }
+    __shared__ unsigned sCnt[4];
+    flush_stats(st, counters, sCnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative variant (all-hex meshes).  Mesh data lives in packed 256-byte cell records
+// (6 planes | U | 6 neighbour ids).  Each round, a wave finds the distinct cells its busy lanes sit in
+// (ballot + readlane), fetches up to four whole records with ONE coalesced 16-byte-per-lane load
+// (16 lanes per record) into its private LDS slots, and every lane then reads its cell's planes with
+// ds_read_b128 (same-cell lanes broadcast).  That replaces 18 scattered per-lane gathers per visit
+// and their serialised round trips by a single L2 round trip per visit.  Lanes whose cell did not
+// get a slot (more than four distinct cells in the wave: unsorted clouds) read the record directly
+// from global memory in the same round, so every busy lane advances every round.
+// The walk is written as a wave-synchronous state machine; per lane it performs exactly the loop
+// nest of particle_cycles (<= 50 hops per segment, <= 5 reflections), in the same arithmetic order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoopSlots = 4;
+
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__global__ __launch_bounds__(kBlock) void step_kernel_coop(double* __restrict__ x, double* __restrict__ y,
+                                                           double* __restrict__ z, int32_t* __restrict__ cell,
+                                                           const int64_t* __restrict__ gid, double* __restrict__ vel,
+                                                           int64_t n, double dt, double sigma, uint32_t step0,
+                                                           int nCyc, uint32_t seed, MeshView m,
+                                                           unsigned long long* __restrict__ counters) {
+    __shared__ double4 sRec[kBlock / 64][kCoopSlots][8];
+    __shared__ unsigned sCnt[4];
+    const int lane = threadIdx.x & 63;
+    double4(*slots)[8] = sRec[threadIdx.x >> 6];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int cur = (i < n) ? cell[i] : CPF_CELL_FROZEN;
+    const bool wasLost = cur == CPF_CELL_LOST;
+    const bool hadParticle = cur >= 0;
+    bool valid = hadParticle;
+    D3 P = {0, 0, 0}, v = {0, 0, 0};
+    if (valid) P = {x[i], y[i], z[i]};
+    const uint64_t id = (valid && gid) ? (uint64_t)gid[i] : (uint64_t)i;
+    StepStats st = {0, 0, 0, 0};
+
+    for (int c = 0; c < nCyc; ++c) {
+        if (valid && cur < 0) { cur = CPF_CELL_FROZEN; valid = false; }      // lost in the previous cycle: w = 0
+        bool busy = valid;
+        bool needAdvect = busy, reflected = false, lostNow = false;
+        int token = INT32_MIN, h = 0, j = 0;
+        D3 S = P, E = P, hit = P;
+        if (busy) ++st.steps;
+        while (__ballot(busy) != 0ull) {
+            // ---- distinct cells of the busy lanes -> slots (wave-uniform scalars)
+            unsigned long long todo = __ballot(busy);
+            int myslot = -1, c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+#pragma unroll
+            for (int k = 0; k < kCoopSlots; ++k) {
+                if (todo != 0ull) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int ck = __builtin_amdgcn_readlane(cur, leader);
+                    const bool mine = busy && cur == ck;
+                    if (mine) myslot = k;
+                    todo &= ~__ballot(mine);
+                    if (k == 0) c0 = ck; else if (k == 1) c1 = ck; else if (k == 2) c2 = ck; else c3 = ck;
+                }
+            }
+            // ---- one coalesced load: lanes 16g..16g+15 copy record g (256 B) into LDS slot g
+            const int g = lane >> 4;
+            const int cg = g == 0 ? c0 : (g == 1 ? c1 : (g == 2 ? c2 : c3));
+            if (cg >= 0) {
+                const double2 val = reinterpret_cast<const double2*>(m.cellRec + 8 * (int64_t)cg)[lane & 15];
+                reinterpret_cast<double2*>(slots[g])[lane & 15] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- every busy lane does one cell visit
+            if (busy) {
+                int next, outSlot = 0;
+                double4 wallPlane;
+                if (myslot >= 0) {
+                    const double4* rec = slots[myslot];
+                    if (needAdvect) {
+                        const double4 u = rec[6];
+                        v = {u.x, u.y, u.z};
+                    }
+                    if (needAdvect) {
+                        const D3 Pn = axpy(dt, v, P);                              // particles.cu:355-362
+                        D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                        if (BROWNIAN) disp = axpy(sigma, normal3(id, step0 + (uint32_t)c, seed), disp);
+                        E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                        needAdvect = false;
+                    }
+                    next = trace_fixed<6>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                    wallPlane = rec[outSlot];
+                } else {
+                    const double4* rec = m.cellRec + 8 * (int64_t)cur;
+                    if (needAdvect) {
+                        const double4 u = rec[6];
+                        v = {u.x, u.y, u.z};
+                        const D3 Pn = axpy(dt, v, P);
+                        D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                        if (BROWNIAN) disp = axpy(sigma, normal3(id, step0 + (uint32_t)c, seed), disp);
+                        E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                        needAdvect = false;
+                    }
+                    next = trace_fixed<6>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                    wallPlane = next < 0 ? rec[outSlot] : make_double4(0, 0, 0, 0);
+                }
+                ++st.hops;
+                if (next == cur) {
+                    busy = false;                                                  // segment ends in this cell
+                } else if (next < 0) {                                             // boundary face
+                    if (!REFLECT) { busy = false; lostNow = true; }
+                    else {
+                        // mirror end point and velocity about the wall (ConvexQuery.cu:286-309)
+                        hit = S; reflected = true; ++st.refl;
+                        const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
+                        const double sd = dot3(wallPlane, E) - wallPlane.w;
+                        E = axpy(-2.0 * sd, nn, E);
+                        v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
+                        token = next;
+                        h = 0;
+                        if (++j == kMaxReflect) { busy = false; lostNow = true; }  // still on a wall after 5 bounces
+                    }
+                } else {
+                    token = cur;
+                    cur = next;
+                    if (++h == kMaxHops) busy = false;                             // hop cap: keep the last cell
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                                       // slots are rewritten next round
+        }
+        // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit; else P + disp == E
+        if (valid) {
+            if (reflected) P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
+            else P = E;
+            if (lostNow) { cur = CPF_CELL_LOST; ++st.lost; }
+        }
+    }
+    if (hadParticle) {
+        x[i] = P.x; y[i] = P.y; z[i] = P.z;
+        cell[i] = cur;
+        if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
+    } else if (wasLost) {
+        cell[i] = CPF_CELL_FROZEN;
+    }
+    flush_stats(st, counters, sCnt);
+}
+
+// LDS-staged variant (all-hex meshes): see LdsTracer
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__global__ __launch_bounds__(kBlock) void step_kernel_lds(double* __restrict__ x, double* __restrict__ y,
+                                                          double* __restrict__ z, int32_t* __restrict__ cell,
+                                                          const int64_t* __restrict__ gid, double* __restrict__ vel,
+                                                          int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
+                                                          uint32_t seed, MeshView m,
+                                                          unsigned long long* __restrict__ counters) {
+    __shared__ StagedCells sm;
+    __shared__ int sMin;
+    __shared__ unsigned sCnt[4];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int cur = (i < n) ? cell[i] : CPF_CELL_FROZEN;
+    D3 P = {0, 0, 0};
+    if (cur >= 0) P = {x[i], y[i], z[i]};
+    // smallest active cell id of the block: wave min by butterfly shuffles, then one LDS atomic per wave
+    if (threadIdx.x == 0) sMin = INT32_MAX;
     __syncthreads();
-    nSteps = wave_sum(nSteps); nHops = wave_sum(nHops); nRefl = wave_sum(nRefl); nLost = wave_sum(nLost);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&sCnt[0], nSteps); atomicAdd(&sCnt[1], nHops);
-        atomicAdd(&sCnt[2], nRefl); atomicAdd(&sCnt[3], nLost);
+    int mn = cur >= 0 ? cur : INT32_MAX;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+    if ((threadIdx.x & 63) == 0 && mn != INT32_MAX) atomicMin(&sMin, mn);
+    __syncthreads();
+    const int blockMin = sMin;
+    int base = 0, cnt = 0;
+    if (blockMin != INT32_MAX) {
+        base = max(0, min(blockMin - kBack, m.nCells - kWin));
+        cnt = min(kWin, m.nCells - base);
+        // cooperative, coalesced copy: 16 bytes per thread per step
+        const double2* gp = reinterpret_cast<const double2*>(m.planes + 6 * (int64_t)base);
+        double2* sp = reinterpret_cast<double2*>(sm.planes);
+        for (int k = threadIdx.x; k < cnt * 12; k += kBlock) sp[k] = gp[k];
+        const double2* gu = reinterpret_cast<const double2*>(m.U + base);
+        double2* su = reinterpret_cast<double2*>(sm.U);
+        for (int k = threadIdx.x; k < cnt * 2; k += kBlock) su[k] = gu[k];
+        const int2* gn = reinterpret_cast<const int2*>(m.nbr + 6 * (int64_t)base);   // 24*base bytes: 8-aligned
+        int2* sn = reinterpret_cast<int2*>(sm.nbr);
+        for (int k = threadIdx.x; k < cnt * 3; k += kBlock) sn[k] = gn[k];
     }
     __syncthreads();
-    if (threadIdx.x < 4 && sCnt[threadIdx.x])
-        atomicAdd(&counters[(blockIdx.x & (kCounterSlots - 1)) * 4 + threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
+    StepStats st = {0, 0, 0, 0};
+    if (cur >= 0) {
+        D3 v = {0, 0, 0};
+        const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
+        const LdsTracer tr{m, &sm, base, cnt};
+        particle_cycles<LdsTracer, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0, nCyc, seed, st);
+        x[i] = P.x; y[i] = P.y; z[i] = P.z;
+        cell[i] = cur;
+        if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
+    } else if (cur == CPF_CELL_LOST && i < n) {
+        cell[i] = CPF_CELL_FROZEN;
+    }
+    flush_stats(st, counters, sCnt);
 }
 
 template <int V, bool B, bool R>
@@ -241,6 +535,43 @@ static void launch_step_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, 
                            sigma, step0, nCyc, seed, m, counters);
     else
         hipLaunchKernelGGL((step_kernel<V, B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
+                           sigma, step0, nCyc, seed, m, counters);
+}
+
+template <bool B, bool R>
+static void launch_step_lds_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
+                               const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
+                               int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
+    if (storeVel)
+        hipLaunchKernelGGL((step_kernel_lds<B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
+                           step0, nCyc, seed, m, counters);
+    else
+        hipLaunchKernelGGL((step_kernel_lds<B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
+                           sigma, step0, nCyc, seed, m, counters);
+}
+
+template <bool B, bool R>
+static void launch_step_pf_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
+                              const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
+                              int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
+    if (storeVel)
+        hipLaunchKernelGGL((step_kernel_pf<kVariantFixedScalar, B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid,
+                           vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+    else
+        hipLaunchKernelGGL((step_kernel_pf<kVariantFixedScalar, B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid,
+                           vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+}
+
+template <bool B, bool R>
+static void launch_step_coop_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z,
+                                int32_t* cell, const int64_t* gid, double* vel, int64_t n, double dt, double sigma,
+                                uint32_t step0, int nCyc, uint32_t seed, const MeshView& m,
+                                unsigned long long* counters) {
+    if (storeVel)
+        hipLaunchKernelGGL((step_kernel_coop<B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
+                           step0, nCyc, seed, m, counters);
+    else
+        hipLaunchKernelGGL((step_kernel_coop<B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
                            sigma, step0, nCyc, seed, m, counters);
 }
 
@@ -260,7 +591,8 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant) {
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
+                       int pfBlocks) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
@@ -269,6 +601,35 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     switch (variant) {
         case kVariantFixed:
             launch_step_v<kVariantFixed>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            break;
+        case kVariantCoop:
+            if (brown) {
+                if (reflect) launch_step_coop_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_coop_sv<true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            } else {
+                if (reflect) launch_step_coop_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_coop_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            }
+            break;
+        case kVariantPrefetch: {
+            const dim3 pgrid((unsigned)std::min<int64_t>(grid.x, (int64_t)pfBlocks));
+            if (brown) {
+                if (reflect) launch_step_pf_sv<true, true>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_pf_sv<true, false>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            } else {
+                if (reflect) launch_step_pf_sv<false, true>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_pf_sv<false, false>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            }
+            break;
+        }
+        case kVariantLds:
+            if (brown) {
+                if (reflect) launch_step_lds_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_lds_sv<true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            } else {
+                if (reflect) launch_step_lds_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+                else launch_step_lds_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            }
             break;
         case kVariantFixedScalar:
             launch_step_v<kVariantFixedScalar>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
@@ -462,7 +823,7 @@ __global__ __launch_bounds__(kBlock) void locate_initial_kernel(const double* __
             bool inside = true;
             for (int s = m.cellOff[c]; s < m.cellOff[c + 1]; ++s) {
                 const double4 pl = m.planes[s];
-                if (!(pl.w - dot3(pl, P) <= 0.0)) { inside = false; break; }
+                if (!(plane_dist(pl, P) <= 0.0)) { inside = false; break; }
             }
             if (inside) found = c;
         }
@@ -563,6 +924,24 @@ __global__ void u3_to_u4_kernel(const double* __restrict__ u3, double4* __restri
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (c < nCells) u4[c] = make_double4(u3[3 * c], u3[3 * c + 1], u3[3 * c + 2], 0.0);
 }
+// packed 256-byte cell records for all-hex meshes: [0..5] planes, [6] U, [7] six neighbour ids + pad
+__global__ void build_cell_records_kernel(const double4* __restrict__ planes, const int32_t* __restrict__ nbr,
+                                          const double4* __restrict__ U, double4* __restrict__ rec, int64_t nCells) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nCells) return;
+    double4* r = rec + 8 * c;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = planes[6 * c + s];
+    r[6] = U[c];
+    int32_t* nb = reinterpret_cast<int32_t*>(r + 7);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) nb[s] = nbr[6 * c + s];
+    nb[6] = 0; nb[7] = 0;
+}
+__global__ void update_record_velocity_kernel(const double4* __restrict__ U, double4* __restrict__ rec, int64_t nCells) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c < nCells) rec[8 * c + 6] = U[c];
+}
 __global__ void count_negative_kernel(const int32_t* __restrict__ cell, int64_t n, unsigned long long* out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     unsigned v = (i < n && cell[i] < 0) ? 1u : 0u;
@@ -590,6 +969,15 @@ hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, 
 }
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells) {
     if (nCells > 0) hipLaunchKernelGGL(u3_to_u4_kernel, grid_for(nCells), dim3(kBlock), 0, st, u3, u4, nCells);
+    return hipGetLastError();
+}
+hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,
+                                     double4* rec, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(build_cell_records_kernel, grid_for(nCells), dim3(kBlock), 0, st, planes, nbr, U, rec, nCells);
+    return hipGetLastError();
+}
+hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(update_record_velocity_kernel, grid_for(nCells), dim3(kBlock), 0, st, U, rec, nCells);
     return hipGetLastError();
 }
 hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out) {

@@ -34,6 +34,8 @@ static inline v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
 static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline double dotf(v3 a, v3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+/* signed plane distance (Cf - P).n = d - n.P as one fma chain: <= 0 on the inner side */
+static inline double plane_dist(v3 n, double d, v3 P) { return fma(-n.z, P.z, fma(-n.y, P.y, fma(-n.x, P.x, d))); }
 static inline v3 axpy(double s, v3 a, v3 b) { return V(fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)); }
 /* plain (un-fused) forms for the one-off host geometry */
 static inline double dotp(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -107,7 +109,7 @@ static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const doubl
     double dTmin = 1.1;
     for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
         v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
-        double fd = planes[4 * s + 3] - dotf(n, P0);       /* (Cf - P0).n, <= 0 inside */
+        double fd = plane_dist(n, planes[4 * s + 3], P0);  /* (Cf - P0).n, <= 0 inside */
         double dT = fd / dotf(n, Pd);
         if (isinf(dT)) dT = -1.0;
         if (nbr[s] == token) continue;
@@ -231,7 +233,7 @@ void cw_locate_initial(const double* px, const double* py, const double* pz, int
             int inside = 1;
             for (int s = cellOff[c]; s < cellOff[c + 1]; ++s) {
                 v3 nn = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
-                if (!(planes[4 * s + 3] - dotf(nn, P) <= 0.0)) { inside = 0; break; }
+                if (!(plane_dist(nn, planes[4 * s + 3], P) <= 0.0)) { inside = 0; break; }
             }
             if (inside) found = c;
         }
@@ -245,4 +247,15 @@ int cw_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* diagnostics: one cycle, per-particle number of cell visits and reflections (divergence studies) */
+void cw_step_count(double* px, double* py, double* pz, int* cell, int n, double dt, const int* cellOff,
+                   const double* planes, const int* nbr, const double* U, int nthreads, int* visits, int* reflections) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        cw_stats st = {0, 0, 0};
+        step_one(i, px, py, pz, cell, NULL, dt, cellOff, planes, nbr, U, &st, 0.0, NULL, 0, 0);
+        visits[i] = (int)st.hops; reflections[i] = (int)st.reflections;
+    }
 }

@@ -52,7 +52,7 @@ def test_initial_locate_matches_bruteforce(setup):
     assert n_out == int((ref < 0).sum()) and 0 < n_out < n
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
 def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     """Every kernel variant (generic CSR walk, all-hex fixed-slot walk, fixed-slot + wave-uniform scalar
@@ -66,7 +66,7 @@ def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     ctx.set_particles(xyz)
     ctx.locate_initial()
     _, cell0 = ctx.get_particles()
-    if variant == 2:
+    if variant >= 2:
         ctx.sort_by_cell()                 # the scalar path only triggers on cell-coherent waves
     x, y, z = (xyz[:, k].copy() for k in range(3))
     c = cell0.copy()

@@ -18,8 +18,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--field", default="uniform")
-    ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--variants", default="0,2,4,5")
     ap.add_argument("--unsorted", action="store_true")
+    ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
     args = ap.parse_args()
     import torch
     import bench
@@ -42,14 +44,16 @@ def main():
     torch.cuda.synchronize()
     ref = None
     rows = []
+    if args.no_stats:
+        ctx.set_option("stats", 0)
     for v in [int(s) for s in args.variants.split(",")]:
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
         p = lambda t: t.data_ptr()   # noqa: E731
-        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, args.warmup, 0)
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, args.warmup, args.flags)
         torch.cuda.synchronize()
         ctx.timing_enable(True)
-        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, args.warmup, args.steps, 0)
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, args.warmup, args.steps, args.flags)
         launches, ms = ctx.timing_read()
         ctx.timing_enable(False)
         avg = ms / launches
@@ -61,6 +65,17 @@ def main():
         rows.append(dict(variant=v, kernel_ms=round(avg, 4), gps=round(n / avg / 1e6, 2), gbs=round(56 * n / avg / 1e6, 1),
                          identical_to_first=same))
         print(json.dumps(rows[-1]), flush=True)
+    # IO floor: same loads/stores, zero cycles (no walk)
+    from cudaparticlesfoam_amd import _lib as L
+    x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
+    torch.cuda.synchronize()
+    ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, 0, L.STEP_FUSE_CYCLES)
+    ctx.timing_enable(True)
+    for _ in range(20):
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, 0, L.STEP_FUSE_CYCLES)
+    launches, ms = ctx.timing_read()
+    print(json.dumps(dict(variant="zero-cycle (IO floor)", kernel_ms=round(ms / launches, 4),
+                          gbs=round(56 * n / (ms / launches) / 1e6, 1))), flush=True)
     ctx.close()
 
 
