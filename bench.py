@@ -38,14 +38,16 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
     ap.add_argument("--exchange-interval", type=int, default=4)
+    ap.add_argument("--rebalance-interval", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     return ap.parse_args()
 
 
-def seed_in_fluid(ctx, torch, n, box, seed, device):
-    """n points uniform in `box`, rejection-resampled until located in a cell."""
+def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None):
+    """n points uniform in `box`, rejection-resampled until located in a cell (SURVEY.md 8d config 3);
+    with cell_range=(lo, hi) only points whose cell lies in [lo, hi) are kept (a rank seeding its own slab)."""
     g = torch.Generator(device=device); g.manual_seed(seed)
     lo = torch.tensor(box[0], dtype=torch.float64, device=device)
     ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
@@ -60,6 +62,8 @@ def seed_in_fluid(ctx, torch, n, box, seed, device):
         ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
         torch.cuda.synchronize()
         keep = c >= 0
+        if cell_range is not None:
+            keep &= (c >= cell_range[0]) & (c < cell_range[1])
         xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
         have += int(keep.sum())
     cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
@@ -118,7 +122,8 @@ def main():
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
     from cudaparticlesfoam_amd.cases import pitzdaily as pz
-    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges, x_slab_renumbering
+    from cudaparticlesfoam_amd.parallel import (HipOps, ShardedCloud, slab_bounding_box, slab_cell_ranges,
+                                                    x_slab_renumbering)
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
@@ -142,14 +147,24 @@ def main():
 
     n_total = int(args.particles) * (world if args.scaling == "weak" else 1)
     n_local = n_total // world
-    x, y, z, c = seed_in_fluid(ctx, torch, n_local, pz.DOMAIN_BOX, 1000 + rank, device)
+    # every rank seeds its own x-slab: the sampling box is clipped to the slab's points, then points are kept
+    # only if their cell belongs to the rank
+    box = [list(pz.DOMAIN_BOX[0]), list(pz.DOMAIN_BOX[1])]
+    if world > 1:
+        lo_pt, hi_pt = slab_bounding_box(mesh, int(cell_lo[rank]), int(cell_lo[rank + 1]))
+        box[0][0] = max(box[0][0], float(lo_pt[0]) - 1e-9)
+        box[1][0] = min(box[1][0], float(hi_pt[0]) + 1e-9)
+    x, y, z, c = seed_in_fluid(ctx, torch, n_local, box, 1000 + rank, device,
+                               (int(cell_lo[rank]), int(cell_lo[rank + 1])) if world > 1 else None)
     gid = torch.arange(n_local, dtype=torch.int64, device=device) + rank * n_local
-    cloud = ShardedCloud(HipOps(ctx), cell_lo, int(n_local * 1.3) + 4096, device, rank, world,
+    # 288 GB of HBM: slack is free.  3x capacity and a send buffer as large as the shard make an overflow
+    # impossible even if a whole neighbouring slab drains into this rank between two rebalances.
+    cap = (int(n_local * 3.0) if world > 1 else n_local) + 4096
+    cloud = ShardedCloud(HipOps(ctx), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
                          exchange_interval=args.exchange_interval)
+    cloud.rebalance_interval = args.rebalance_interval
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
-    if world > 1:
-        cloud.exchange()                      # move every particle to its owner before timing
     if not args.no_sort:
         cloud.sort()
     torch.cuda.synchronize()
@@ -200,6 +215,7 @@ def main():
                                    % ("uniform (10,0,0)" if args.field == "uniform" else "analytic step-flow", n_local),
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
+                       "rebalance_interval": args.rebalance_interval if world > 1 else None,
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
                                                      if world > 1 else None),
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),

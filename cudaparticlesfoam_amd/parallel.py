@@ -46,6 +46,22 @@ def x_slab_renumbering(centres: np.ndarray) -> np.ndarray:
     return new_of_old
 
 
+def slab_bounding_box(mesh, cell_first: int, cell_last: int):
+    """Axis-aligned bounding box (lower, upper) of the cells [cell_first, cell_last): where a rank
+    samples when it seeds its own slab."""
+    own = np.asarray(mesh.owner); nei = np.asarray(mesh.neighbour)
+    fo = np.asarray(mesh.face_offsets)
+    sel = (own >= cell_first) & (own < cell_last)
+    sel[: nei.size] |= (nei >= cell_first) & (nei < cell_last)
+    faces = np.nonzero(sel)[0]
+    if faces.size == 0:
+        raise ValueError("empty cell range [%d, %d)" % (cell_first, cell_last))
+    nv = fo[faces + 1] - fo[faces]
+    idx = np.repeat(fo[faces], nv) + (np.arange(int(nv.sum())) - np.repeat(np.cumsum(nv) - nv, nv))
+    pts = np.asarray(mesh.points)[np.asarray(mesh.face_verts)[idx]]
+    return pts.min(0), pts.max(0)
+
+
 class HipOps:
     """Device operations of a shard, all through the C-ABI (no CPU fallback)."""
 
@@ -103,6 +119,9 @@ class ShardedCloud:
         self.step_index = 0
         self.handed_off = 0          # cumulative particles sent away by this rank
         self.exchanges = 0
+        self.rebalances = 0
+        self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
+        self.n_cells = int(self.cell_lo[-1])
 
     # -- filling
     def set_particles(self, x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, cell: Optional[torch.Tensor],
@@ -122,8 +141,11 @@ class ShardedCloud:
         for _ in range(n_cycles):
             self.ops.step(self, dt, D, self.step_index, 1, flags)
             self.step_index += 1
-            if self.world > 1 and self.step_index % self.exchange_interval == 0:
-                self.exchange()
+            if self.world > 1:
+                if self.rebalance_interval and self.step_index % self.rebalance_interval == 0:
+                    self.rebalance(self.n_cells)
+                elif self.step_index % self.exchange_interval == 0:
+                    self.exchange()
 
     def exchange(self):
         """Hand particles that left this rank's cell range to their owners (all-to-all-v)."""
@@ -153,6 +175,21 @@ class ShardedCloud:
         self.n = n_stay + n_recv
         self.handed_off += sum(send_counts)
         self.exchanges += 1
+
+    def rebalance(self, n_cells: int):
+        """Recompute the cell ranges so that every rank owns the same number of particles (global
+        per-cell histogram -> all-reduce -> equal-count cuts), then hand particles to their new owners.
+        Legal at any time because the mesh is replicated; keeps a drifting cloud (everything flows to
+        the outlet) from piling up on one rank."""
+        if self.world == 1:
+            return
+        c = self.cell[: self.n]
+        hist = torch.bincount(c[c >= 0].to(torch.int64), minlength=n_cells).to(torch.float64)
+        dist.all_reduce(hist, group=self.group)
+        self.cell_lo = slab_cell_ranges(hist.cpu().numpy(), self.world)
+        self.cell_lo_dev.copy_(torch.from_numpy(self.cell_lo.copy()))
+        self.exchange()
+        self.rebalances += 1
 
     def sort(self):
         self.ops.sort(self)

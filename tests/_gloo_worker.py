@@ -17,6 +17,7 @@ from oracle import oracle as O                                                # 
 
 def main():
     out_path, interval = sys.argv[1], int(sys.argv[2])
+    rebalance = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -39,14 +40,17 @@ def main():
     g, x, y, z, c = cloud.gather_to_numpy()
     owned_ok = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     total0 = cloud.global_count()
+    cloud.rebalance_interval = rebalance
     cloud.step(0.2, 30)
     if interval > 1:
         cloud.exchange()
     total1 = cloud.global_count()
     g, x, y, z, c = cloud.gather_to_numpy()
+    cell_lo = cloud.cell_lo
     owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
-             total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges)
+             total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
+             n_local=cloud.n)
     dist.barrier()
     dist.destroy_process_group()
 

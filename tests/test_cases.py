@@ -75,3 +75,21 @@ def test_analytic_field_respects_walk_cap(pitz):
     speed = np.linalg.norm(U, axis=1)
     assert speed.max() * 1e-4 < 2e-3           # < ~4 cells per Lagrangian sub-step (50-tet cap)
     assert (U[:, 2] == 0).all()
+
+
+def test_slab_bounding_boxes_tile_the_domain(pitz):
+    """What bench.py --gpus N uses to let every rank seed its own x-slab."""
+    from cudaparticlesfoam_amd.parallel import slab_bounding_box, slab_cell_ranges, x_slab_renumbering
+    mesh = pitz["mesh"].renumber_cells(x_slab_renumbering(pitz["centres"]))
+    c, v = mesh.cell_centres_volumes()
+    lo = slab_cell_ranges(v, 8)
+    assert lo[0] == 0 and lo[-1] == mesh.n_cells and (np.diff(lo) > 0).all()
+    prev_hi = None
+    for r in range(8):
+        a, b = slab_bounding_box(mesh, int(lo[r]), int(lo[r + 1]))
+        cc = c[lo[r]:lo[r + 1]]
+        assert (cc >= a - 1e-12).all() and (cc <= b + 1e-12).all()
+        if prev_hi is not None:
+            assert a[0] <= prev_hi + 1e-12            # neighbouring slabs touch or overlap by one column
+        prev_hi = b[0]
+    assert abs(slab_bounding_box(mesh, 0, mesh.n_cells)[0][0] - mesh.points[:, 0].min()) < 1e-15

@@ -33,13 +33,13 @@ def _single_process_answer(oracle_libs):
     return x, y, z, c
 
 
-@pytest.mark.parametrize("world,interval", [(2, 1), (2, 4), (3, 1)])
-def test_sharded_equals_single_process(world, interval, tmp_path, oracle_libs):
+@pytest.mark.parametrize("world,interval,rebalance", [(2, 1, 0), (2, 4, 0), (3, 1, 0), (2, 4, 10)])
+def test_sharded_equals_single_process(world, interval, rebalance, tmp_path, oracle_libs):
     out = str(tmp_path / "shard")
     env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(HERE, "_gloo_worker.py"), out, str(interval)]
+           os.path.join(HERE, "_gloo_worker.py"), out, str(interval), str(rebalance)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     x, y, z, c = _single_process_answer(oracle_libs)
@@ -56,3 +56,8 @@ def test_sharded_equals_single_process(world, interval, tmp_path, oracle_libs):
         assert np.array_equal(d["cell"], c[g])
         handed += int(d["handed"])
     assert seen.all() and handed > 0
+    if rebalance:
+        ds = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
+        assert all(int(d["rebalances"]) == 3 for d in ds)
+        counts = [int(d["n_local"]) for d in ds]
+        assert max(counts) - min(counts) <= 0.1 * 6000        # equal-count cuts (cell granularity)
