@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--sort-interval", type=int, default=25, help="re-sort the cloud by cell every that many steps")
     return ap.parse_args()
 
 
@@ -163,6 +164,7 @@ def main():
     cloud = ShardedCloud(HipOps(ctx), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
                          exchange_interval=args.exchange_interval)
     cloud.rebalance_interval = args.rebalance_interval
+    cloud.sort_interval = 0 if args.no_sort else args.sort_interval
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
     if not args.no_sort:
@@ -220,7 +222,7 @@ def main():
                                                      if world > 1 else None),
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
-                       "sorted_by_cell": not args.no_sort, "visit_stats_from": "the %d warm-up steps" % args.warmup},
+                       "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "cpf::step_kernel_coop<false,true,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),

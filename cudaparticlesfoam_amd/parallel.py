@@ -121,6 +121,7 @@ class ShardedCloud:
         self.exchanges = 0
         self.rebalances = 0
         self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
+        self.sort_interval = 0       # 0 = never; else re-sort by cell every that many steps (coalescing)
         self.n_cells = int(self.cell_lo[-1])
 
     # -- filling
@@ -141,6 +142,8 @@ class ShardedCloud:
         for _ in range(n_cycles):
             self.ops.step(self, dt, D, self.step_index, 1, flags)
             self.step_index += 1
+            if self.sort_interval and self.step_index % self.sort_interval == 0:
+                self.sort()
             if self.world > 1:
                 if self.rebalance_interval and self.step_index % self.rebalance_interval == 0:
                     self.rebalance(self.n_cells)

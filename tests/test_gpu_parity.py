@@ -351,3 +351,38 @@ def test_full_size_properties(setup, gpu_ctx_factory):
     fd = pl[:, :, 3] - (pl[:, :, 0] * xs[:, None] + pl[:, :, 1] * ys[:, None] + pl[:, :, 2] * zs[:, None])
     assert fd.max() <= 1e-9
     ctx.use_own_stream()
+
+
+def test_generic_polyhedral_path_on_reference_tet_mesh(oracle_libs, gpu_ctx_factory):
+    """Cells == the tets of the reference's own test geometry (createBoxMesh): 4-faced cells force the generic
+    CSR walk.  HIP == cell-walk statement bit for bit, and == the reference tet walk (same elements, per-tet
+    velocity, ~1e5 wall reflections) to rounding, every particle."""
+    from tetcells import box_tets, tet_cell_polymesh
+    tw, cw = oracle_libs.TetWalk(), oracle_libs.CellWalk()
+    pos, tets = box_tets(6, 5, 4)
+    mesh = tet_cell_polymesh(pos, tets)
+    rng = np.random.default_rng(4)
+    U = rng.normal(size=(mesh.n_cells, 3))
+    m = tw.tables(pos, tets, U); t = cw.build(mesh)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(U)
+    n = 20000
+    xyz = rng.uniform([0, 0, 0], [6, 5, 4], size=(n, 3))
+    ctx.set_particles(xyz)
+    assert ctx.locate_initial() == 0
+    _, cell0 = ctx.get_particles()
+    assert np.array_equal(cell0, cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t,
+                                                   nthreads=cw.max_threads))
+    P = np.zeros((n, 4)); P[:, :3] = xyz; P[:, 3] = 1
+    ids = cell0.copy(); vels = np.zeros((n, 4)); disps = np.zeros((n, 4))
+    x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), cell0.copy()
+    for k in (1, 9, 50):
+        ctx.step(0.2, 0.0, k)
+        cw.step(x, y, z, c, 0.2, k, t, U, nthreads=cw.max_threads)
+        tw.cycles(P, ids, vels, disps, 0.2, k, m, nthreads=tw.max_threads)
+        xyzw, cell = ctx.get_particles()
+        assert np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) \
+            and np.array_equal(xyzw[:, 2], z)
+        assert np.array_equal(cell, ids)
+        assert np.abs(xyzw[:, :3] - P[:, :3]).max() <= 1e-11
+    assert ctx.counters()["reflections"] > 50000

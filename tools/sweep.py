@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--unsorted", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--pf-blocks", type=int, default=0)
     args = ap.parse_args()
     import torch
     import bench
@@ -46,6 +47,8 @@ def main():
     rows = []
     if args.no_stats:
         ctx.set_option("stats", 0)
+    if args.pf_blocks:
+        ctx.set_option("pf_blocks", args.pf_blocks)
     for v in [int(s) for s in args.variants.split(",")]:
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
