@@ -37,9 +37,11 @@ def parse():
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU (weak) / total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
-    ap.add_argument("--exchange-interval", type=int, default=4)
-    ap.add_argument("--rebalance-interval", type=int, default=12)
+    ap.add_argument("--exchange-interval", type=int, default=8)
+    ap.add_argument("--rebalance-interval", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=25, help="re-sort the cloud by cell every that many steps")
@@ -130,8 +132,12 @@ def main():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     # ---- synthetic case: pitzDaily mesh renumbered into x-slabs (same mesh for every N)
     mesh0 = pz.pitzdaily_mesh()
@@ -163,10 +169,18 @@ def main():
     cap = (int(n_local * 3.0) if world > 1 else n_local) + 4096
     cloud = ShardedCloud(HipOps(ctx), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
                          exchange_interval=args.exchange_interval)
+    cloud.force_collectives = args.force_dist
+    if args.force_dist and world == 1:
+        cloud.send_capacity = cloud.capacity
+        cloud.sendbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
+        cloud.recvbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
     cloud.rebalance_interval = args.rebalance_interval
     cloud.sort_interval = 0 if args.no_sort else args.sort_interval
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
+    if world > 1 or args.force_dist:
+        cloud.rebalance(mesh.n_cells)         # also pays RCCL's one-time all-reduce / all-to-all set-up before timing
+        cloud.exchange()
     if not args.no_sort:
         cloud.sort()
     torch.cuda.synchronize()
@@ -235,7 +249,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
                                        "sample": "unavailable: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -122,6 +122,7 @@ class ShardedCloud:
         self.rebalances = 0
         self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
         self.sort_interval = 0       # 0 = never; else re-sort by cell every that many steps (coalescing)
+        self.force_collectives = False   # run the hand-off path even with one rank (single-GPU smoke of the N>1 code)
         self.n_cells = int(self.cell_lo[-1])
 
     # -- filling
@@ -144,7 +145,7 @@ class ShardedCloud:
             self.step_index += 1
             if self.sort_interval and self.step_index % self.sort_interval == 0:
                 self.sort()
-            if self.world > 1:
+            if self.world > 1 or self.force_collectives:
                 if self.rebalance_interval and self.step_index % self.rebalance_interval == 0:
                     self.rebalance(self.n_cells)
                 elif self.step_index % self.exchange_interval == 0:
@@ -152,7 +153,7 @@ class ShardedCloud:
 
     def exchange(self):
         """Hand particles that left this rank's cell range to their owners (all-to-all-v)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         self.ops.pack(self)
         # one small D2H: per-destination counts + nStay (sizes must be host-known for the collective)
@@ -184,7 +185,7 @@ class ShardedCloud:
         per-cell histogram -> all-reduce -> equal-count cuts), then hand particles to their new owners.
         Legal at any time because the mesh is replicated; keeps a drifting cloud (everything flows to
         the outlet) from piling up on one rank."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         c = self.cell[: self.n]
         hist = torch.bincount(c[c >= 0].to(torch.int64), minlength=n_cells).to(torch.float64)
