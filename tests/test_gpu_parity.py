@@ -386,3 +386,65 @@ def test_generic_polyhedral_path_on_reference_tet_mesh(oracle_libs, gpu_ctx_fact
         assert np.array_equal(cell, ids)
         assert np.abs(xyzw[:, :3] - P[:, :3]).max() <= 1e-11
     assert ctx.counters()["reflections"] > 50000
+
+
+def test_config2_one_million_particles_bit_exact(setup):
+    """BASELINE.json configs[1]: pitzDaily frozen U, 1e6 particles, positions checked against the CPU statement
+    after 1, 10 and 100 cycles (bit for bit) -- and therefore, through the oracle chain, within rounding of the
+    reference arithmetic (tests/test_oracle_golden.py: <= 1e-14 relative after 1000 cycles)."""
+    pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
+    U = setup["pitz"]["U_analytic"]
+    n = 1_000_000
+    xyz = _seed_points(pz, n, pz.INLET_BOX, seed=12345)          # SURVEY.md 8d config 2 seeding
+    ctx.set_velocity(U)
+    ctx.set_particles(xyz)
+    assert ctx.locate_initial() == 0
+    _, cell0 = ctx.get_particles()
+    ctx.sort_by_cell()
+    x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), cell0.copy()
+    for k in (1, 9, 90):
+        ctx.step(1e-4, 0.0, k)
+        cw.step(x, y, z, c, 1e-4, k, t, U, nthreads=cw.max_threads)
+        xyzw, cell = ctx.get_particles()
+        assert np.array_equal(cell, c)
+        assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+
+
+def test_tutorial_case_end_to_end(tmp_path, pitz):
+    """BASELINE.json configs[0] shape on the GPU path: the tutorial dictionary (cudaParticlesDict:17-29, inverted
+    seeding box, D = 1.5e-5, dt 1e-4, deltaT 0.1 => 1000 cycles in ONE advect.H pass), 1e4 particles, through the
+    host mirror of the fragments with the library's VTU writer."""
+    import os
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import CudaParticles
+    pz = pitz["pz"]
+    d = dict(pz.PARTICLE_DICT, numParticles=10000, saveInterval=250)
+    frames = []
+
+    def writer(frame, xyzw, vel, cell):
+        frames.append((frame, xyzw.copy(), cell.copy()))
+
+    p = CudaParticles(pitz["mesh"], pitz["U_analytic"], d, writer=writer)
+    assert p.outOfDomain == 0 and frames[0][0] == 0
+    assert p.advect(100.0, 0.1) == 0                              # before startTime 282: gate closed (advect.H:33)
+    assert p.advect(300.0, 0.1) == 1000
+    assert [f[0] for f in frames] == [0, 1, 251, 501, 751]        # step % saveInterval == 0 -> frame step+1
+    xyzw, cell = p.particles()
+    assert (cell >= 0).all() and (xyzw[:, 3] == 1).all()          # every boundary reflects: nobody leaves
+    lo, hi = pitz["mesh"].bounds()
+    assert (xyzw[:, :3] >= lo - 1e-12).all() and (xyzw[:, :3] <= hi + 1e-12).all()
+    moved = np.linalg.norm(xyzw[:, :3] - frames[0][1][:, :3], axis=1)
+    assert moved.mean() > 0.02                                    # 0.1 s at O(1-10) m/s
+    c = p.ctx.counters()
+    assert c["particle_steps"] == 10000 * 1000 and c["lost"] == 0
+    lib = L.load()
+    ke = C_double()
+    path = str(tmp_path / "particle_1000.vtu").encode()
+    import ctypes
+    assert lib.cpf_write_vtu(p.ctx.h, path, ctypes.byref(ke)) == 0 and os.path.getsize(path) > 10000 * 40
+    p.close()
+
+
+def C_double():
+    import ctypes
+    return ctypes.c_double()
