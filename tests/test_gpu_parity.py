@@ -448,3 +448,41 @@ def test_tutorial_case_end_to_end(tmp_path, pitz):
 def C_double():
     import ctypes
     return ctypes.c_double()
+
+
+def test_config5_transient_velocity_on_refined_mesh(oracle_libs, gpu_ctx_factory, pitz):
+    """BASELINE.json configs[4] shape (pimple-like): a 16x larger mesh (195 600 hex cells, TJunction scale),
+    U re-uploaded before every Eulerian step as nCells x 3 doubles (the reference re-uploads 12 copies per
+    cell, src/advect.H:44-57), sub-cycled like advect.H.  HIP == CPU statement bit for bit at every step."""
+    import time
+    pz = pitz["pz"]
+    cw = oracle_libs.CellWalk()
+    mesh = pz.pitzdaily_mesh(refine=4)
+    assert mesh.n_cells == 16 * 12225
+    centres, _ = mesh.cell_centres_volumes()
+    t = cw.build(mesh)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh)
+    base = pz.analytic_step_u(mesh, centres)
+    n = 200000
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=8)
+    ctx.set_velocity(base)
+    ctx.set_particles(xyz)
+    ctx.locate_initial()
+    _, cell0 = ctx.get_particles()
+    assert np.array_equal(cell0, cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t,
+                                                   nthreads=cw.max_threads))
+    keep = cell0 >= 0
+    ctx.set_particles(xyz[keep], cell0[keep])
+    ctx.sort_by_cell()
+    x, y, z, c = xyz[keep, 0].copy(), xyz[keep, 1].copy(), xyz[keep, 2].copy(), cell0[keep].copy()
+    upload = 0.0
+    for step in range(5):
+        U = base * (1.0 + 0.3 * np.sin(0.7 * step)) + np.array([0.0, 0.4 * np.cos(step), 0.0])   # transient field
+        t0 = time.perf_counter(); ctx.set_velocity(U); upload += time.perf_counter() - t0
+        ctx.step(2.5e-5, 0.0, 8)                    # finer mesh => shorter Lagrangian dt (50-cell walk cap, SURVEY 5.7)
+        cw.step(x, y, z, c, 2.5e-5, 8, t, U, nthreads=cw.max_threads)
+        xyzw, cell = ctx.get_particles()
+        assert np.array_equal(cell, c)
+        assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+    assert upload / 5 < 0.05                        # 4.7 MB per refresh; the reference would move 56 MB
