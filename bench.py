@@ -218,7 +218,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))              # PMC passes are separate rocprofv3 runs (tools/profile_run.sh)
+                if rec.get("particles_per_launch") == n_local and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
