@@ -248,13 +248,22 @@ class CudaParticles:
         if U is not None:                                                              # advect.H:44-57
             self.ctx.set_velocity(U)
         D = self.diffusionCoeff if self.usingBrownianMotion else 0.0
-        for _ in range(n_cycles):                                                      # advect.H:86
+        done = 0
+        while done < n_cycles:                                                         # advect.H:86
             will_write = self.writer is not None and (
                 self.step % self.saveInterval == 0 or run_time_value == self.particleEndTime)
-            self.ctx.step(cycle_dt, D, 1, self._flags(will_write))
+            if will_write:
+                chunk = 1
+            else:
+                # cycles until the next output point run inside ONE launch (U is frozen during the loop)
+                to_next = self.saveInterval - (self.step % self.saveInterval) if self.writer is not None else n_cycles
+                chunk = max(1, min(n_cycles - done, to_next))
+            flags = self._flags(will_write) | (L.STEP_FUSE_CYCLES if chunk > 1 else 0)
+            self.ctx.step(cycle_dt, D, chunk, flags)
             if will_write:                                                             # advect.H:166-169
                 self._write(self.step + 1)
-            self.step += 1                                                             # advect.H:182
+            self.step += chunk                                                         # advect.H:182
+            done += chunk
         return n_cycles
 
     def particles(self):

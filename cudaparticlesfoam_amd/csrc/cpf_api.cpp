@@ -46,9 +46,8 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
-    int pfBlocks = 256 * 6;                     // persistent-grid size of variant 4 ("pf_blocks")
     bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
-    int stepVariant = 5;                        // cpf_set_option("step_variant"), see include/cpf.h
+    int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -397,8 +396,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
-                                      ctx->pfBlocks));
+                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant));
         if (ctx->timing) {
             CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             ctx->events.emplace_back(e0, e1);
@@ -490,17 +488,12 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
     const std::string k(key);
     if (k == "step_variant") {
-        CPF_REQUIRE(ctx, value >= 0 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..5");
+        CPF_REQUIRE(ctx, value >= 0 && value <= 3 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..3");
         ctx->stepVariant = (int)value;
         return CPF_OK;
     }
     if (k == "stats") {
         ctx->stats = value != 0;
-        return CPF_OK;
-    }
-    if (k == "pf_blocks") {
-        CPF_REQUIRE(ctx, value >= 1 && value <= 65536, CPF_ERR_ARG, "pf_blocks must be in [1, 65536]");
-        ctx->pfBlocks = (int)value;
         return CPF_OK;
     }
     return fail(ctx, CPF_ERR_ARG, "cpf_set_option: unknown key '" + k + "'");

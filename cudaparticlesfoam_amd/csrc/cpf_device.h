@@ -31,8 +31,7 @@ struct GridView {
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
-                       int pfBlocks);
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant);
 hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
                                  int64_t n, const MeshView& m, const GridView& g);
 hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,

@@ -113,8 +113,7 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
 }
 
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
-enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantLds = 3, kVariantPrefetch = 4,
-       kVariantCoop = 5 };
+enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3 };
 
 // Where a walk gets its mesh data from.  Every tracer runs the same arithmetic in the same order.
 template <int VARIANT>
@@ -134,35 +133,6 @@ struct GlobalTracer {
                               6 * cur);
     }
     __device__ __forceinline__ double4 velocity(int cur) const { return m.U[cur]; }
-};
-
-// LDS-staged tracer: the block copies the face planes, neighbour ids and velocities of a window of
-// kWin consecutive cells around its particles into LDS once (coalesced 16-byte loads), and every
-// visit inside the window is served by ds_read_b128 (same-cell lanes broadcast) instead of a
-// 64-address gather through the vector-memory path.  Cells outside the window use global loads.
-constexpr int kWin = 128;    // cells staged per block: 128 * (6*32 + 6*4 + 32) B = 31 KiB
-constexpr int kBack = 40;    // of which this many lie below the block's smallest cell id
-struct StagedCells {
-    double4 planes[kWin * 6];
-    double4 U[kWin];
-    int32_t nbr[kWin * 6];
-};
-struct LdsTracer {
-    const MeshView& m;
-    const StagedCells* sm;
-    int base, cnt;
-    __device__ __forceinline__ int trace(D3& S, const D3& E, int cur, int token, int& outSlot) const {
-        const int r = cur - base;
-        if ((unsigned)r < (unsigned)cnt)
-            return trace_fixed<6>(S, E, cur, sm->planes + 6 * r, sm->nbr + 6 * r, token, outSlot, 6 * cur);
-        return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
-                              6 * cur);
-    }
-    __device__ __forceinline__ double4 velocity(int cur) const {
-        const int r = cur - base;
-        if ((unsigned)r < (unsigned)cnt) return sm->U[r];
-        return m.U[cur];
-    }
 };
 
 // Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
@@ -279,44 +249,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
             D3 v = {0, 0, 0};
             const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
             const GlobalTracer<VARIANT> tr{m};
-            particle_cycles<GlobalTracer<VARIANT>, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0,
-                                                                                 nCyc, seed, st);
-            x[i] = P.x; y[i] = P.y; z[i] = P.z;
-            cell[i] = cur;
-            if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
-        } else if (cur == CPF_CELL_LOST) {
-            cell[i] = CPF_CELL_FROZEN;
-        }
-    }
-    __shared__ unsigned sCnt[4];
-    flush_stats(st, counters, sCnt);
-}
-
-// Persistent, software-pipelined variant: a fixed grid (a few blocks per CU) strides over the cloud and
-// each thread issues the loads of its NEXT particle before it walks the current one, so the HBM
-// round trip of the streaming state overlaps the walk instead of preceding it.
-template <int VARIANT, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
-__global__ __launch_bounds__(kBlock) void step_kernel_pf(double* __restrict__ x, double* __restrict__ y,
-                                                         double* __restrict__ z, int32_t* __restrict__ cell,
-                                                         const int64_t* __restrict__ gid, double* __restrict__ vel,
-                                                         int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
-                                                         uint32_t seed, MeshView m,
-                                                         unsigned long long* __restrict__ counters) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    StepStats st = {0, 0, 0, 0};
-    const GlobalTracer<VARIANT> tr{m};
-    int cNext = CPF_CELL_FROZEN;
-    D3 pNext = {0, 0, 0};
-    if (i < n) { cNext = cell[i]; pNext = {x[i], y[i], z[i]}; }
-    for (; i < n; i += stride) {
-        int cur = cNext;
-        D3 P = pNext;
-        const int64_t j = i + stride;
-        if (j < n) { cNext = cell[j]; pNext = {x[j], y[j], z[j]}; }      // in flight during the walk below
-        if (cur >= 0) {
-            D3 v = {0, 0, 0};
-            const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
             particle_cycles<GlobalTracer<VARIANT>, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0,
                                                                                  nCyc, seed, st);
             x[i] = P.x; y[i] = P.y; z[i] = P.z;
@@ -471,61 +403,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel_coop(double* __restrict__ 
     flush_stats(st, counters, sCnt);
 }
 
-// LDS-staged variant (all-hex meshes): see LdsTracer
-template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
-__global__ __launch_bounds__(kBlock) void step_kernel_lds(double* __restrict__ x, double* __restrict__ y,
-                                                          double* __restrict__ z, int32_t* __restrict__ cell,
-                                                          const int64_t* __restrict__ gid, double* __restrict__ vel,
-                                                          int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
-                                                          uint32_t seed, MeshView m,
-                                                          unsigned long long* __restrict__ counters) {
-    __shared__ StagedCells sm;
-    __shared__ int sMin;
-    __shared__ unsigned sCnt[4];
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    int cur = (i < n) ? cell[i] : CPF_CELL_FROZEN;
-    D3 P = {0, 0, 0};
-    if (cur >= 0) P = {x[i], y[i], z[i]};
-    // smallest active cell id of the block: wave min by butterfly shuffles, then one LDS atomic per wave
-    if (threadIdx.x == 0) sMin = INT32_MAX;
-    __syncthreads();
-    int mn = cur >= 0 ? cur : INT32_MAX;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
-    if ((threadIdx.x & 63) == 0 && mn != INT32_MAX) atomicMin(&sMin, mn);
-    __syncthreads();
-    const int blockMin = sMin;
-    int base = 0, cnt = 0;
-    if (blockMin != INT32_MAX) {
-        base = max(0, min(blockMin - kBack, m.nCells - kWin));
-        cnt = min(kWin, m.nCells - base);
-        // cooperative, coalesced copy: 16 bytes per thread per step
-        const double2* gp = reinterpret_cast<const double2*>(m.planes + 6 * (int64_t)base);
-        double2* sp = reinterpret_cast<double2*>(sm.planes);
-        for (int k = threadIdx.x; k < cnt * 12; k += kBlock) sp[k] = gp[k];
-        const double2* gu = reinterpret_cast<const double2*>(m.U + base);
-        double2* su = reinterpret_cast<double2*>(sm.U);
-        for (int k = threadIdx.x; k < cnt * 2; k += kBlock) su[k] = gu[k];
-        const int2* gn = reinterpret_cast<const int2*>(m.nbr + 6 * (int64_t)base);   // 24*base bytes: 8-aligned
-        int2* sn = reinterpret_cast<int2*>(sm.nbr);
-        for (int k = threadIdx.x; k < cnt * 3; k += kBlock) sn[k] = gn[k];
-    }
-    __syncthreads();
-    StepStats st = {0, 0, 0, 0};
-    if (cur >= 0) {
-        D3 v = {0, 0, 0};
-        const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
-        const LdsTracer tr{m, &sm, base, cnt};
-        particle_cycles<LdsTracer, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0, nCyc, seed, st);
-        x[i] = P.x; y[i] = P.y; z[i] = P.z;
-        cell[i] = cur;
-        if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
-    } else if (cur == CPF_CELL_LOST && i < n) {
-        cell[i] = CPF_CELL_FROZEN;
-    }
-    flush_stats(st, counters, sCnt);
-}
-
 template <int V, bool B, bool R>
 static void launch_step_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
                            const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
@@ -536,30 +413,6 @@ static void launch_step_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, 
     else
         hipLaunchKernelGGL((step_kernel<V, B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
                            sigma, step0, nCyc, seed, m, counters);
-}
-
-template <bool B, bool R>
-static void launch_step_lds_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
-                               const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
-                               int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
-    if (storeVel)
-        hipLaunchKernelGGL((step_kernel_lds<B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma,
-                           step0, nCyc, seed, m, counters);
-    else
-        hipLaunchKernelGGL((step_kernel_lds<B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt,
-                           sigma, step0, nCyc, seed, m, counters);
-}
-
-template <bool B, bool R>
-static void launch_step_pf_sv(bool storeVel, dim3 grid, hipStream_t st, double* x, double* y, double* z, int32_t* cell,
-                              const int64_t* gid, double* vel, int64_t n, double dt, double sigma, uint32_t step0,
-                              int nCyc, uint32_t seed, const MeshView& m, unsigned long long* counters) {
-    if (storeVel)
-        hipLaunchKernelGGL((step_kernel_pf<kVariantFixedScalar, B, R, true>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid,
-                           vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-    else
-        hipLaunchKernelGGL((step_kernel_pf<kVariantFixedScalar, B, R, false>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid,
-                           vel, n, dt, sigma, step0, nCyc, seed, m, counters);
 }
 
 template <bool B, bool R>
@@ -591,8 +444,7 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
 
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
-                       int pfBlocks) {
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
@@ -609,26 +461,6 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
             } else {
                 if (reflect) launch_step_coop_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
                 else launch_step_coop_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-            }
-            break;
-        case kVariantPrefetch: {
-            const dim3 pgrid((unsigned)std::min<int64_t>(grid.x, (int64_t)pfBlocks));
-            if (brown) {
-                if (reflect) launch_step_pf_sv<true, true>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-                else launch_step_pf_sv<true, false>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-            } else {
-                if (reflect) launch_step_pf_sv<false, true>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-                else launch_step_pf_sv<false, false>(storeVel, pgrid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-            }
-            break;
-        }
-        case kVariantLds:
-            if (brown) {
-                if (reflect) launch_step_lds_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-                else launch_step_lds_sv<true, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-            } else {
-                if (reflect) launch_step_lds_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
-                else launch_step_lds_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
             }
             break;
         case kVariantFixedScalar:

@@ -133,11 +133,10 @@ int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
 int cpf_set_seed(cpf_context* ctx, uint32_t seed);
 /* tuning knobs, never semantics (every step variant is bit-identical):
  *   "step_variant"  0 generic CSR walk (any polyhedral mesh; forced when a cell is not a hex)
- *                   1 all-hex fixed-slot walk        2 + wave-uniform scalar plane fetches
- *                   3 block-level LDS window         4 persistent grid with next-particle prefetch
- *                   5 (default) wave-cooperative LDS cell cache on packed 256-byte cell records
- *   "stats"         1 (default) accumulate the cpf_get_counters statistics, 0 skip that work
- *   "pf_blocks"     grid size of variant 4 */
+ *                   1 all-hex fixed-slot walk, per-lane gathers
+ *                   2 + wave-uniform plane fetches through the scalar cache
+ *                   3 (default) wave-cooperative LDS cell cache on packed 256-byte cell records
+ *   "stats"         1 (default) accumulate the cpf_get_counters statistics, 0 skip that work */
 int cpf_set_option(cpf_context* ctx, const char* key, double value);   /* Brownian stream; default 1591593751 (particles.cu:544) */
 
 /* ---------------------------------------------------------------------------------------------

@@ -52,14 +52,19 @@ def test_subcycling_and_output_cadence(api):
     n = p.advect(300.0, 0.1)
     assert n == max(math.ceil(0.1 / 1e-4), 1) == 1000                          # advect.H:36
     steps = [c for c in p.ctx.calls if c[0] == "step"]
-    assert len(steps) == 1000 and all(abs(c[1] - 0.1 / 1000) < 1e-18 and c[2] == 1.5e-5 and c[3] == 1 for c in steps)
+    assert sum(c[3] for c in steps) == 1000 and all(abs(c[1] - 0.1 / 1000) < 1e-18 and c[2] == 1.5e-5 for c in steps)
     assert frames[1:] == [s + 1 for s in range(0, 1000, 10)]                   # step % saveInterval == 0 -> step+1
-    assert [c[4] for c in steps[:11]] == [L.STEP_STORE_VEL] + [0] * 9 + [L.STEP_STORE_VEL]
-    assert p.step == 1000
+    # an output cycle runs alone with velocities stored; the 9 cycles up to the next output point are ONE launch
+    assert [(c[3], c[4]) for c in steps[:4]] == [(1, L.STEP_STORE_VEL), (9, L.STEP_FUSE_CYCLES)] * 2
+    assert len(steps) == 200 and p.step == 1000
     # deltaT smaller than dt: one cycle of length deltaT
     p2 = api.CudaParticles(None, np.zeros((4, 3)), dict(dt=1e-3))
     assert p2.advect(0.0, 2.5e-4) == 1
     assert [c for c in p2.ctx.calls if c[0] == "step"][0][1] == 2.5e-4
+    # no writer: the whole Eulerian step is one fused launch
+    p3 = api.CudaParticles(None, np.zeros((4, 3)), dict(dt=1e-4))
+    assert p3.advect(0.0, 0.1) == 1000
+    assert [(c[3], c[4]) for c in p3.ctx.calls if c[0] == "step"] == [(1000, L.STEP_FUSE_CYCLES)]
 
 
 def test_velocity_refresh_and_injected_positions(api):

@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-VARS="${1:-2}"; shift || true
+VARS="${1:-3}"; shift || true
 OUT=gpurun_out/pmc_sweep; rm -rf "$OUT"; mkdir -p "$OUT"
 SETS=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"

@@ -18,11 +18,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--field", default="uniform")
-    ap.add_argument("--variants", default="0,2,4,5")
+    ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--unsorted", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--pf-blocks", type=int, default=0)
     args = ap.parse_args()
     import torch
     import bench
@@ -47,8 +46,6 @@ def main():
     rows = []
     if args.no_stats:
         ctx.set_option("stats", 0)
-    if args.pf_blocks:
-        ctx.set_option("pf_blocks", args.pf_blocks)
     for v in [int(s) for s in args.variants.split(",")]:
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
