@@ -75,7 +75,7 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
 // opposite-sign pair can never give dT > tol, and den == 0 / NaN fall out of every comparison
 // exactly like the isinf -> -1 substitution of ConvexQuery.cu:89.
 // `pl`/`nb` may be wave-uniform pointers (scalar loads, one fetch per wave) or per-lane ones.
-template <int NF>
+template <int NF, bool SKIP_ZERO_DEN>
 __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const double4* __restrict__ pl,
                                            const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
     const D3 P0 = S;
@@ -89,7 +89,8 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
         // no lane of the wave moves across this face's plane (den == +-0 exactly, e.g. the front/back
         // faces of a one-cell-thick mesh, or wall-parallel faces in aligned flow): dT would be +-inf
         // (-> -1) or NaN, never accepted (ConvexQuery.cu:86-95), so the face costs nothing more
-        if (__ballot(den != 0.0) == 0ull) continue;
+        // (only worth a branch when the planes are already on chip: it would serialise global gathers)
+        if (SKIP_ZERO_DEN && __ballot(den != 0.0) == 0ull) continue;
         const int bs = nb[s];
         const double fd = plane_dist(p, P0);
         // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
@@ -126,10 +127,10 @@ struct GlobalTracer {
             // fetch that cell's planes once per wave through the scalar cache instead of 64 times
             const int ucur = __builtin_amdgcn_readfirstlane(cur);
             if (__ballot(cur != ucur) == 0ull)
-                return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token,
+                return trace_fixed<6, false>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token,
                                       outSlot, 6 * ucur);
         }
-        return trace_fixed<6>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
+        return trace_fixed<6, false>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
                               6 * cur);
     }
     __device__ __forceinline__ double4 velocity(int cur) const { return m.U[cur]; }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_coop(double* __restrict__ 
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         needAdvect = false;
                     }
-                    next = trace_fixed<6>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                    next = trace_fixed<6, true>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                     wallPlane = rec[outSlot];
                 } else {
                     const double4* rec = m.cellRec + 8 * (int64_t)cur;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_coop(double* __restrict__ 
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         needAdvect = false;
                     }
-                    next = trace_fixed<6>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                    next = trace_fixed<6, false>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                     wallPlane = next < 0 ? rec[outSlot] : make_double4(0, 0, 0, 0);
                 }
                 ++st.hops;
