@@ -46,6 +46,8 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
+    int sortInterval = 25;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
+    uint32_t lastSortStep = 0;
     bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h
     // timing
@@ -411,7 +413,14 @@ int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags)
     CPF_REQUIRE(ctx, ctx->located, CPF_ERR_STATE, "cpf_step: particles have no cells yet (call cpf_locate_initial)");
     int r = cpf_step_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel, ctx->n, dt, D, ctx->stepCounter,
                          nCycles, flags);
-    if (r == CPF_OK) ctx->stepCounter += (uint32_t)nCycles;
+    if (r != CPF_OK) return r;
+    ctx->stepCounter += (uint32_t)nCycles;
+    // keep waves cell-coherent: particle ids (and stored velocities) travel with the particles, so callers
+    // never see the reordering
+    if (ctx->sortInterval > 0 && ctx->stepCounter - ctx->lastSortStep >= (uint32_t)ctx->sortInterval) {
+        r = cpf_sort_by_cell_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n);
+        ctx->lastSortStep = ctx->stepCounter;
+    }
     return r;
 }
 
@@ -433,7 +442,8 @@ int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int3
     const int endBit = sortEndBit(ctx);
     int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
     if (r) return r;
-    CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, n, endBit, ctx->scratch, ctx->scratchBytes));
+    CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, x == ctx->x ? ctx->vel : nullptr, n, endBit,
+                                   ctx->scratch, ctx->scratchBytes));
     return CPF_OK;
 }
 
@@ -490,6 +500,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     if (k == "step_variant") {
         CPF_REQUIRE(ctx, value >= 0 && value <= 3 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..3");
         ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    if (k == "sort_interval") {
+        CPF_REQUIRE(ctx, value >= 0 && value <= 1e9, CPF_ERR_ARG, "sort_interval must be >= 0 (0 = never)");
+        ctx->sortInterval = (int)value;
         return CPF_OK;
     }
     if (k == "stats") {

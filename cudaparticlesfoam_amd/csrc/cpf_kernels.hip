@@ -728,6 +728,14 @@ __global__ void gather_kernel(const T* __restrict__ src, T* __restrict__ dst, co
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
 }
+__global__ void gather3_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                               const int32_t* __restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const int64_t j = perm[i];
+        dst[3 * i] = src[3 * j]; dst[3 * i + 1] = src[3 * j + 1]; dst[3 * i + 2] = src[3 * j + 2];
+    }
+}
 // AoS <-> SoA conversion for the reference-shaped accessors (Particle = double4)
 __global__ void unpack_xyz_kernel(const double* __restrict__ xyz, double* x, double* y, double* z, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -826,13 +834,13 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
     hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
-    // keys out + iota + perm + one 8-byte staging array, each 256-B aligned
+    // keys out + iota + perm + one staging array (24 bytes per particle: also serves the velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(tmp) + al(4 * (size_t)n) * 3 + al(8 * (size_t)n);
+    return al(tmp) + al(4 * (size_t)n) * 3 + al(24 * (size_t)n);
 }
 
-hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
-                        int endBit, void* scratch, size_t scratchBytes) {
+hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
+                        int64_t n, int endBit, void* scratch, size_t scratchBytes) {
     if (n <= 1) return hipSuccess;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t tmpBytes = 0;
@@ -843,7 +851,7 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     uint32_t* keysOut = (uint32_t*)p; p += al(4 * (size_t)n);
     int32_t* idx = (int32_t*)p; p += al(4 * (size_t)n);
     int32_t* perm = (int32_t*)p; p += al(4 * (size_t)n);
-    double* stage = (double*)p; p += al(8 * (size_t)n);
+    double* stage = (double*)p; p += al(24 * (size_t)n);
     if ((size_t)(p - (char*)scratch) > scratchBytes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(kBlock), 0, st, idx, n);
     // negative ids (lost/frozen) compare as huge unsigned keys and end up at the tail: sort all 32 bits
@@ -860,6 +868,11 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     if (gid) {
         hipLaunchKernelGGL((gather_kernel<int64_t>), grid_for(n), dim3(kBlock), 0, st, gid, (int64_t*)stage, perm, n);
         e = hipMemcpyAsync(gid, stage, 8 * (size_t)n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    if (vel3) {
+        hipLaunchKernelGGL(gather3_kernel, grid_for(n), dim3(kBlock), 0, st, vel3, stage, perm, n);
+        e = hipMemcpyAsync(vel3, stage, 24 * (size_t)n, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;
     }
     e = hipMemcpyAsync(cell, keysOut, 4 * (size_t)n, hipMemcpyDeviceToDevice, st);

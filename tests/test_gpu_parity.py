@@ -520,3 +520,26 @@ def test_all_particles_outside_the_mesh(setup):
     xyzw, cell = ctx.get_particles()
     assert (cell == -2).all() and (xyzw[:, 3] == 0).all() and np.array_equal(xyzw[:, :3], xyz)   # frozen in place
     assert ctx.counters()["particle_steps"] == before["particle_steps"]
+
+
+def test_auto_sort_is_invisible(setup, gpu_ctx_factory):
+    """cpf_step re-sorts the owned cloud every `sort_interval` cycles; ids and stored velocities travel with the
+    particles, so results (positions, cells, velocities by particle id) do not depend on the interval."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, mesh = setup["pz"], setup["mesh"]
+    U = setup["pitz"]["U_analytic"]
+    xyz = _seed_points(pz, 30000, pz.DOMAIN_BOX, seed=3)
+    outs = []
+    for interval in (0, 7, 25):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sort_interval", interval)
+        ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz); ctx.locate_initial()
+        for _ in range(6):
+            ctx.step(1e-4, 0.0, 9)
+            ctx.step(1e-4, 0.0, 1, L.STEP_STORE_VEL)
+        outs.append(ctx.get_particles(want_vel=True))
+        ctx.close()
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert np.array_equal(a, b)
+    assert np.abs(outs[0][2][:, :3]).max() > 1.0          # velocities really are stored
