@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<label>_summary.json (tools/profile_run.sh) into the small files committed under profiles/."""
+import glob, json, os, shutil, sys
+
+label = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.load(open(os.path.join(ROOT, "gpurun_out", label + "_summary.json")))
+ks = [k for k in d["kernels"] if "step_kernel" in k["kernel"]][0]
+pmc = list(d["pmc"].values())[0]; cal = list(d["calibration_zero_cycle_step"].values())[0]
+n = 10_000_000
+ff = (28 * n) / (cal["FETCH_SIZE_KB"] * 1024); wf = (28 * n) / (cal["WRITE_SIZE_KB"] * 1024)
+hbm = pmc["FETCH_SIZE_KB"] * 1024 * ff + pmc["WRITE_SIZE_KB"] * 1024 * wf
+out = dict(label=label, kernel=ks["kernel"].split("(")[0], particles_per_launch=n,
+           rocprofv3_kernel_trace=dict(calls=ks["calls"], avg_us=round(ks["avg_us"], 2), min_us=round(ks["min_us"], 2),
+                                       max_us=round(ks["max_us"], 2), pct_of_gpu_time=round(ks["pct"], 1),
+                                       note="100 timed launches (statistics off) + 10 warm-up launches (statistics on), same command as the bench"),
+           pmc_raw=dict(FETCH_SIZE_KB=pmc["FETCH_SIZE_KB"], WRITE_SIZE_KB=pmc["WRITE_SIZE_KB"], dispatches=pmc["dispatches"]),
+           calibration=dict(what="same kernel, zero cycles: 280 MB read + 280 MB written (known)",
+                            FETCH_SIZE_KB=cal["FETCH_SIZE_KB"], WRITE_SIZE_KB=cal["WRITE_SIZE_KB"],
+                            fetch_correction=round(ff, 4), write_correction=round(wf, 4)),
+           hbm_bytes_per_launch=int(hbm), algorithmic_bytes_per_launch=56 * n,
+           traffic_over_algorithmic=round(hbm / (56 * n), 4))
+P = os.path.join(ROOT, "profiles")
+json.dump(out, open(os.path.join(P, "pmc_latest.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, label + "_pmc_hbm.json"), "w"), indent=1)
+json.dump(dict(label=label, kernels=d["kernels"]), open(os.path.join(P, label + "_rocprofv3_kernel_stats.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", label, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(P, label + "_kernel_stats.csv"))
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", label, "stats", "**", "*domain_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(P, label + "_domain_stats.csv"))
+print(json.dumps(out, indent=1))
