@@ -543,3 +543,30 @@ def test_auto_sort_is_invisible(setup, gpu_ctx_factory):
         for a, b in zip(o, outs[0]):
             assert np.array_equal(a, b)
     assert np.abs(outs[0][2][:, :3]).max() > 1.0          # velocities really are stored
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 9, 11])
+def test_random_sheared_meshes_bit_exact(seed, oracle_libs, gpu_ctx_factory):
+    """Random graded, sheared hexahedral blocks with random cell-constant U and time steps that cross several cells
+    and bounce off several walls per step (tests/test_oracle_random.py shows these equal the reference algorithm)."""
+    from test_oracle_random import _case
+    cw = oracle_libs.CellWalk()
+    rng, mesh, U, dt = _case(seed)
+    t = cw.build(mesh)
+    lo, hi = mesh.bounds()
+    xyz = rng.uniform(lo, hi, size=(20000, 3))
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+    n_out = ctx.locate_initial()
+    _, cell0 = ctx.get_particles()
+    ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    assert np.array_equal(cell0, ref0) and n_out == int((ref0 < 0).sum())
+    x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
+    for k in (1, 7, 40):
+        ctx.step(dt, 0.0, k)
+        cw.step(x, y, z, c, dt, k, t, U, nthreads=cw.max_threads)
+        xyzw, cell = ctx.get_particles()
+        assert np.array_equal(cell, c)
+        assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+    assert ctx.counters()["reflections"] > 1000
+    ctx.close()
