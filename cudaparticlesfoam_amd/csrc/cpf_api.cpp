@@ -28,6 +28,7 @@ struct cpf_context {
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes)
+    float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;
     size_t meshBytes = 0;
@@ -110,12 +111,12 @@ int ensureScratch(cpf_context* ctx, size_t bytes) {
 
 int sortEndBit(const cpf_context* ctx) {
     int bits = 1;
-    while (((int64_t)1 << bits) < ctx->host.nCells + 2) ++bits;   // keeps -1/-2 (all-ones low bits) at the tail
-    return std::min(bits, 32);
+    while (((int64_t)1 << bits) < ctx->host.nCells + 2) ++bits;   // the all-ones key of lost/frozen sorts last
+    return std::min(bits + 6, 32);                                // + 6 sub-cell bits (kSubBits in cpf_kernels.hip)
 }
 
 void freeMesh(cpf_context* c) {
-    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec);
+    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_cellBox);
     freeDev(c->d_binOff); freeDev(c->d_binCells);
     c->haveMesh = c->haveU = false; c->meshBytes = 0;
 }
@@ -151,6 +152,7 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     CPF_HIP(ctx, up(ctx->d_nbr, h.nbr.data(), h.nbr.size() * 4));
     CPF_HIP(ctx, up(ctx->d_binOff, h.binOff.data(), h.binOff.size() * 4));
     CPF_HIP(ctx, up(ctx->d_binCells, h.binCells.data(), h.binCells.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_cellBox, h.cellBox.data(), h.cellBox.size() * 4));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U, (size_t)nCells * sizeof(double4)));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U3, (size_t)nCells * 3 * sizeof(double)));
     CPF_HIP(ctx, hipMemset(ctx->d_U, 0, (size_t)nCells * sizeof(double4)));
@@ -437,13 +439,14 @@ int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int3
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_sort_by_cell: call cpf_set_mesh first");
     CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (x && y && z && cell)), CPF_ERR_ARG, "cpf_sort_by_cell: bad arguments");
+    CPF_REQUIRE(ctx, ctx->host.nCells < ((int64_t)1 << 26) - 2, CPF_ERR_STATE, "cpf_sort_by_cell: more than 2^26 cells");
     if (n <= 1) return CPF_OK;
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     const int endBit = sortEndBit(ctx);
     int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
     if (r) return r;
     CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, x == ctx->x ? ctx->vel : nullptr, n, endBit,
-                                   ctx->scratch, ctx->scratchBytes));
+                                   ctx->d_cellBox, ctx->scratch, ctx->scratchBytes));
     return CPF_OK;
 }
 

@@ -18,6 +18,7 @@ struct HostTables {
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
     int32_t maxCellFaces = 0, minCellFaces = 0;
+    std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 4/extent per axis (sub-cell sort key)
 };
 
 // polyMesh -> HostTables.  Returns empty string on success, else the reason (CPF_ERR_MESH).

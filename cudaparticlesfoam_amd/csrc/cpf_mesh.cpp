@@ -119,6 +119,15 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
+    // ---- per-cell boxes for the sort key (cell, 4x4x4 position inside the cell's box)
+    out.cellBox.resize((size_t)nCells * 6);
+    for (int64_t c = 0; c < nCells; ++c)
+        for (int k = 0; k < 3; ++k) {
+            const double e = bmax[3 * c + k] - bmin[3 * c + k];
+            out.cellBox[6 * c + k] = (float)bmin[3 * c + k];
+            out.cellBox[6 * c + 3 + k] = e > 0.0 ? (float)(4.0 / e) : 0.0f;
+        }
+
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)
     for (int k = 0; k < 3; ++k) { out.lo[k] = 1e300; out.hi[k] = -1e300; }
     for (int64_t p = 0; p < nPoints; ++p)

@@ -570,3 +570,38 @@ def test_random_sheared_meshes_bit_exact(seed, oracle_libs, gpu_ctx_factory):
         assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
     assert ctx.counters()["reflections"] > 1000
     ctx.close()
+
+
+def test_sort_orders_by_cell_then_position(setup):
+    """cpf_sort_by_cell_dev: cells non-decreasing (lost/frozen at the tail), a permutation (ids intact), and inside
+    one cell the particles come in sub-box order (4 x 4 x 4 bins of the cell's bounding box)."""
+    import torch
+    pz, ctx, mesh = setup["pz"], setup["ctx"], setup["mesh"]
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 400000
+    xyz = _seed_points(pz, n, (np.array(pz.DOMAIN_BOX[0]) - 0.003, np.array(pz.DOMAIN_BOX[1]) + 0.003), seed=17)
+    x, y, z = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+    c = torch.empty(n, dtype=torch.int32, device=dev); g = torch.arange(n, dtype=torch.int64, device=dev)
+    p = lambda t: t.data_ptr()   # noqa: E731
+    ctx.locate_initial_dev(p(x), p(y), p(z), p(c), n)
+    ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
+    torch.cuda.synchronize()
+    cs, gs = c.cpu().numpy(), g.cpu().numpy()
+    inside = cs >= 0
+    k = int(inside.sum())
+    assert inside[:k].all() and not inside[k:].any() and 0 < k < n           # outside particles at the tail
+    assert (np.diff(cs[:k]) >= 0).all()
+    assert np.array_equal(np.sort(gs), np.arange(n))
+    assert np.array_equal(x.cpu().numpy(), xyz[gs, 0]) and np.array_equal(z.cpu().numpy(), xyz[gs, 2])
+    # sub-cell order: recompute the bins on the host for the fullest cell
+    big = np.bincount(cs[:k]).argmax()
+    sel = cs == big
+    pts = np.stack([x.cpu().numpy()[sel], y.cpu().numpy()[sel], z.cpu().numpy()[sel]], 1)
+    off, cf = mesh.cell_faces(); fo = mesh.face_offsets
+    vid = np.unique(np.concatenate([mesh.face_verts[fo[f]:fo[f + 1]] for f in cf[off[big]:off[big + 1]]]))
+    lo, hi = mesh.points[vid].min(0), mesh.points[vid].max(0)
+    u = np.clip(((pts.astype(np.float32) - lo.astype(np.float32)) * (4.0 / (hi - lo)).astype(np.float32)).astype(np.int64), 0, 3)
+    sub = (u[:, 0] << 4) | (u[:, 1] << 2) | u[:, 2]
+    assert (np.diff(sub) >= 0).mean() > 0.999                                   # fp32 bin edges: allow a stray particle
+    ctx.use_own_stream()
