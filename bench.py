@@ -44,7 +44,7 @@ def parse():
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
-    ap.add_argument("--sort-interval", type=int, default=25, help="re-sort the cloud by cell every that many steps")
+    ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
     return ap.parse_args()
 
 

@@ -47,7 +47,7 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
-    int sortInterval = 25;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
+    int sortInterval = 50;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
     uint32_t lastSortStep = 0;
     bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h

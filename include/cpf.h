@@ -137,7 +137,7 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   2 + wave-uniform plane fetches through the scalar cache
  *                   3 (default) wave-cooperative LDS cell cache on packed 256-byte cell records
  *   "stats"         1 (default) accumulate the cpf_get_counters statistics, 0 skip that work
- *   "sort_interval" cpf_step re-sorts the context-owned cloud by cell every N cycles (default 25, 0 = never);
+ *   "sort_interval" cpf_step re-sorts the context-owned cloud by cell every N cycles (default 50, 0 = never);
  *                   invisible to callers: cpf_get_particles always answers in particle-id order */
 int cpf_set_option(cpf_context* ctx, const char* key, double value);   /* Brownian stream; default 1591593751 (particles.cu:544) */
 
