@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
     return ap.parse_args()
@@ -106,7 +106,7 @@ def cpu_baseline(mesh, centres, U, seconds):
             best = (th, cal)
         th //= 2
     th, cal = best
-    cycles = int(max(3, min(2000, seconds / max(cal, 1e-6))))
+    cycles = int(max(3, min(50000, seconds / max(cal, 1e-6))))
     t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, cycles, m, th); el = time.perf_counter() - t0
     return dict(value=round(n * cycles / el / 1e6, 3), unit="Mparticle-steps/s", cores=int(th), kind=kind,
                 sample="%d particles x %d cycles, pitzDaily 146700-tet decomposition, uniform U, OpenMP over "

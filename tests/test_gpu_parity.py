@@ -605,3 +605,18 @@ def test_sort_orders_by_cell_then_position(setup):
     sub = (u[:, 0] << 4) | (u[:, 1] << 2) | u[:, 2]
     assert (np.diff(sub) >= 0).mean() > 0.999                                   # fp32 bin edges: allow a stray particle
     ctx.use_own_stream()
+
+
+def test_64bit_labels_give_the_same_tables(setup, gpu_ctx_factory):
+    """cpf_set_mesh_l64 (OpenFOAM built with WM_LABEL_SIZE=64) == cpf_set_mesh."""
+    import copy
+    mesh = setup["mesh"]
+    m64 = copy.copy(mesh)
+    m64.face_offsets = mesh.face_offsets.astype(np.int64); m64.face_verts = mesh.face_verts.astype(np.int64)
+    m64.owner = mesh.owner.astype(np.int64); m64.neighbour = mesh.neighbour.astype(np.int64)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(m64)
+    a = ctx.mesh_tables(); b = setup["ctx"].mesh_tables()
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    ctx.close()
