@@ -850,7 +850,7 @@ __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __r
 
 size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
     // keys in + keys out + iota + perm + one staging array (24 bytes per particle: also serves the velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -862,7 +862,7 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     if (n <= 1) return hipSuccess;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t tmpBytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
     char* p = (char*)scratch;
     void* tmp = p; p += al(tmpBytes);
