@@ -8,7 +8,7 @@ seeded over the whole fluid domain (BASELINE.json configs[2]; SURVEY.md 8d confi
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one Lagrangian cycle of the whole cloud (one launch of the fused kernel per rank,
-plus the hand-off every --exchange-interval steps when N > 1).  Inputs are resident in HBM when the
+plus, when N > 1, the ownership re-cut + hand-off every --rebalance-interval steps).  Inputs are resident in HBM when the
 timed region starts.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -37,9 +37,15 @@ def parse():
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU (weak) / total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
-    ap.add_argument("--exchange-interval", type=int, default=8)
-    ap.add_argument("--rebalance-interval", type=int, default=24)
+    ap.add_argument("--exchange-interval", type=int, default=0,
+                    help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
+    ap.add_argument("--rebalance-interval", type=int, default=8,
+                    help="N>1: re-cut the cell ranges to equal particle counts + hand-off every that many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--balance", choices=["time", "count"], default="time",
+                    help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
+    ap.add_argument("--overlap-steps", type=int, default=4,
+                    help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -175,6 +181,10 @@ def main():
         cloud.sendbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
         cloud.recvbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
     cloud.rebalance_interval = args.rebalance_interval
+    cloud.overlap_steps = args.overlap_steps
+    cloud.timing_on = True
+    if (world > 1 or args.force_dist) and args.balance == "time":
+        cloud.enable_time_balancing()
     cloud.sort_interval = 0 if args.no_sort else args.sort_interval
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
@@ -196,14 +206,24 @@ def main():
     ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
     n_before = cloud.global_count()
     ctx.timing_enable(True)
-    handed0 = cloud.handed_off
+    ctx.timing_read()                              # drop the warm-up launches' events
+    handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
     torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
     cloud.step(dt, args.steps)
+    cloud.flush()                                  # a hand-off still in flight belongs to the timed region
     torch.cuda.synchronize(); barrier()
     el = time.perf_counter() - t0
-    launches, kernel_ms = ctx.timing_read()
+    launches, kernel_ms = ctx.timing_read()        # + what the load balancer drained during the timed region
+    launches += cloud.kernel_launches - launches0; kernel_ms += cloud.kernel_ms - ms0
+    psteps = cloud.particle_steps - psteps0
     ctx.timing_enable(False)
+    per_rank = [cloud.n]
+    if world > 1:
+        tn = torch.tensor([cloud.n], dtype=torch.int64, device=device)
+        rows = [torch.empty_like(tn) for _ in range(world)]
+        dist.all_gather(rows, tn)
+        per_rank = [int(r.item()) for r in rows]
     t = torch.tensor([el], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -213,7 +233,8 @@ def main():
     if rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        achieved = ALGO_BYTES_PER_PARTICLE_STEP * cloud.n / avg_kernel_s / 1e9 if launches else 0.0
+        per_launch = psteps / max(launches, 1)           # rank 0's particles per launch (varies when N > 1)
+        achieved = ALGO_BYTES_PER_PARTICLE_STEP * per_launch / avg_kernel_s / 1e9 if launches else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -234,6 +255,10 @@ def main():
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
                        "rebalance_interval": args.rebalance_interval if world > 1 else None,
+                       "overlap_steps": args.overlap_steps if (world > 1 or args.force_dist) else None,
+                       "balance": (("measured step time" if args.balance == "time" else "particle count")
+                                   if (world > 1 or args.force_dist) else None),
+                       "particles_per_rank_at_end": per_rank if world > 1 else None,
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
                                                      if world > 1 else None),
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
@@ -242,7 +267,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "cpf::step_kernel_coop<false,true,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
-                         "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE_STEP * cloud.n},
+                         "launches": launches, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PARTICLE_STEP * per_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

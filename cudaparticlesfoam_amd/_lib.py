@@ -64,6 +64,8 @@ SIGNATURES = {
     "cpf_seed_box_dev": (_int, [_ctx, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "cpf_sort_by_cell_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64]),
     "cpf_pack_leavers_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _int, _vp, _i64, _vp, _vp]),
+    "cpf_cell_histogram_dev": (_int, [_ctx, _vp, _i64, _dbl, _vp]),
+    "cpf_cell_ranges_dev": (_int, [_ctx, _vp, _int, _vp]),
     "cpf_unpack_arrivals_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64]),
     "cpf_dev_alloc": (_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
     "cpf_dev_free": (_int, [_ctx, _vp]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     "cpf_write_vtu_arrays": (_int, [C.c_char_p, _i64, _vp, _vp, _vp, C.POINTER(_dbl)]),
     "cpf_timing_enable": (_int, [_ctx, _int]),
     "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "cpf_timing_poll": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
 }
 
 _lib = None

@@ -168,6 +168,12 @@ class Context:
         self._ck(self.lib.cpf_pack_leavers_dev(self.h, x, y, z, cell, gid, n, cell_lo, n_ranks, my_rank, sendbuf,
                                                send_cap, counts, n_stay))
 
+    def cell_histogram_dev(self, cell, n, scale, weights):
+        self._ck(self.lib.cpf_cell_histogram_dev(self.h, cell, n, scale, weights))
+
+    def cell_ranges_dev(self, weights, n_ranks, cell_lo):
+        self._ck(self.lib.cpf_cell_ranges_dev(self.h, weights, n_ranks, cell_lo))
+
     def unpack_arrivals_dev(self, x, y, z, cell, gid, n_stay, recvbuf, n_recv):
         self._ck(self.lib.cpf_unpack_arrivals_dev(self.h, x, y, z, cell, gid, n_stay, recvbuf, n_recv))
 
@@ -177,6 +183,12 @@ class Context:
     def timing_read(self):
         a, b = C.c_int64(), C.c_double()
         self._ck(self.lib.cpf_timing_read(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timing_poll(self):
+        """Like timing_read but never waits: only launches that already finished are drained."""
+        a, b = C.c_int64(), C.c_double()
+        self._ck(self.lib.cpf_timing_poll(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
 

@@ -539,6 +539,28 @@ int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int3
     return CPF_OK;
 }
 
+int cpf_cell_histogram_dev(cpf_context* ctx, const int32_t* cell, int64_t n, double scale, double* weights_dev) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_cell_histogram_dev: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, n >= 0 && weights_dev && (cell || n == 0), CPF_ERR_ARG, "cpf_cell_histogram_dev: bad arguments");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    int r = ensureScratch(ctx, cpf::histogram_scratch_bytes(ctx->host.nCells));
+    if (r != CPF_OK) return r;
+    CPF_HIP(ctx, cpf::cell_histogram(ctx->stream, cell, n, ctx->host.nCells, scale, weights_dev, ctx->scratch,
+                                     ctx->scratchBytes));
+    return CPF_OK;
+}
+
+int cpf_cell_ranges_dev(cpf_context* ctx, const double* weights_dev, int nRanks, int32_t* cellLo_dev) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_cell_ranges_dev: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, weights_dev && cellLo_dev && nRanks >= 1 && nRanks <= 16, CPF_ERR_ARG,
+                "cpf_cell_ranges_dev: bad arguments (1 <= nRanks <= 16)");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, cpf::cell_ranges(ctx->stream, weights_dev, ctx->host.nCells, nRanks, cellLo_dev));
+    return CPF_OK;
+}
+
 int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                             int64_t nStay, const double* recvbuf, int64_t nRecv) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
@@ -687,6 +709,27 @@ int cpf_timing_read(cpf_context* ctx, int64_t* launches, double* total_ms) {
     *launches = (int64_t)ctx->events.size();
     *total_ms = tot;
     ctx->events.clear();
+    return CPF_OK;
+}
+
+int cpf_timing_poll(cpf_context* ctx, int64_t* launches, double* total_ms) {
+    CPF_REQUIRE(ctx, ctx && launches && total_ms, CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    double tot = 0.0;
+    size_t done = 0;
+    for (; done < ctx->events.size(); ++done) {          // launches complete in stream order
+        auto& p = ctx->events[done];
+        const hipError_t q = hipEventQuery(p.second);
+        if (q == hipErrorNotReady) break;
+        CPF_HIP(ctx, q);
+        float ms = 0.f;
+        CPF_HIP(ctx, hipEventElapsedTime(&ms, p.first, p.second));
+        tot += (double)ms;
+        ctx->eventPool.push_back(p.first); ctx->eventPool.push_back(p.second);
+    }
+    ctx->events.erase(ctx->events.begin(), ctx->events.begin() + (std::ptrdiff_t)done);
+    *launches = (int64_t)done;
+    *total_ms = tot;
     return CPF_OK;
 }
 

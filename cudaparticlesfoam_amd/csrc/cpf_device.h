@@ -69,6 +69,10 @@ size_t handoff_scratch_bytes(int64_t n, int nRanks);
 hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
                         const int32_t* cellLo, int nRanks, int myRank, double* sendbuf, int64_t sendCapacity,
                         int64_t* counts, int64_t* nStay, void* scratch, size_t scratchBytes);
+size_t histogram_scratch_bytes(int64_t nCells);
+hipError_t cell_histogram(hipStream_t st, const int32_t* cell, int64_t n, int64_t nCells, double scale, double* weights,
+                          void* scratch, size_t scratchBytes);
+hipError_t cell_ranges(hipStream_t st, const double* weights, int64_t nCells, int nRanks, int32_t* cellLo);
 hipError_t unpack_arrivals(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                            int64_t nStay, const double* recvbuf, int64_t nRecv);
 

@@ -155,6 +155,15 @@ __global__ __launch_bounds__(kBlock) void fill_holes_kernel(double* __restrict__
     }
 }
 
+// After the split the slots [nStay, n) hold stale copies (leavers and moved fillers).  Marking them CPF_CELL_LOST
+// lets the caller keep stepping the old range [0, n) while the all-to-all is still in flight (the host learns nStay
+// only with the counts): inactive lanes cost one 4-byte load.
+__global__ __launch_bounds__(kBlock) void mark_tail_kernel(int32_t* __restrict__ cell, const int64_t* __restrict__ nStayPtr,
+                                                           int64_t n) {
+    for (int64_t i = *nStayPtr + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        cell[i] = CPF_CELL_LOST;
+}
+
 __global__ __launch_bounds__(kBlock) void unpack_arrivals_kernel(double* __restrict__ x, double* __restrict__ y,
                                                                  double* __restrict__ z, int32_t* __restrict__ cell,
                                                                  int64_t* __restrict__ gid, int64_t nStay,
@@ -166,6 +175,193 @@ __global__ __launch_bounds__(kBlock) void unpack_arrivals_kernel(double* __restr
     x[i] = rec[0]; y[i] = rec[1]; z[i] = rec[2];
     cell[i] = (int32_t)rec[3];
     if (gid) gid[i] = (int64_t)rec[4];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ownership re-cut: per-cell particle counts -> (all-reduce over ranks, by the host layer) -> range cuts.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHistBlock = 1024;             // 16 waves per block: one block per CU keeps a private LDS histogram
+constexpr int kHistBlocks = 512;
+constexpr int kHistMaxLdsCells = 32768;      // 128 KB of the CU's 160 KB LDS as u32 bins
+
+// Path A (meshes up to 32768 cells): every block counts a contiguous chunk of the shard into an LDS histogram
+// (ds_add_u32; runs of equal cells in a wave -- the cloud is mostly cell-sorted -- are pre-counted with a ballot
+// so they cost one LDS atomic), then stores it densely as one row of partial[block][cell].  No global atomics,
+// independent of how sorted the input is, and deterministic.
+__global__ __launch_bounds__(kHistBlock) void cell_histogram_lds_kernel(const int32_t* __restrict__ cell, int64_t n,
+                                                                        int nCells, int64_t perBlock,
+                                                                        unsigned int* __restrict__ partial) {
+    extern __shared__ unsigned int sHist[];
+    for (int b = threadIdx.x; b < nCells; b += kHistBlock) sHist[b] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * perBlock;
+    const int64_t hi = (lo + perBlock < n) ? lo + perBlock : n;
+    const int lane = threadIdx.x & 63;
+    constexpr int kUnroll = 4;                                        // 4 independent loads in flight per lane
+    for (int64_t base = lo; base < hi; base += kUnroll * kHistBlock) {   // wave-uniform trip count
+        int cs[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t i = base + (int64_t)u * kHistBlock + threadIdx.x;
+            cs[u] = (i < hi) ? cell[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int c = cs[u];
+            bool todo = c >= 0;
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long m = __ballot(todo);
+                if (m == 0ull) break;
+                const int leader = __ffsll((long long)m) - 1;
+                const int cl = __builtin_amdgcn_readlane(c, leader);
+                const unsigned long long same = __ballot(todo && c == cl);
+                if (lane == leader) atomicAdd(&sHist[cl], (unsigned int)__popcll(same));
+                if (c == cl) todo = false;
+            }
+            if (todo) atomicAdd(&sHist[c], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned int* row = partial + (int64_t)blockIdx.x * nCells;
+    for (int b = threadIdx.x; b < nCells; b += kHistBlock) row[b] = sHist[b];
+}
+
+// weights[c] = scale * sum over blocks of partial[block][c].  A block takes 64 cells; its 4 waves split the rows
+// (lane = cell, so every row read is one coalesced 256-byte segment) and combine through LDS.
+__global__ __launch_bounds__(kBlock) void cell_histogram_reduce_kernel(const unsigned int* __restrict__ partial,
+                                                                       int nBlocks, int nCells, double scale,
+                                                                       double* __restrict__ weights) {
+    __shared__ unsigned long long sPart[kBlock / 64][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    unsigned long long s = 0;
+    if (b < nCells) {
+#pragma unroll 8
+        for (int k = grp; k < nBlocks; k += kBlock / 64) s += partial[(int64_t)k * nCells + b];
+    }
+    sPart[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && b < nCells) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int g = 0; g < kBlock / 64; ++g) tot += sPart[g][lane];
+        weights[b] = (double)tot * scale;
+    }
+}
+
+// Path B (larger meshes): global 64-bit atomics, one per run of equal cells in a wave.
+__global__ __launch_bounds__(kBlock) void cell_histogram_global_kernel(const int32_t* __restrict__ cell, int64_t n,
+                                                                       unsigned long long* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int c = (i < n) ? cell[i] : -1;
+    bool todo = c >= 0;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long m = __ballot(todo);
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const int cl = __builtin_amdgcn_readlane(c, leader);
+        const unsigned long long same = __ballot(todo && c == cl);
+        if (lane == leader) atomicAdd(&hist[cl], (unsigned long long)__popcll(same));
+        if (c == cl) todo = false;
+    }
+    if (todo) atomicAdd(&hist[c], 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void counts_to_weights_kernel(const unsigned long long* __restrict__ hist,
+                                                                   int nCells, double scale, double* __restrict__ weights) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b < nCells) weights[b] = (double)hist[b] * scale;
+}
+
+size_t histogram_scratch_bytes(int64_t nCells) {
+    return nCells <= kHistMaxLdsCells ? (size_t)kHistBlocks * (size_t)nCells * 4 : (size_t)nCells * 8;
+}
+
+hipError_t cell_histogram(hipStream_t st, const int32_t* cell, int64_t n, int64_t nCells, double scale, double* weights,
+                          void* scratch, size_t scratchBytes) {
+    if (scratchBytes < histogram_scratch_bytes(nCells)) return hipErrorInvalidValue;
+    const int cellBlocks = (int)((nCells + kBlock - 1) / kBlock);
+    if (nCells <= kHistMaxLdsCells) {
+        static bool attrSet = false;
+        if (!attrSet) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cell_histogram_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kHistMaxLdsCells * 4);
+            if (e != hipSuccess) return e;
+            attrSet = true;
+        }
+        int64_t perBlock = (n + kHistBlocks - 1) / kHistBlocks;
+        perBlock = (perBlock + 4 * kHistBlock - 1) / (4 * kHistBlock) * (4 * kHistBlock);   // whole unrolled trips
+        if (perBlock == 0) perBlock = 4 * kHistBlock;
+        hipLaunchKernelGGL(cell_histogram_lds_kernel, dim3(kHistBlocks), dim3(kHistBlock), (size_t)nCells * 4, st, cell, n,
+                           (int)nCells, perBlock, (unsigned int*)scratch);
+        hipLaunchKernelGGL(cell_histogram_reduce_kernel, dim3((unsigned)((nCells + 63) / 64)), dim3(kBlock), 0, st,
+                           (const unsigned int*)scratch, kHistBlocks, (int)nCells, scale, weights);
+    } else {
+        hipError_t e = hipMemsetAsync(scratch, 0, (size_t)nCells * 8, st);
+        if (e != hipSuccess) return e;
+        if (n > 0)
+            hipLaunchKernelGGL(cell_histogram_global_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                               st, cell, n, (unsigned long long*)scratch);
+        hipLaunchKernelGGL(counts_to_weights_kernel, dim3(cellBlocks), dim3(kBlock), 0, st,
+                           (const unsigned long long*)scratch, (int)nCells, scale, weights);
+    }
+    return hipGetLastError();
+}
+
+// Equal-weight cuts of cells 0..nCells-1 into nRanks contiguous ranges, the rule of parallel.slab_cell_ranges:
+// cum0[i] = w[0] + ... + w[i-1] (i = 0..nCells), cut_q = #{ i : cum0[i] < total*q/nRanks }  (== searchsorted-left,
+// cum0 being non-decreasing).  One block: per-thread chunk sums, a serial scan of the 1024 chunk sums in LDS, then
+// every thread walks its chunk again and counts.  A few tens of microseconds even for 1e6 cells; runs once per
+// re-cut.
+__global__ __launch_bounds__(kHistBlock) void cell_ranges_kernel(const double* __restrict__ w, int nCells, int nRanks,
+                                                                 int32_t* __restrict__ cellLo) {
+    __shared__ double sBase[kHistBlock];
+    __shared__ double sTotal;
+    __shared__ int sCut[kMaxRanks];
+    const int nIdx = nCells + 1;                                   // cum0 has nCells + 1 entries
+    const int per = (nIdx + kHistBlock - 1) / kHistBlock;
+    const int i0 = min(nIdx, (int)threadIdx.x * per), i1 = min(nIdx, i0 + per);
+    double s = 0.0;
+    for (int i = i0; i < i1; ++i) s += (i < nCells) ? w[i] : 0.0;
+    sBase[threadIdx.x] = s;
+    if (threadIdx.x < kMaxRanks) sCut[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < kHistBlock; ++t) { const double v = sBase[t]; sBase[t] = run; run += v; }
+        sTotal = run;
+    }
+    __syncthreads();
+    const double total = sTotal;
+    int below[kMaxRanks];
+#pragma unroll
+    for (int q = 0; q < kMaxRanks; ++q) below[q] = 0;
+    double run = sBase[threadIdx.x];
+    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+        for (int q = 1; q < kMaxRanks; ++q)
+            if (q < nRanks && run < total * (double)q / (double)nRanks) ++below[q];
+        if (i < nCells) run += w[i];
+    }
+#pragma unroll
+    for (int q = 1; q < kMaxRanks; ++q)
+        if (q < nRanks && below[q]) atomicAdd(&sCut[q], below[q]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int prev = 0;
+        cellLo[0] = 0;
+        for (int q = 1; q < nRanks; ++q) { prev = max(prev, sCut[q]); cellLo[q] = prev; }
+        cellLo[nRanks] = nCells;
+    }
+}
+
+hipError_t cell_ranges(hipStream_t st, const double* weights, int64_t nCells, int nRanks, int32_t* cellLo) {
+    if (nRanks < 1 || nRanks > kMaxRanks) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cell_ranges_kernel, dim3(1), dim3(kHistBlock), 0, st, weights, (int)nCells, nRanks, cellLo);
+    return hipGetLastError();
 }
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -198,6 +394,7 @@ hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t
         const int fillBlocks = (int)std::min<int64_t>(1024, (n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(fill_holes_kernel, dim3(fillBlocks), dim3(kBlock), 0, st, x, y, z, cell, gid, holes, fillers,
                            holeFill);
+        hipLaunchKernelGGL(mark_tail_kernel, dim3(fillBlocks), dim3(kBlock), 0, st, cell, nStay, n);
     }
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@ therefore decoupled from the step cadence.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Sequence
 
 import numpy as np
@@ -35,6 +36,20 @@ def slab_cell_ranges(weights: np.ndarray, n_ranks: int) -> np.ndarray:
     for r in range(1, n_ranks + 1):          # keep ranges non-decreasing even for degenerate weights
         lo[r] = max(lo[r], lo[r - 1])
     return lo
+
+
+COST_UNIT_MS = 2.0e-8      # ms per particle-step that counts as cost 1 (~ the measured single-GPU rate)
+
+
+def device_cell_ranges(hist: torch.Tensor, n_ranks: int) -> torch.Tensor:
+    """``slab_cell_ranges`` on the histogram's own device (int64 counts or float64 weights -> int32
+    cell_lo[n_ranks+1]); counts are exact in float64 below 2^53, so both give the same cuts."""
+    cum = torch.cumsum(hist.to(torch.float64), 0)
+    cum0 = torch.cat([cum.new_zeros(1), cum])
+    targets = cum[-1] * torch.arange(1, n_ranks, dtype=torch.float64, device=hist.device) / n_ranks
+    cuts = torch.searchsorted(cum0, targets, right=False)
+    lo = torch.cat([cuts.new_zeros(1), cuts, cuts.new_full((1,), hist.numel())])
+    return torch.cummax(lo, 0).values.to(torch.int32)
 
 
 def x_slab_renumbering(centres: np.ndarray) -> np.ndarray:
@@ -76,6 +91,18 @@ class HipOps:
         self.ctx.step_dev(self._p(s.x), self._p(s.y), self._p(s.z), self._p(s.cell), self._p(s.gid), None, s.n, dt, D,
                           step0, n_cycles, flags)
 
+    def step_slice(self, s: "ShardedCloud", first: int, count: int, dt, D, step0, n_cycles, flags):
+        """Steps only particles [first, first+count) for n_cycles (one fused launch): arrivals catching up on the
+        steps they missed while in flight.  Not a timed launch (keeps the balancer's per-launch times clean)."""
+        timing = s.balance_by_time or s.timing_on
+        if timing:
+            self.ctx.timing_enable(False)
+        self.ctx.step_dev(s.x.data_ptr() + 8 * first, s.y.data_ptr() + 8 * first, s.z.data_ptr() + 8 * first,
+                          s.cell.data_ptr() + 4 * first, s.gid.data_ptr() + 8 * first, None, count, dt, D, step0, n_cycles,
+                          flags | L.STEP_FUSE_CYCLES)
+        if timing:
+            self.ctx.timing_enable(True)
+
     def pack(self, s: "ShardedCloud"):
         self.ctx.pack_leavers_dev(self._p(s.x), self._p(s.y), self._p(s.z), self._p(s.cell), self._p(s.gid), s.n,
                                   self._p(s.cell_lo_dev), s.world, s.rank, self._p(s.sendbuf), s.send_capacity,
@@ -84,6 +111,20 @@ class HipOps:
     def unpack(self, s: "ShardedCloud", n_stay: int, recvbuf: torch.Tensor, n_recv: int):
         self.ctx.unpack_arrivals_dev(self._p(s.x), self._p(s.y), self._p(s.z), self._p(s.cell), self._p(s.gid), n_stay,
                                      self._p(recvbuf), n_recv)
+
+    def enable_timing(self, s: "ShardedCloud"):
+        self.ctx.timing_enable(True)
+
+    def step_time(self, s: "ShardedCloud", wait: bool):
+        """(launches, summed device ms) of this rank's step launches since the last call; ``wait`` blocks for
+        the launches still in flight, otherwise only finished ones are drained."""
+        return self.ctx.timing_read() if wait else self.ctx.timing_poll()
+
+    def histogram(self, s: "ShardedCloud", scale: float):
+        self.ctx.cell_histogram_dev(self._p(s.cell), s.n, scale, self._p(s.weights_dev))
+
+    def cell_ranges(self, s: "ShardedCloud"):
+        self.ctx.cell_ranges_dev(self._p(s.weights_dev), s.world, self._p(s.cell_lo_dev))
 
     def sort(self, s: "ShardedCloud"):
         self.ctx.sort_by_cell_dev(self._p(s.x), self._p(s.y), self._p(s.z), self._p(s.cell), self._p(s.gid), s.n)
@@ -115,8 +156,23 @@ class ShardedCloud:
         self.recvbuf = torch.empty(self.send_capacity * L.HANDOFF_DOUBLES, **f64)
         self.counts_dev = torch.zeros(16, dtype=torch.int64, device=device)
         self.nstay_dev = torch.zeros(1, dtype=torch.int64, device=device)
-        self.exchange_interval = max(1, int(exchange_interval))
+        # overlapped hand-off: after the split the step loop runs on for ``overlap_steps`` cycles while counts and
+        # payload travel on a side stream; the arrivals then catch up on the cycles they missed (see step())
+        self.overlap_steps = 0
+        self.timing_on = False       # set when the caller brackets step launches with events itself (bench.py)
+        self._pending = None
+        self._sort_due = False
+        self._step_args = None
+        self._side = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        self.weights_dev = None      # per-cell particle counts x cost (allocated by the first rebalance)
+        # load balancing by MEASURED step time (see rebalance()): ms per particle-step of this rank's region
+        self.balance_by_time = False
+        self.cost_per_particle = None
+        self.kernel_ms = 0.0         # step-kernel device time drained by the balancer (ms) ...
+        self.kernel_launches = 0     # ... and the launches it covers (bench.py adds them to its own read)
+        self.exchange_interval = max(0, int(exchange_interval))   # 0 = only hand off inside rebalance()
         self.step_index = 0
+        self.particle_steps = 0      # cumulative particles x steps stepped by this rank
         self.handed_off = 0          # cumulative particles sent away by this rank
         self.exchanges = 0
         self.rebalances = 0
@@ -140,60 +196,155 @@ class ShardedCloud:
 
     # -- the hot loop
     def step(self, dt: float, n_cycles: int = 1, D: float = 0.0, flags: int = 0):
+        if self._pending is not None and self._step_args != (dt, D, flags):
+            self._finish_exchange()                     # the catch-up replays the window with ONE set of arguments
+        self._step_args = (dt, D, flags)
+        dist_on = self.world > 1 or self.force_collectives
         for _ in range(n_cycles):
+            if self._pending is not None and self.step_index - self._pending["step"] >= self.overlap_steps:
+                self._finish_exchange()
             self.ops.step(self, dt, D, self.step_index, 1, flags)
             self.step_index += 1
+            self.particle_steps += self.n
             if self.sort_interval and self.step_index % self.sort_interval == 0:
-                self.sort()
-            if self.world > 1 or self.force_collectives:
+                if self._pending is None:
+                    self.sort()
+                else:
+                    self._sort_due = True               # never reorder while stale tail slots are in the range
+            if dist_on:
                 if self.rebalance_interval and self.step_index % self.rebalance_interval == 0:
-                    self.rebalance(self.n_cells)
-                elif self.step_index % self.exchange_interval == 0:
-                    self.exchange()
+                    self._finish_exchange()
+                    self._recut()
+                    self._begin_exchange()
+                elif self.exchange_interval and self.step_index % self.exchange_interval == 0:
+                    self._finish_exchange()
+                    self._begin_exchange()
+        if self.overlap_steps == 0:
+            self._finish_exchange()
+
+    def flush(self):
+        """Completes a hand-off still in flight (arrivals appended and caught up)."""
+        self._finish_exchange()
 
     def exchange(self):
-        """Hand particles that left this rank's cell range to their owners (all-to-all-v)."""
+        """Hand particles that left this rank's cell range to their owners (all-to-all-v), synchronously."""
         if self.world == 1 and not self.force_collectives:
             return
-        self.ops.pack(self)
-        # one small D2H: per-destination counts + nStay (sizes must be host-known for the collective)
-        host = torch.cat([self.counts_dev[: self.world], self.nstay_dev]).cpu()
-        send_counts = [int(v) for v in host[: self.world]]
-        n_stay = int(host[self.world])
-        if sum(send_counts) > self.send_capacity:
-            raise RuntimeError("hand-off buffer overflow: %d leavers > capacity %d" % (sum(send_counts),
-                                                                                       self.send_capacity))
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(v) for v in rc.cpu()]
-        n_recv = sum(recv_counts)
-        if n_stay + n_recv > self.capacity:
-            raise RuntimeError("shard overflow: %d + %d arrivals > capacity %d" % (n_stay, n_recv, self.capacity))
-        if n_recv > self.send_capacity:
-            self.recvbuf = torch.empty(n_recv * L.HANDOFF_DOUBLES, dtype=torch.float64, device=self.device)
-        D = L.HANDOFF_DOUBLES
-        dist.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: sum(send_counts) * D],
-                               [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
-        self.ops.unpack(self, n_stay, self.recvbuf, n_recv)
-        self.n = n_stay + n_recv
-        self.handed_off += sum(send_counts)
-        self.exchanges += 1
+        self._finish_exchange()
+        self._begin_exchange()
+        self._finish_exchange()
 
-    def rebalance(self, n_cells: int):
-        """Recompute the cell ranges so that every rank owns the same number of particles (global
-        per-cell histogram -> all-reduce -> equal-count cuts), then hand particles to their new owners.
-        Legal at any time because the mesh is replicated; keeps a drifting cloud (everything flows to
-        the outlet) from piling up on one rank."""
+    def _begin_exchange(self):
+        """Split the shard on the compute stream: leavers into the send buffer, stayers compacted into
+        [0, nStay), the stale tail marked inactive.  Counts and nStay stay in device memory for now."""
+        self.ops.pack(self)
+        ev = None
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        self._pending = {"step": self.step_index, "event": ev}
+
+    def _finish_exchange(self):
+        """Counts all-gather + payload all-to-all-v on the side stream (the compute stream keeps running the
+        steps queued since the split), then append the arrivals and let them catch up on those steps.
+
+        One host synchronisation, on the side stream only: the per-destination counts of every rank are
+        all-gathered on the device (world x (world+1) int64) and copied to the host once, which gives this
+        rank both its send sizes (its row) and its receive sizes (its column)."""
+        p = self._pending
+        if p is None:
+            return
+        self._pending = None
+        W = self.world
+        D = L.HANDOFF_DOUBLES
+        side = contextlib.nullcontext() if self._side is None else torch.cuda.stream(self._side)
+        with side:
+            if self._side is not None:
+                self._side.wait_event(p["event"])
+            meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
+            rows = [torch.empty_like(meta) for _ in range(W)]
+            dist.all_gather(rows, meta, group=self.group)
+            host = torch.cat(rows + [self.cell_lo_dev.to(torch.int64)]).cpu().numpy()
+            table = host[: W * (W + 1)].reshape(W, W + 1)
+            self.cell_lo = host[W * (W + 1):].astype(np.int32)
+            send_counts = [int(v) for v in table[self.rank, :W]]
+            recv_counts = [int(v) for v in table[:, self.rank]]
+            n_stay = int(table[self.rank, W])
+            n_send, n_recv = sum(send_counts), sum(recv_counts)
+            if n_send > self.send_capacity:
+                raise RuntimeError("hand-off buffer overflow: %d leavers > capacity %d" % (n_send, self.send_capacity))
+            if n_stay + n_recv > self.capacity:
+                raise RuntimeError("shard overflow: %d + %d arrivals > capacity %d" % (n_stay, n_recv, self.capacity))
+            if n_recv * D > self.recvbuf.numel():
+                self.recvbuf = torch.empty(n_recv * D, dtype=torch.float64, device=self.device)
+            dist.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
+                                   [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
+            if self._side is not None:
+                done = torch.cuda.Event()
+                done.record(self._side)
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)   # also orders the next pack after this all-to-all
+        missed = self.step_index - p["step"]
+        self.particle_steps -= (self.n - n_stay) * missed             # the inactive tail was not real work
+        self.ops.unpack(self, n_stay, self.recvbuf, n_recv)
+        if missed and n_recv:
+            dt, Dc, flags = self._step_args
+            self.ops.step_slice(self, n_stay, n_recv, dt, Dc, p["step"], missed, flags)
+            self.particle_steps += n_recv * missed
+        self.n = n_stay + n_recv
+        self.handed_off += n_send
+        self.exchanges += 1
+        if self._sort_due:
+            self._sort_due = False
+            self.sort()
+
+    def rebalance(self, n_cells: Optional[int] = None):
+        """Re-cut the ranges (see ``_recut``) and hand particles to their new owners, synchronously."""
         if self.world == 1 and not self.force_collectives:
             return
-        c = self.cell[: self.n]
-        hist = torch.bincount(c[c >= 0].to(torch.int64), minlength=n_cells).to(torch.float64)
-        dist.all_reduce(hist, group=self.group)
-        self.cell_lo = slab_cell_ranges(hist.cpu().numpy(), self.world)
-        self.cell_lo_dev.copy_(torch.from_numpy(self.cell_lo.copy()))
-        self.exchange()
+        self._finish_exchange()
+        self._recut(n_cells)
+        self._begin_exchange()
+        self._finish_exchange()                # also refreshes the host copy self.cell_lo
+
+    def _recut(self, n_cells: Optional[int] = None):
+        """Re-cut the cell ranges so that every rank owns the same number of particles (or the same
+        measured cost), then hand particles to their new owners.  Per-cell histogram (HIP kernel) ->
+        all-reduce -> prefix sums and cut search in one HIP kernel (no host round trip; the rule of
+        ``slab_cell_ranges``) -> exchange.
+
+        Legal at any time because the mesh is replicated.  For a cloud that drifts with the flow the
+        equal-count cuts drift with it, so re-cutting hands over far fewer particles than keeping the
+        ranges fixed would (and nothing piles up on the outlet rank)."""
+        n_cells = self.n_cells if n_cells is None else int(n_cells)
+        if self.weights_dev is None or self.weights_dev.numel() != n_cells:
+            self.weights_dev = torch.zeros(n_cells, dtype=torch.float64, device=self.device)
+        # equal-COST cuts when balancing by time: every rank scales its counts by its measured ms per
+        # particle-step (hops per step differ across the mesh: fine cells cost more), so the all-reduced
+        # histogram is a cost density; scale 1 gives equal-count cuts
+        self.ops.histogram(self, self._measured_cost() if self.balance_by_time else 1.0)
+        dist.all_reduce(self.weights_dev, group=self.group)
+        self.ops.cell_ranges(self)
         self.rebalances += 1
+
+    def enable_time_balancing(self, on: bool = True):
+        """Re-cut by measured cost instead of by particle count (must be set the same on every rank)."""
+        self.balance_by_time = bool(on)
+        if on:
+            self.ops.enable_timing(self)
+
+    def _measured_cost(self) -> float:
+        """This rank's cost per particle-step in units of COST_UNIT_MS (about 1 at the 1e7-particle bench rate;
+        the unit only has to be the same on every rank), from the HIP-event times of its own step launches.
+        Never stalls the launch queue except for the very first measurement; smoothed 50/50 with the previous
+        value.  Before any step has run every rank returns 1 (plain equal-count cuts)."""
+        first = self.cost_per_particle is None
+        launches, ms = self.ops.step_time(self, wait=first)
+        self.kernel_ms += ms; self.kernel_launches += launches
+        if launches > 0 and self.n > 0:
+            cost = ms / launches / self.n / COST_UNIT_MS
+            self.cost_per_particle = cost if first else 0.5 * (self.cost_per_particle + cost)
+        return 1.0 if self.cost_per_particle is None else self.cost_per_particle
 
     def sort(self):
         self.ops.sort(self)
@@ -201,11 +352,13 @@ class ShardedCloud:
     # -- inspection
     def gather_to_numpy(self):
         """(gid, x, y, z, cell) of this shard on the host."""
+        self._finish_exchange()
         n = self.n
         return (self.gid[:n].cpu().numpy(), self.x[:n].cpu().numpy(), self.y[:n].cpu().numpy(),
                 self.z[:n].cpu().numpy(), self.cell[:n].cpu().numpy())
 
     def global_count(self) -> int:
+        self._finish_exchange()
         t = torch.tensor([self.n], dtype=torch.int64, device=self.device)
         if self.world > 1:
             dist.all_reduce(t, group=self.group)

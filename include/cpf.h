@@ -163,11 +163,20 @@ int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int3
  * O(leavers) particles move; order is not preserved), leavers are written, grouped by destination
  * rank and in index order, into sendbuf as records of CPF_HANDOFF_DOUBLES doubles (x, y, z, cell-as-double,
  * gid-as-double).  counts[nRanks] (device int64) = records per destination; nStay (device).
- * Lost/frozen particles stay where they are. */
+ * Lost/frozen particles stay where they are.  The slots [nStay, n) are then marked CPF_CELL_LOST, so a
+ * caller that learns nStay late (it sits in device memory) may keep stepping [0, n) while the all-to-all is
+ * in flight and let the arrivals catch up afterwards (cpf_step_dev on the appended slice, same step0). */
 #define CPF_HANDOFF_DOUBLES 5
 int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                          int64_t n, const int32_t* cellLo_dev, int nRanks, int myRank, double* sendbuf,
                          int64_t sendCapacity, int64_t* counts_dev, int64_t* nStay_dev);
+/* Ownership re-cut, step 1: weights_dev[c] = scale * (number of this shard's particles in cell c), c < nCells
+ * (device doubles, overwritten; lost/frozen particles are not counted).  scale = this rank's measured cost per
+ * particle-step (or 1 for equal-count cuts); the host layer all-reduces the weights over the ranks. */
+int cpf_cell_histogram_dev(cpf_context* ctx, const int32_t* cell, int64_t n, double scale, double* weights_dev);
+/* step 2: cellLo_dev[0..nRanks] (device int32) = contiguous cell ranges of equal total weight:
+ * cellLo[q] = #{ i in 0..nCells : w[0]+...+w[i-1] < total*q/nRanks }, cellLo[0] = 0, cellLo[nRanks] = nCells. */
+int cpf_cell_ranges_dev(cpf_context* ctx, const double* weights_dev, int nRanks, int32_t* cellLo_dev);
 /* append nRecv received records at index nStay.. of the arrays */
 int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                             int64_t nStay, const double* recvbuf, int64_t nRecv);
@@ -223,6 +232,9 @@ int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const 
 int cpf_timing_enable(cpf_context* ctx, int on);
 /* Drains the recorded pairs: number of launches and their summed device time in ms. */
 int cpf_timing_read(cpf_context* ctx, int64_t* launches, double* total_ms);
+/* Same, but never waits: drains only the launches that have already finished (possibly none).  Feeds the
+ * multi-GPU load balancer with this rank's measured step time without stalling the launch queue. */
+int cpf_timing_poll(cpf_context* ctx, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,8 @@ from oracle import oracle as O                                                # 
 def main():
     out_path, interval = sys.argv[1], int(sys.argv[2])
     rebalance = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 0               # steps the loop runs on while a hand-off is in flight
+    slow_rank0 = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # > 0: balance by "measured" time, rank 0 that much slower
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -32,7 +34,8 @@ def main():
     cell_lo = slab_cell_ranges(vols, world)
     # every rank starts with an arbitrary slice of the cloud (NOT its own slab): first exchange fixes that
     mine = np.arange(rank, n_total, world)
-    cloud = ShardedCloud(FakeOps(cw, t, U), cell_lo, n_total + 16, torch.device("cpu"), rank, world,
+    ops = FakeOps(cw, t, U, 2.0e-8 * (slow_rank0 if (slow_rank0 and rank == 0) else 1.0))
+    cloud = ShardedCloud(ops, cell_lo, n_total + 16, torch.device("cpu"), rank, world,
                          send_fraction=1.0, exchange_interval=interval)
     cloud.set_particles(torch.from_numpy(xyz[mine, 0].copy()), torch.from_numpy(xyz[mine, 1].copy()),
                         torch.from_numpy(xyz[mine, 2].copy()), None, torch.from_numpy(mine.astype(np.int64)))
@@ -41,6 +44,10 @@ def main():
     owned_ok = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     total0 = cloud.global_count()
     cloud.rebalance_interval = rebalance
+    cloud.overlap_steps = overlap
+    cloud.sort_interval = 7 if overlap else 0
+    if slow_rank0:
+        cloud.enable_time_balancing()
     cloud.step(0.2, 30)
     if interval > 1:
         cloud.exchange()
@@ -50,7 +57,7 @@ def main():
     owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
-             n_local=cloud.n)
+             n_local=cloud.n, cell_lo=np.asarray(cell_lo))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -317,6 +317,167 @@ def test_handoff_pack_unpack_single_gpu(setup, gpu_ctx_factory):
     ctx.use_own_stream()
 
 
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_cell_histogram_matches_bincount(setup, order):
+    """Per-cell particle counts x scale (input of the ownership re-cut) == numpy.bincount, for cell-sorted input
+    (one LDS atomic per run) and for shuffled input (per-lane atomics); lost/frozen states are ignored."""
+    import torch
+    mesh, ctx = setup["mesh"], setup["ctx"]
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(31)
+    n = 1_000_003
+    c = rng.integers(0, mesh.n_cells, size=n).astype(np.int32)
+    c[rng.random(n) < 0.01] = -1
+    c[rng.random(n) < 0.01] = -2
+    c[:5000] = 17                                                                    # one hot cell
+    if order == "sorted":
+        c = np.sort(c)
+    cell = torch.from_numpy(c).to(dev)
+    w = torch.full((mesh.n_cells,), 77.0, dtype=torch.float64, device=dev)          # must be overwritten, not added to
+    want = np.bincount(c[c >= 0], minlength=mesh.n_cells)
+    for scale in (1.0, 0.375):
+        ctx.cell_histogram_dev(cell.data_ptr(), n, scale, w.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(w.cpu().numpy(), want * scale)
+    ctx.cell_histogram_dev(cell.data_ptr(), 0, 1.0, w.data_ptr())                   # empty shard -> all zero
+    torch.cuda.synchronize()
+    assert float(w.abs().sum().item()) == 0.0
+    ctx.use_own_stream()
+
+
+def test_cell_histogram_global_path_on_a_large_mesh(gpu_ctx_factory):
+    """Meshes with more cells than fit an LDS histogram (> 32768) take the global-atomic path."""
+    import torch
+    from cudaparticlesfoam_amd.cases import box_mesh
+    mesh = box_mesh(40, 40, 25)                                                      # 40 000 cells
+    ctx = gpu_ctx_factory(); ctx.set_mesh(mesh)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(2)
+    c = np.sort(rng.integers(-2, mesh.n_cells, size=300_001).astype(np.int32))
+    c = np.concatenate([c, rng.integers(0, mesh.n_cells, size=7777).astype(np.int32)])   # sorted body + unsorted tail
+    w = torch.empty(mesh.n_cells, dtype=torch.float64, device=dev)
+    ctx.cell_histogram_dev(torch.from_numpy(c).to(dev).data_ptr(), c.size, 2.0, w.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy(), 2.0 * np.bincount(c[c >= 0], minlength=mesh.n_cells))
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8, 16])
+def test_cell_ranges_kernel_matches_host_rule(setup, n_ranks):
+    """Equal-weight cuts on the device == parallel.slab_cell_ranges on integer-valued weights (exact prefix
+    sums), including empty cells, an empty cloud and all the weight in one cell."""
+    import torch
+    from cudaparticlesfoam_amd.parallel import slab_cell_ranges
+    mesh, ctx = setup["mesh"], setup["ctx"]
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(n_ranks)
+    cases = [rng.integers(0, 2000, size=mesh.n_cells).astype(np.float64),
+             (rng.integers(0, 50, size=mesh.n_cells) * (rng.random(mesh.n_cells) < 0.05)).astype(np.float64),
+             np.zeros(mesh.n_cells), np.eye(1, mesh.n_cells, 4321)[0] * 9.0]
+    lo = torch.full((n_ranks + 1,), -7, dtype=torch.int32, device=dev)
+    for w in cases:
+        ctx.cell_ranges_dev(torch.from_numpy(w).to(dev).data_ptr(), n_ranks, lo.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(lo.cpu().numpy(), slab_cell_ranges(w, n_ranks))
+    ctx.use_own_stream()
+
+
+def test_deferred_handoff_catch_up_is_bit_exact(setup, gpu_ctx_factory):
+    """The overlapped hand-off on one GPU, without a process group: split the cloud as rank 0 of 2, keep stepping
+    the OLD range for 3 cycles (the stale tail must be inert), then append the 'arrivals' (the send buffer itself)
+    and let them replay the 3 cycles in one fused launch.  With Brownian motion on, every particle must end
+    exactly where plain stepping puts it: the (gid, step) Philox streams make the replay order-independent."""
+    import torch
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges
+    pz, mesh, cw, t = setup["pz"], setup["mesh"], setup["cw"], setup["tables"]
+    U = setup["pitz"]["U_analytic"]
+    dev = torch.device("cuda", 0)
+    ctx = gpu_ctx_factory(); ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_seed(99)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 150_000
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=5)
+    x, y, z = (xyz[:, k].copy() for k in range(3))
+    c = cw.locate_initial(x, y, z, t)
+    gid = np.arange(n, dtype=np.int64) + 10
+    cell_lo = slab_cell_ranges(setup["pitz"]["vols"], 2)
+    cloud = ShardedCloud(HipOps(ctx), cell_lo, n + 8, dev, rank=0, world=2, send_fraction=1.0)
+    cloud.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), torch.from_numpy(c).to(dev),
+                        torch.from_numpy(gid).to(dev))
+    dt, D = 1e-4, 1e-6
+    cloud.ops.step(cloud, dt, D, 0, 2, 0)                                   # steps 0, 1
+    cloud.ops.pack(cloud)                                                   # split after step 1
+    counts = cloud.counts_dev[:2].cpu().tolist(); n_stay = int(cloud.nstay_dev.item())
+    assert counts[0] == 0 and counts[1] > 1000 and n_stay + counts[1] == n
+    assert bool((cloud.cell[n_stay:n] == L.CELL_LOST).all())                # stale tail marked inert
+    cloud.ops.step(cloud, dt, D, 2, 3, 0)                                   # steps 2, 3, 4 on the OLD range
+    cloud.ops.unpack(cloud, n_stay, cloud.sendbuf, counts[1])               # arrivals = what was sent
+    cloud.ops.step_slice(cloud, n_stay, counts[1], dt, D, 2, 3, 0)          # they replay steps 2..4
+    torch.cuda.synchronize()
+    g, gx, gy, gz, gc = cloud.gather_to_numpy()
+    # the answer: the same kernel stepping the undisturbed cloud 5 cycles (device log/cos differ from libm in the
+    # last bits, so the Brownian term is compared GPU to GPU; the D = 0 walk is pinned to the oracle elsewhere)
+    plain = ShardedCloud(HipOps(ctx), [0, mesh.n_cells], n, dev)
+    plain.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), torch.from_numpy(c).to(dev),
+                        torch.from_numpy(gid).to(dev))
+    plain.ops.step(plain, dt, D, 0, 5, 0)
+    torch.cuda.synchronize()
+    _, px, py, pz_, pc = plain.gather_to_numpy()
+    o = g - 10
+    assert np.array_equal(np.sort(o), np.arange(n))
+    assert np.array_equal(gx, px[o]) and np.array_equal(gy, py[o]) and np.array_equal(gz, pz_[o])
+    assert np.array_equal(gc, pc[o])
+    moved = np.abs(px - x).max()
+    assert moved > 1e-4                                                       # and the cloud did move
+
+
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_sharded_cloud_one_rank_rccl_group(setup, gpu_ctx_factory, tmp_path, overlap):
+    """The N>1 host path (histogram -> all-reduce -> device re-cut -> pack -> all-gather of counts -> all-to-all-v
+    -> unpack) on ONE GPU with a real one-rank RCCL group: particle results must not depend on it."""
+    import torch
+    import torch.distributed as dist
+    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+    pz, mesh, cw, t = setup["pz"], setup["mesh"], setup["cw"], setup["tables"]
+    U = setup["pitz"]["U_analytic"]
+    dev = torch.device("cuda", 0)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1,
+                                device_id=dev)
+        created = True
+    try:
+        ctx = gpu_ctx_factory()
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(U)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        n = 200_000
+        xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=77)
+        x, y, z = (xyz[:, k].copy() for k in range(3))
+        c = cw.locate_initial(x, y, z, t)
+        cloud = ShardedCloud(HipOps(ctx), [0, mesh.n_cells], n + 64, dev, 0, 1, send_fraction=1.0, exchange_interval=0)
+        cloud.force_collectives = True
+        cloud.rebalance_interval = 3
+        cloud.sort_interval = 4
+        cloud.overlap_steps = overlap                   # side-stream counts + all-to-all while the loop runs on
+        cloud.enable_time_balancing()
+        cloud.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), None,
+                            torch.arange(n, dtype=torch.int64, device=dev))
+        cloud.step(1e-4, 10)
+        torch.cuda.synchronize()
+        assert cloud.rebalances == 3 and cloud.n == n and list(cloud.cell_lo) == [0, mesh.n_cells]
+        g, gx, gy, gz, gc = cloud.gather_to_numpy()
+        cw.step(x, y, z, c, 1e-4, 10, t, U)
+        assert np.array_equal(np.sort(g), np.arange(n))
+        assert np.array_equal(gx, x[g]) and np.array_equal(gy, y[g]) and np.array_equal(gz, z[g])
+        assert np.array_equal(gc, c[g])
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_full_size_properties(setup, gpu_ctx_factory):
     """BASELINE.json's full size (1e7 particles, pitzDaily) through size-independent properties: particle
     count conserved, every active particle lies inside the cell it claims (all plane distances <= 1e-9 on a

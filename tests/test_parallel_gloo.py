@@ -33,15 +33,37 @@ def _single_process_answer(oracle_libs):
     return x, y, z, c
 
 
-@pytest.mark.parametrize("world,interval,rebalance", [(2, 1, 0), (2, 4, 0), (3, 1, 0), (2, 4, 10)])
-def test_sharded_equals_single_process(world, interval, rebalance, tmp_path, oracle_libs):
-    out = str(tmp_path / "shard")
+def _run_workers(world, out, *args):
     env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(HERE, "_gloo_worker.py"), out, str(interval), str(rebalance)]
+           os.path.join(HERE, "_gloo_worker.py"), out] + [str(a) for a in args]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_libs):
+    """Re-cut by measured cost: rank 0 pretends to be 3x slower per particle, so the cuts must converge towards
+    3*n0 == n1 (n0 -> N/4) instead of n0 == n1; the particle results stay those of one process."""
+    out = str(tmp_path / "tb")
+    _run_workers(2, out, 0, 5, 3.0)
+    x, y, z, c = _single_process_answer(oracle_libs)
+    ds = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    for d in ds:
+        g = d["gid"]
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g]) and bool(d["owned_ok2"])
+    n0, n1 = int(ds[0]["n_local"]), int(ds[1]["n_local"])
+    assert n0 + n1 == 6000 and 0.15 * 6000 < n0 < 0.36 * 6000, (n0, n1)
+
+
+@pytest.mark.parametrize("world,interval,rebalance,overlap", [(2, 1, 0, 0), (2, 4, 0, 0), (3, 1, 0, 0), (2, 4, 10, 0),
+                                                             (3, 0, 5, 0), (2, 0, 5, 3), (3, 4, 0, 4), (2, 0, 6, 10)])
+def test_sharded_equals_single_process(world, interval, rebalance, overlap, tmp_path, oracle_libs):
+    """overlap > 0: the step loop keeps running for that many cycles after the split while counts and payload
+    travel; the arrivals then replay the cycles they missed (same per-particle Philox stream, same result)."""
+    out = str(tmp_path / "shard")
+    _run_workers(world, out, interval, rebalance, 0, overlap)
     x, y, z, c = _single_process_answer(oracle_libs)
     seen = np.zeros(6000, bool)
     handed = 0
@@ -56,8 +78,25 @@ def test_sharded_equals_single_process(world, interval, rebalance, tmp_path, ora
         assert np.array_equal(d["cell"], c[g])
         handed += int(d["handed"])
     assert seen.all() and handed > 0
-    if rebalance:
+    if rebalance and 30 % rebalance == 0:
         ds = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
-        assert all(int(d["rebalances"]) == 3 for d in ds)
-        counts = [int(d["n_local"]) for d in ds]
-        assert max(counts) - min(counts) <= 0.1 * 6000        # equal-count cuts (cell granularity)
+        assert all(int(d["rebalances"]) == 30 // rebalance for d in ds)
+        # the last re-cut happened after the last step: the ranges must be THE equal-count cuts of the final
+        # global per-cell histogram (cell granularity: a cell is never split), identical on every rank
+        from cudaparticlesfoam_amd.parallel import slab_cell_ranges
+        hist = np.bincount(c[c >= 0], minlength=240).astype(np.float64)
+        want = slab_cell_ranges(hist, world)
+        assert all(np.array_equal(d["cell_lo"], want) for d in ds)
+        assert [int(d["n_local"]) for d in ds] == [int(((c >= want[r]) & (c < want[r + 1])).sum()) for r in range(world)]
+
+def test_device_cell_ranges_match_host_rule():
+    """The on-device re-cut (cumsum + searchsorted in torch) applies the same rule as slab_cell_ranges."""
+    import torch
+    from cudaparticlesfoam_amd.parallel import device_cell_ranges, slab_cell_ranges
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n = int(rng.integers(1, 400)); w = int(rng.integers(1, 9))
+        h = rng.integers(0, 6, size=n) * (rng.random(n) < rng.random())
+        a = slab_cell_ranges(h.astype(np.float64), w)
+        b = device_cell_ranges(torch.from_numpy(h.astype(np.int64)), w).numpy()
+        assert b.dtype == np.int32 and np.array_equal(a, b)

@@ -33,11 +33,22 @@ def t(f, reps=5):
 
 print("pack kernels only      %.3f ms" % t(lambda: cloud.ops.pack(cloud)))
 print("pack + counts .cpu()   %.3f ms" % t(lambda: (cloud.ops.pack(cloud), torch.cat([cloud.counts_dev[:1], cloud.nstay_dev]).cpu())))
+cloud.weights_dev = torch.zeros(mesh.n_cells, dtype=torch.float64, device=dev)
+print("histogram (unsorted)   %.3f ms" % t(lambda: cloud.ops.histogram(cloud, 1.0)))
+cloud.sort()
+print("histogram (sorted)     %.3f ms" % t(lambda: cloud.ops.histogram(cloud, 1.0)))
+print("all_reduce weights     %.3f ms" % t(lambda: dist.all_reduce(cloud.weights_dev)))
+print("cell_ranges kernel     %.3f ms" % t(lambda: cloud.ops.cell_ranges(cloud)))
+meta = torch.cat([cloud.counts_dev[:1], cloud.nstay_dev]); rows = [torch.empty_like(meta)]
+print("all_gather counts      %.3f ms" % t(lambda: dist.all_gather(rows, meta)))
+print("unpack (0 arrivals)    %.3f ms" % t(lambda: cloud.ops.unpack(cloud, cloud.n, cloud.recvbuf, 0)))
 sc = torch.tensor([0], dtype=torch.int64, device=dev); rc = torch.empty_like(sc)
 print("a2a counts             %.3f ms" % t(lambda: dist.all_to_all_single(rc, sc)))
 print("a2a counts + .cpu()    %.3f ms" % t(lambda: (dist.all_to_all_single(rc, sc), rc.cpu())))
 print("full exchange()        %.3f ms" % t(cloud.exchange))
 print("full rebalance()       %.3f ms" % t(lambda: cloud.rebalance(mesh.n_cells)))
+cloud.enable_time_balancing()
+print("rebalance(), by time   %.3f ms" % t(lambda: cloud.rebalance(mesh.n_cells)))
 print("sort()                 %.3f ms" % t(cloud.sort))
 print("step                   %.3f ms" % t(lambda: cloud.ops.step(cloud, 1e-4, 0.0, 0, 1, 0)))
 dist.destroy_process_group()
