@@ -176,6 +176,7 @@ class ShardedCloud:
         self.handed_off = 0          # cumulative particles sent away by this rank
         self.exchanges = 0
         self.rebalances = 0
+        self.grown = 0               # times the arrays had to be enlarged for arrivals
         self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
         self.sort_interval = 0       # 0 = never; else re-sort by cell every that many steps (coalescing)
         self.force_collectives = False   # run the hand-off path even with one rank (single-GPU smoke of the N>1 code)
@@ -221,6 +222,21 @@ class ShardedCloud:
                     self._begin_exchange()
         if self.overlap_steps == 0:
             self._finish_exchange()
+
+    def _grow(self, needed: int, n_keep: int):
+        """More arrivals than slack: move the shard into larger arrays (HBM is plentiful; on the compute stream,
+        so it is ordered after the steps in flight)."""
+        cap = max(int(needed), int(self.capacity * 1.5)) + 4096
+        for name in ("x", "y", "z", "cell", "gid"):
+            old = getattr(self, name)
+            new = torch.empty(cap, dtype=old.dtype, device=self.device)
+            new[:n_keep].copy_(old[:n_keep])
+            setattr(self, name, new)
+        if self.send_capacity >= self.capacity:                       # "a send buffer as large as the shard" stays so
+            self.send_capacity = cap
+            self.sendbuf = torch.empty(cap * L.HANDOFF_DOUBLES, dtype=torch.float64, device=self.device)
+        self.capacity = cap
+        self.grown += 1
 
     def flush(self):
         """Completes a hand-off still in flight (arrivals appended and caught up)."""
@@ -273,10 +289,10 @@ class ShardedCloud:
             n_send, n_recv = sum(send_counts), sum(recv_counts)
             if n_send > self.send_capacity:
                 raise RuntimeError("hand-off buffer overflow: %d leavers > capacity %d" % (n_send, self.send_capacity))
-            if n_stay + n_recv > self.capacity:
-                raise RuntimeError("shard overflow: %d + %d arrivals > capacity %d" % (n_stay, n_recv, self.capacity))
             if n_recv * D > self.recvbuf.numel():
                 self.recvbuf = torch.empty(n_recv * D, dtype=torch.float64, device=self.device)
+                if self._side is not None:
+                    self.recvbuf.record_stream(torch.cuda.current_stream(self.device))   # unpack reads it there
             dist.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
                                    [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
             if self._side is not None:
@@ -286,6 +302,8 @@ class ShardedCloud:
             torch.cuda.current_stream(self.device).wait_event(done)   # also orders the next pack after this all-to-all
         missed = self.step_index - p["step"]
         self.particle_steps -= (self.n - n_stay) * missed             # the inactive tail was not real work
+        if n_stay + n_recv > self.capacity:
+            self._grow(n_stay + n_recv, n_stay)
         self.ops.unpack(self, n_stay, self.recvbuf, n_recv)
         if missed and n_recv:
             dt, Dc, flags = self._step_args
@@ -342,7 +360,8 @@ class ShardedCloud:
         launches, ms = self.ops.step_time(self, wait=first)
         self.kernel_ms += ms; self.kernel_launches += launches
         if launches > 0 and self.n > 0:
-            cost = ms / launches / self.n / COST_UNIT_MS
+            # clamped: one rank's bad measurement must not pull most of the cloud onto another rank
+            cost = min(4.0, max(0.25, ms / launches / self.n / COST_UNIT_MS))
             self.cost_per_particle = cost if first else 0.5 * (self.cost_per_particle + cost)
         return 1.0 if self.cost_per_particle is None else self.cost_per_particle
 

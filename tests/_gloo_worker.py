@@ -19,6 +19,7 @@ def main():
     out_path, interval = sys.argv[1], int(sys.argv[2])
     rebalance = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 0               # steps the loop runs on while a hand-off is in flight
+    capacity = int(sys.argv[6]) if len(sys.argv) > 6 else 0              # 0: room for the whole cloud on every rank
     slow_rank0 = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # > 0: balance by "measured" time, rank 0 that much slower
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -35,7 +36,7 @@ def main():
     # every rank starts with an arbitrary slice of the cloud (NOT its own slab): first exchange fixes that
     mine = np.arange(rank, n_total, world)
     ops = FakeOps(cw, t, U, 2.0e-8 * (slow_rank0 if (slow_rank0 and rank == 0) else 1.0))
-    cloud = ShardedCloud(ops, cell_lo, n_total + 16, torch.device("cpu"), rank, world,
+    cloud = ShardedCloud(ops, cell_lo, capacity or (n_total + 16), torch.device("cpu"), rank, world,
                          send_fraction=1.0, exchange_interval=interval)
     cloud.set_particles(torch.from_numpy(xyz[mine, 0].copy()), torch.from_numpy(xyz[mine, 1].copy()),
                         torch.from_numpy(xyz[mine, 2].copy()), None, torch.from_numpy(mine.astype(np.int64)))
@@ -57,7 +58,7 @@ def main():
     owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
-             n_local=cloud.n, cell_lo=np.asarray(cell_lo))
+             n_local=cloud.n, grown=cloud.grown, cell_lo=np.asarray(cell_lo))
     dist.barrier()
     dist.destroy_process_group()
 

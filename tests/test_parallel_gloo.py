@@ -42,6 +42,21 @@ def _run_workers(world, out, *args):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_shard_grows_when_arrivals_exceed_its_slack(tmp_path, oracle_libs):
+    """Capacity just above the initial share: the drifting cloud piles up on the downstream rank, whose arrays
+    must be enlarged in flight (overlapped hand-off on) without losing or corrupting a particle."""
+    out = str(tmp_path / "grow")
+    _run_workers(2, out, 2, 0, 0, 1, 3050)                  # fixed ranges, hand-off every 2 steps, 1 overlapped
+    x, y, z, c = _single_process_answer(oracle_libs)
+    ds = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    assert sum(int(d["grown"]) for d in ds) >= 1
+    assert sum(int(d["n_local"]) for d in ds) == 6000
+    for d in ds:
+        g = d["gid"]
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g])
+
+
 def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_libs):
     """Re-cut by measured cost: rank 0 pretends to be 3x slower per particle, so the cuts must converge towards
     3*n0 == n1 (n0 -> N/4) instead of n0 == n1; the particle results stay those of one process."""
