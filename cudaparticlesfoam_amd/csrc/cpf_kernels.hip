@@ -143,7 +143,7 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
-    double dTmin = 1.1;
+    double dTmin = 2.0;                 // any start value > 1 is equivalent (candidates have dT <= 1); 2.0 is an inline constant
     const int2* nb = reinterpret_cast<const int2*>(rec + 7);
     {
         const double4 p0 = rec[0], p1 = rec[1];
@@ -356,11 +356,12 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
     // Per-lane end point E and last wall hit point, parked in LDS between rounds (SoA: conflict-free).  Neither is
     // needed while the six planes are tested, and the kernel's speed is set by waves per SIMD: 12 VGPRs less
     // is one more resident wave.  A lane only ever reads back what it wrote itself, so no barrier is involved.
-    __shared__ double sE[3][kCoopBlock];
-    __shared__ double sHit[3][kCoopBlock];
+    __shared__ double sLane[6][kCoopBlock];            // one array: one address register + immediate offsets
+    double(*sE)[kCoopBlock] = sLane;
+    double(*sHit)[kCoopBlock] = sLane + 3;
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
-    double4(*slots)[8] = sRec[threadIdx.x >> 6];
+    double4(*slots)[8] = sRec[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];   // wave-uniform: lives in SGPRs
     const int64_t i = (int64_t)blockIdx.x * kCoopBlock + threadIdx.x;
     int cur = (i < n) ? cell[i] : CPF_CELL_FROZEN;
     const bool wasLost = cur == CPF_CELL_LOST;
@@ -397,7 +398,9 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
             const int g = lane >> 4;
             const int cg = g == 0 ? c0 : (g == 1 ? c1 : (g == 2 ? c2 : c3));
             if (cg >= 0) {
-                const double2 val = reinterpret_cast<const double2*>(m.cellRec + 8 * (int64_t)cg)[lane & 15];
+                // scalar base + 32-bit lane offset (records of up to 2^24 cells): no 64-bit address kept per lane
+                const unsigned off = (unsigned)cg * 256u + (unsigned)(lane & 15) * 16u;
+                const double2 val = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(m.cellRec) + off);
                 reinterpret_cast<double2*>(slots[g])[lane & 15] = val;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -423,11 +426,7 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;
                     }
-#ifdef CPF_EXP_SINGLE
-                    next = trace_fixed<6, true>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
-#else
                     next = trace_lds6(S, E, cur, rec, token, outSlot);
-#endif
                     wallPlane = rec[outSlot];
                 } else {
                     const double4* rec = m.cellRec + 8 * (int64_t)cur;
