@@ -50,7 +50,6 @@ def parse():
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-sort", action="store_true")
-    ap.add_argument("--sort-key", type=int, default=None, help="cpf_set_option sort_key (developer sweeps)")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
     return ap.parse_args()
 
@@ -187,8 +186,6 @@ def main():
     if (world > 1 or args.force_dist) and args.balance == "time":
         cloud.enable_time_balancing()
     cloud.sort_interval = 0 if args.no_sort else args.sort_interval
-    if args.sort_key is not None:
-        ctx.set_option("sort_key", args.sort_key)
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
     if world > 1 or args.force_dist:

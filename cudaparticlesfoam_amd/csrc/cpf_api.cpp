@@ -47,7 +47,6 @@ struct cpf_context {
     unsigned long long* d_counters = nullptr;
     uint32_t seed = 1591593751u;                // cuda/particles.cu:544
     uint32_t stepCounter = 0;
-    int sortKey = 0;                            // "sort_key": sub-cell part of the sort key (0 box 4x4x4, 1 along U)
     int sortInterval = 50;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
     uint32_t lastSortStep = 0;
     bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
@@ -113,7 +112,7 @@ int ensureScratch(cpf_context* ctx, size_t bytes) {
 int sortEndBit(const cpf_context* ctx) {
     int bits = 1;
     while (((int64_t)1 << bits) < ctx->host.nCells + 2) ++bits;   // the all-ones key of lost/frozen sorts last
-    return std::min(bits + cpf::sort_sub_bits(ctx->sortKey), 32);  // + the sub-cell bits of the key mode
+    return std::min(bits + ctx->host.subBits[0] + ctx->host.subBits[1] + ctx->host.subBits[2], 32);  // + sub-cell bits
 }
 
 void freeMesh(cpf_context* c) {
@@ -447,7 +446,8 @@ int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int3
     int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
     if (r) return r;
     CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, x == ctx->x ? ctx->vel : nullptr, n, endBit,
-                                   ctx->d_cellBox, ctx->d_U, ctx->sortKey, ctx->scratch, ctx->scratchBytes));
+                                   ctx->d_cellBox, ctx->host.subBits, ctx->host.subOrder, ctx->scratch,
+                                   ctx->scratchBytes));
     return CPF_OK;
 }
 
@@ -509,11 +509,6 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     if (k == "sort_interval") {
         CPF_REQUIRE(ctx, value >= 0 && value <= 1e9, CPF_ERR_ARG, "sort_interval must be >= 0 (0 = never)");
         ctx->sortInterval = (int)value;
-        return CPF_OK;
-    }
-    if (k == "sort_key") {
-        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "sort_key must be 0 (cell box 4x4x4) or 1 (along the cell velocity)");
-        ctx->sortKey = (int)value;
         return CPF_OK;
     }
     if (k == "stats") {

@@ -62,9 +62,8 @@ hipError_t launch_soa_to_aos(hipStream_t st, const double* x, const double* y, c
 
 size_t sort_scratch_bytes(int64_t n, int endBit);
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
-                        int64_t n, int endBit, const float* cellBox, const double4* U, int mode, void* scratch,
-                        size_t scratchBytes);
-int sort_sub_bits(int mode);
+                        int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
+                        void* scratch, size_t scratchBytes);
 
 // multi-GPU hand-off (cpf_handoff.hip)
 size_t handoff_scratch_bytes(int64_t n, int nRanks);

@@ -18,7 +18,10 @@ struct HostTables {
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
     int32_t maxCellFaces = 0, minCellFaces = 0;
-    std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 4/extent per axis (sub-cell sort key)
+    std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
+    // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes
+    // from most to least significant (the longest domain axis first)
+    int32_t subBits[3] = {2, 2, 2}, subOrder[3] = {0, 1, 2};
 };
 
 // polyMesh -> HostTables.  Returns empty string on success, else the reason (CPF_ERR_MESH).

@@ -429,6 +429,9 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                     next = trace_lds6(S, E, cur, rec, token, outSlot);
                     wallPlane = rec[outSlot];
                 } else {
+                    // no slot: more than kCoopSlots distinct cells in the wave (a cloud that is not kept sorted).
+                    // Per-lane gathers keep such a wave moving; letting these lanes wait for a free slot instead
+                    // measured 1.7x slower on an unsorted cloud and no faster on a sorted one.
                     const double4* rec = m.cellRec + 8 * (int64_t)cur;
                     if (needAdvect) {
                         const double4 u = rec[6];
@@ -922,42 +925,30 @@ hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n,
 // sort by cell: radix sort (cell, index) pairs on the low bits only, then gather every array.
 // Stable and deterministic, so the order of particles is reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-// Sort key = (cell, sub-cell position): particles that share a wave then also share a neighbourhood INSIDE the
-// cell, so they cross the same faces in the same round.
-//   mode 0: position in the cell's bounding box quantised 4 x 4 x 4 (6 bits; rounds per wave on the bench cloud
-//           2.68 -> 2.31 against sorting by cell alone)
-//   mode 1: position ALONG THE CELL'S VELOCITY, 256 bins over the box's extent in that direction (8 bits): how many
-//           faces a particle crosses this step is, to first order, a function of its distance to the downstream
-//           faces, so a wave of equal-distance particles finishes its rounds together
-constexpr int kSubBitsBox = 6, kSubBitsAlongU = 8;
+// Sort key = (cell, position inside the cell's bounding box quantised per axis): particles that share a wave then
+// also share a neighbourhood INSIDE the cell, so they cross the same faces in the same round.  The bit layout
+// (bits per axis, axis significance) is chosen at mesh ingest (cpf_mesh.cpp): 4 x 4 x 4 for 3-D meshes, 4 x 32 for
+// a 2-D case like pitzDaily.  Measured on the bench cloud: rounds per wave 2.68 (cell only) -> 2.31 -> 2.23.
+struct SubKey { int bits[3]; int order[3]; };
 __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                  const double* __restrict__ z, const int32_t* __restrict__ cell,
-                                 const float* __restrict__ cellBox, const double4* __restrict__ U, int mode,
+                                 const float* __restrict__ cellBox, SubKey sk, int subBits,
                                  uint32_t* __restrict__ keys, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int32_t c = cell[i];
     if (c < 0) { keys[i] = 0xFFFFFFFFu; return; }            // lost / frozen particles go to the tail
-    const float* b = cellBox + 6 * (int64_t)c;              // lo.xyz, 4 / extent.xyz
-    const float rx = ((float)x[i] - b[0]) * b[3], ry = ((float)y[i] - b[1]) * b[4], rz = ((float)z[i] - b[2]) * b[5];
-    if (mode == 1) {
-        // rx,ry,rz in [0,4): box-relative coordinates.  Project on the velocity expressed in the same
-        // coordinates (u_k * 4/extent_k); the projection of the box spans [sum of negative w_k, sum of positive] * 4.
-        const double4 u = U[c];
-        float wx = (float)u.x * b[3], wy = (float)u.y * b[4], wz = (float)u.z * b[5];
-        if (wx == 0.f && wy == 0.f && wz == 0.f) wx = 1.f;                       // fluid at rest: any fixed axis
-        const float lo = 4.f * (fminf(wx, 0.f) + fminf(wy, 0.f) + fminf(wz, 0.f));
-        const float hi = 4.f * (fmaxf(wx, 0.f) + fmaxf(wy, 0.f) + fmaxf(wz, 0.f));
-        const float t = (rx * wx + ry * wy + rz * wz - lo) / (hi - lo);
-        const int bin = min(255, max(0, (int)(t * 256.f)));
-        keys[i] = ((uint32_t)c << kSubBitsAlongU) | (uint32_t)bin;
-        return;
+    const float* b = cellBox + 6 * (int64_t)c;              // lo.xyz, 2^bits / extent.xyz
+    const float r[3] = {((float)x[i] - b[0]) * b[3], ((float)y[i] - b[1]) * b[4], ((float)z[i] - b[2]) * b[5]};
+    uint32_t sub = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = sk.order[k];
+        const int q = min((1 << sk.bits[a]) - 1, max(0, (int)(a == 0 ? r[0] : (a == 1 ? r[1] : r[2]))));
+        sub = (sub << sk.bits[a]) | (uint32_t)q;
     }
-    const int ux = min(3, max(0, (int)rx)), uy = min(3, max(0, (int)ry)), uz = min(3, max(0, (int)rz));
-    keys[i] = ((uint32_t)c << kSubBitsBox) | (uint32_t)((ux << 4) | (uy << 2) | uz);
+    keys[i] = ((uint32_t)c << subBits) | sub;
 }
-
-int sort_sub_bits(int mode) { return mode == 1 ? kSubBitsAlongU : kSubBitsBox; }
 
 size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
@@ -969,9 +960,12 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
 }
 
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
-                        int64_t n, int endBit, const float* cellBox, const double4* U, int mode, void* scratch,
-                        size_t scratchBytes) {
+                        int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
+                        void* scratch, size_t scratchBytes) {
     if (n <= 1) return hipSuccess;
+    SubKey sk;
+    for (int k = 0; k < 3; ++k) { sk.bits[k] = subBits[k]; sk.order[k] = subOrder[k]; }
+    const int nSub = subBits[0] + subBits[1] + subBits[2];
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t tmpBytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
@@ -985,7 +979,7 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     double* stage = (double*)p; p += al(24 * (size_t)n);
     if ((size_t)(p - (char*)scratch) > scratchBytes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(kBlock), 0, st, idx, n);
-    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, U, mode, keysIn, n);
+    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, sk, nSub, keysIn, n);
     // endBit covers the cell bits + sub-cell bits; the all-ones key of lost/frozen particles sorts last
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keysIn, keysOut, idx, perm, (int)n, 0, endBit, st);
     if (e != hipSuccess) return e;

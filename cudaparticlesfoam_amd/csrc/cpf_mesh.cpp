@@ -119,15 +119,6 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
-    // ---- per-cell boxes for the sort key (cell, 4x4x4 position inside the cell's box)
-    out.cellBox.resize((size_t)nCells * 6);
-    for (int64_t c = 0; c < nCells; ++c)
-        for (int k = 0; k < 3; ++k) {
-            const double e = bmax[3 * c + k] - bmin[3 * c + k];
-            out.cellBox[6 * c + k] = (float)bmin[3 * c + k];
-            out.cellBox[6 * c + 3 + k] = e > 0.0 ? (float)(4.0 / e) : 0.0f;
-        }
-
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)
     for (int k = 0; k < 3; ++k) { out.lo[k] = 1e300; out.hi[k] = -1e300; }
     for (int64_t p = 0; p < nPoints; ++p)
@@ -135,6 +126,40 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
             out.lo[k] = std::min(out.lo[k], points[3 * p + k]);
             out.hi[k] = std::max(out.hi[k], points[3 * p + k]);
         }
+    // ---- per-cell boxes + bit layout of the sub-cell sort key.  The key groups particles that sit close together
+    // INSIDE a cell so that the lanes of a wave cross the same faces in the same round.  An axis in which the mesh
+    // is one cell thick (2-D cases extruded in z) gets no bits; with two axes left the longest domain axis (the
+    // main flow direction of a channel) gets 2 bits and leads, the transverse one gets 5: measured rounds per wave
+    // on the pitzDaily bench cloud 2.31 (4x4x4) -> 2.23 (4x32x1); three axes keep 4x4x4.
+    {
+        bool thin[3];
+        int order[3] = {0, 1, 2};
+        double dext[3];
+        for (int k = 0; k < 3; ++k) {
+            dext[k] = out.hi[k] - out.lo[k];
+            thin[k] = true;
+            for (int64_t c = 0; c < nCells && thin[k]; ++c)
+                if (bmax[3 * c + k] - bmin[3 * c + k] < 0.999 * dext[k]) thin[k] = false;
+        }
+        std::sort(order, order + 3, [&](int a, int b) {
+            if (thin[a] != thin[b]) return !thin[a];
+            return dext[a] > dext[b] || (dext[a] == dext[b] && a < b);
+        });
+        const int nThick = (thin[0] ? 0 : 1) + (thin[1] ? 0 : 1) + (thin[2] ? 0 : 1);
+        for (int r = 0; r < 3; ++r) {
+            const int k = order[r];
+            out.subOrder[r] = k;
+            out.subBits[k] = thin[k] ? 0 : (nThick == 3 ? 2 : (nThick == 2 ? (r == 0 ? 2 : 5) : 7));
+        }
+        out.cellBox.resize((size_t)nCells * 6);
+        for (int64_t c = 0; c < nCells; ++c)
+            for (int k = 0; k < 3; ++k) {
+                const double e = bmax[3 * c + k] - bmin[3 * c + k];
+                out.cellBox[6 * c + k] = (float)bmin[3 * c + k];
+                out.cellBox[6 * c + 3 + k] = e > 0.0 ? (float)((double)(1 << out.subBits[k]) / e) : 0.0f;
+            }
+    }
+
     double ext[3], vol = 1.0, diag = 0.0;
     for (int k = 0; k < 3; ++k) {
         ext[k] = out.hi[k] - out.lo[k];

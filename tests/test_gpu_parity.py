@@ -735,7 +735,8 @@ def test_random_sheared_meshes_bit_exact(seed, oracle_libs, gpu_ctx_factory):
 
 def test_sort_orders_by_cell_then_position(setup):
     """cpf_sort_by_cell_dev: cells non-decreasing (lost/frozen at the tail), a permutation (ids intact), and inside
-    one cell the particles come in sub-box order (4 x 4 x 4 bins of the cell's bounding box)."""
+    one cell the particles come in sub-box order.  pitzDaily is one cell thick in z and longest in x, so the key
+    layout chosen at mesh ingest is 4 bins in x (leading) x 32 bins in y, none in z."""
     import torch
     pz, ctx, mesh = setup["pz"], setup["ctx"], setup["mesh"]
     dev = torch.device("cuda", 0)
@@ -762,8 +763,10 @@ def test_sort_orders_by_cell_then_position(setup):
     off, cf = mesh.cell_faces(); fo = mesh.face_offsets
     vid = np.unique(np.concatenate([mesh.face_verts[fo[f]:fo[f + 1]] for f in cf[off[big]:off[big + 1]]]))
     lo, hi = mesh.points[vid].min(0), mesh.points[vid].max(0)
-    u = np.clip(((pts.astype(np.float32) - lo.astype(np.float32)) * (4.0 / (hi - lo)).astype(np.float32)).astype(np.int64), 0, 3)
-    sub = (u[:, 0] << 4) | (u[:, 1] << 2) | u[:, 2]
+    nb = np.array([4.0, 32.0, 1.0])
+    u = ((pts.astype(np.float32) - lo.astype(np.float32)) * (nb / (hi - lo)).astype(np.float32)).astype(np.int64)
+    u = np.clip(u, 0, nb.astype(np.int64) - 1)
+    sub = (u[:, 0] << 5) | u[:, 1]
     assert (np.diff(sub) >= 0).mean() > 0.999                                   # fp32 bin edges: allow a stray particle
     ctx.use_own_stream()
 
