@@ -46,6 +46,8 @@ def parse():
                     help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
     ap.add_argument("--overlap-steps", type=int, default=4,
                     help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight")
+    ap.add_argument("--fused-extra", type=int, default=0,
+                    help="after the timed region, also time this many launches of 8 fused cycles (extra field; 0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -230,6 +232,26 @@ def main():
     el = float(t.item())
     n_after = cloud.global_count()
 
+    # Outside the timed region, single GPU only: the same cloud stepped with 8 cycles fused into one launch
+    # (CPF_STEP_FUSE_CYCLES: what the replacement advect.H does between two output points; results identical,
+    # tests/test_gpu_parity.py).  Reported as an extra, never as `value`.
+    fused = None
+    if world == 1 and not args.force_dist and args.fused_extra > 0:
+        p = lambda a: a.data_ptr()   # noqa: E731
+        K = 8
+        ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
+                     cloud.step_index, K, L.STEP_FUSE_CYCLES)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for r in range(args.fused_extra):
+            ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
+                         cloud.step_index + K * (r + 1), K, L.STEP_FUSE_CYCLES)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        fused = {"cycles_per_launch": K, "launches": args.fused_extra,
+                 "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
+                 "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
+
     if rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
@@ -261,12 +283,13 @@ def main():
                        "particles_per_rank_at_end": per_rank if world > 1 else None,
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
                                                      if world > 1 else None),
+                       "extra_fused_cycles": fused,
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
                        "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "cpf::step_kernel_coop<false,true,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
+                         "kernel": "cpf::step_kernel_coop<false,true,false,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
                          "launches": launches, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PARTICLE_STEP * per_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:
