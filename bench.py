@@ -202,6 +202,7 @@ def main():
             dist.barrier()
 
     dt = 1e-4
+    ctx.set_option("stats", 1)
     cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
     torch.cuda.synchronize(); barrier()
     counters = ctx.counters()

@@ -49,7 +49,7 @@ struct cpf_context {
     uint32_t stepCounter = 0;
     int sortInterval = 50;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
     uint32_t lastSortStep = 0;
-    bool stats = true;                          // "stats": per-launch counters (steps, cells visited, reflections, lost)
+    bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h
     // timing
     bool timing = false;

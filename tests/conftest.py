@@ -45,6 +45,7 @@ def gpu_ctx_factory():
 
     def make():
         c = Context(0)
+        c.set_option("stats", 1)          # the parity tests also compare the visit / reflection counters
         made.append(c)
         return c
     yield make

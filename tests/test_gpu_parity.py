@@ -89,6 +89,38 @@ def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     ctx.set_option("step_variant", 3)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
+def test_production_instantiation_bit_exact(setup, field, fused):
+    """The kernel a host gets by default -- statistics OFF, the 7-waves-per-SIMD instantiation of the
+    wave-cooperative walk -- against the CPU statement, bit for bit (the fixture's contexts switch the
+    statistics on, which selects a different instantiation of the same source)."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
+    U = setup["pitz"][field]
+    n = 300_001
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=4242)
+    ctx.set_option("stats", 0)
+    try:
+        ctx.set_velocity(U)
+        ctx.set_particles(xyz)
+        ctx.locate_initial()
+        _, cell0 = ctx.get_particles()
+        ctx.sort_by_cell()
+        before = ctx.counters()
+        ctx.step(1e-4, 0.0, 40, L.STEP_FUSE_CYCLES if fused else 0)
+        xyzw, cell = ctx.get_particles()
+        assert ctx.counters() == before                                  # nothing was counted
+    finally:
+        ctx.set_option("stats", 1)
+    x, y, z = (xyz[:, k].copy() for k in range(3))
+    c = cell0.copy()
+    st = cw.step(x, y, z, c, 1e-4, 40, t, U, nthreads=cw.max_threads)
+    assert int(st[1]) > 1000                                             # reflections were exercised
+    assert np.array_equal(cell, c)
+    assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+
+
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
 def test_step_vs_reference_algorithm(setup, field, oracle_libs):
     """HIP cell walk vs the reference's tet walk on the 12-tets-per-cell decomposition."""
@@ -586,6 +618,7 @@ def test_tutorial_case_end_to_end(tmp_path, pitz):
         frames.append((frame, xyzw.copy(), cell.copy()))
 
     p = CudaParticles(pitz["mesh"], pitz["U_analytic"], d, writer=writer)
+    p.ctx.set_option("stats", 1)                                  # diagnostics are off by default
     assert p.outOfDomain == 0 and frames[0][0] == 0
     assert p.advect(100.0, 0.1) == 0                              # before startTime 282: gate closed (advect.H:33)
     assert p.advect(300.0, 0.1) == 1000
