@@ -129,9 +129,14 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
     const double den = dot3(p, Pd);
     if (ballot64(den != 0.0) == 0ull) return;          // see trace_fixed: nobody crosses this plane
     const double fd = plane_dist(p, P0);
-    const bool c1 = fabs(fd) <= fabs(den), c2 = (__double2hiint(fd) ^ __double2hiint(den)) >= 0;
+    // c2 only prunes divisions (a face the lane moves away from): "den < 0 or fd >= 0" holds whenever the exact
+    // condition "equal sign bits" can still lead to an accepted face, and whatever else slips through has a
+    // quotient <= 0 and fails dT > tol below, exactly as in the reference -- two compares instead of a 64-bit xor
+    // and an integer compare
+    const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
     const bool c3 = fd < kTol, c4 = bs != token;
-    if ((ballot64(c1) & ballot64(c2) & ballot64(c3) & __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
+    if ((ballot64(c1) & (ballot64(den < 0.0) | ballot64(fd >= 0.0)) & ballot64(c3) &
+         __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
         if (c1 && c2 && c3 && c4) {
             const double dT = fd / den;
             if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
@@ -381,16 +386,17 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
         if (STATS && busy) ++st.steps;
         while (ballot64(busy) != 0ull) {
             // ---- distinct cells of the busy lanes -> slots (wave-uniform scalars)
-            unsigned long long todo = ballot64(busy);
+            const unsigned long long busyMask = ballot64(busy);
+            unsigned long long todo = busyMask;
             int myslot = -1, c0 = -1, c1 = -1, c2 = -1, c3 = -1;
 #pragma unroll
             for (int k = 0; k < kCoopSlots; ++k) {
                 if (todo != 0ull) {
                     const int leader = __ffsll((long long)todo) - 1;
                     const int ck = __builtin_amdgcn_readlane(cur, leader);
-                    const bool mine = busy && cur == ck;
-                    if (mine) myslot = k;
-                    todo &= ~ballot64(mine);
+                    if (busy && cur == ck) myslot = k;
+                    // the compare mask itself, combined in the scalar unit (see ballot64)
+                    todo &= ~(__builtin_amdgcn_uicmp((unsigned)cur, (unsigned)ck, 32 /* eq */) & busyMask);
                     if (k == 0) c0 = ck; else if (k == 1) c1 = ck; else if (k == 2) c2 = ck; else c3 = ck;
                 }
             }
@@ -409,7 +415,6 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
             // ---- every busy lane does one cell visit
             if (busy) {
                 int next, outSlot = 0;
-                double4 wallPlane;
                 D3 E = S;
                 if (!needAdvect) E = {sE[0][tid], sE[1][tid], sE[2][tid]};
                 if (myslot >= 0) {
@@ -427,7 +432,6 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         needAdvect = false;
                     }
                     next = trace_lds6(S, E, cur, rec, token, outSlot);
-                    wallPlane = rec[outSlot];
                 } else {
                     // no slot: more than kCoopSlots distinct cells in the wave (a cloud that is not kept sorted).
                     // Per-lane gathers keep such a wave moving; letting these lanes wait for a free slot instead
@@ -444,7 +448,6 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         needAdvect = false;
                     }
                     next = trace_fixed<6, false>(S, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
-                    wallPlane = next < 0 ? rec[outSlot] : make_double4(0, 0, 0, 0);
                 }
                 if (STATS) ++st.hops;
                 if (next == cur) {
@@ -455,6 +458,10 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         // mirror end point and velocity about the wall (ConvexQuery.cu:286-309)
                         sHit[0][tid] = S.x; sHit[1][tid] = S.y; sHit[2][tid] = S.z;
                         reflected = true; if (STATS) ++st.refl;
+                        // the wall's plane is fetched here, by the few lanes that reflect: reading it after every
+                        // visit cost 2 KB of LDS return bandwidth per wave-round, and LDS bandwidth is what the
+                        // throughput-bound part of this kernel's time consists of
+                        const double4 wallPlane = myslot >= 0 ? slots[myslot][outSlot] : m.cellRec[8 * (int64_t)cur + outSlot];
                         const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
                         const double sd = dot3(wallPlane, E) - wallPlane.w;
                         E = axpy(-2.0 * sd, nn, E);
