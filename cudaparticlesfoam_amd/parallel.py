@@ -137,8 +137,11 @@ class ShardedCloud:
     """This rank's shard: SoA device arrays with slack capacity + hand-off buffers."""
 
     def __init__(self, ops, cell_lo: Sequence[int], capacity: int, device: torch.device, rank: int = 0,
-                 world: int = 1, group=None, send_fraction: float = 0.25, exchange_interval: int = 1):
+                 world: int = 1, group=None, send_fraction: float = 0.25, exchange_interval: int = 1, comm=None):
         self.ops, self.rank, self.world, self.group = ops, rank, world, group
+        # the collectives: torch.distributed (backend "nccl" = RCCL) unless a stand-in with the same three
+        # functions is injected (tests/test_gpu_two_ranks.py runs two ranks as threads on one GPU)
+        self.comm = dist if comm is None else comm
         self.device = device
         self.capacity = int(capacity)
         f64 = dict(dtype=torch.float64, device=device)
@@ -279,7 +282,7 @@ class ShardedCloud:
                 self._side.wait_event(p["event"])
             meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
             rows = [torch.empty_like(meta) for _ in range(W)]
-            dist.all_gather(rows, meta, group=self.group)
+            self.comm.all_gather(rows, meta, group=self.group)
             host = torch.cat(rows + [self.cell_lo_dev.to(torch.int64)]).cpu().numpy()
             table = host[: W * (W + 1)].reshape(W, W + 1)
             self.cell_lo = host[W * (W + 1):].astype(np.int32)
@@ -293,7 +296,7 @@ class ShardedCloud:
                 self.recvbuf = torch.empty(n_recv * D, dtype=torch.float64, device=self.device)
                 if self._side is not None:
                     self.recvbuf.record_stream(torch.cuda.current_stream(self.device))   # unpack reads it there
-            dist.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
+            self.comm.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
                                    [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
             if self._side is not None:
                 done = torch.cuda.Event()
@@ -341,7 +344,7 @@ class ShardedCloud:
         # particle-step (hops per step differ across the mesh: fine cells cost more), so the all-reduced
         # histogram is a cost density; scale 1 gives equal-count cuts
         self.ops.histogram(self, self._measured_cost() if self.balance_by_time else 1.0)
-        dist.all_reduce(self.weights_dev, group=self.group)
+        self.comm.all_reduce(self.weights_dev, group=self.group)
         self.ops.cell_ranges(self)
         self.rebalances += 1
 
@@ -380,5 +383,5 @@ class ShardedCloud:
         self._finish_exchange()
         t = torch.tensor([self.n], dtype=torch.int64, device=self.device)
         if self.world > 1:
-            dist.all_reduce(t, group=self.group)
+            self.comm.all_reduce(t, group=self.group)
         return int(t.item())
