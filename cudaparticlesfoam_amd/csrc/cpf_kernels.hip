@@ -347,7 +347,7 @@ constexpr int kCoopBlock = CPF_COOP_BLOCK;   // waves of a block share nothing b
 // no statistics) fits 72 VGPRs = 7 waves; measured time follows T = 0.10 ms + 0.59 ms / waves on the bench cloud,
 // i.e. the kernel is bound by the length of each wave's dependent chain, and resident waves are what hides it.
 template <bool BROWNIAN, bool STORE_VEL, bool STATS>
-struct CoopOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? 7 : 1; };
+struct CoopOccupancy { static constexpr int waves = (!STORE_VEL && !STATS) ? 7 : 1; };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS>
 __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_coop(double* __restrict__ x, double* __restrict__ y,
@@ -384,6 +384,14 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
         int token = INT32_MIN, h = 0, j = 0;
         D3 S = P;
         if (STATS && busy) ++st.steps;
+        if (BROWNIAN && busy) {
+            // Philox + Box-Muller (fp64 log / sqrt / sincos: a few hundred instructions and many registers) run HERE,
+            // with almost nothing else live, and leave the three deviates in the lane's wall-hit LDS slot, which is
+            // not needed before the first reflection and the kick is consumed in the first round.  Inside the round
+            // loop they cost the whole walk its occupancy (97 VGPRs = 4 waves).
+            const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+            sHit[0][tid] = xi.x; sHit[1][tid] = xi.y; sHit[2][tid] = xi.z;
+        }
         while (ballot64(busy) != 0ull) {
             // ---- distinct cells of the busy lanes -> slots (wave-uniform scalars)
             const unsigned long long busyMask = ballot64(busy);
@@ -426,7 +434,10 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                     if (needAdvect) {
                         const D3 Pn = axpy(dt, v, P);                              // particles.cu:355-362
                         D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
-                        if (BROWNIAN) disp = axpy(sigma, normal3(id, step0 + (uint32_t)c, seed), disp);
+                        if (BROWNIAN) {                                            // the deviates drawn before the round loop
+                            const D3 xi = {sHit[0][tid], sHit[1][tid], sHit[2][tid]};
+                            disp = axpy(sigma, xi, disp);
+                        }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;
@@ -442,7 +453,10 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         v = {u.x, u.y, u.z};
                         const D3 Pn = axpy(dt, v, P);
                         D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
-                        if (BROWNIAN) disp = axpy(sigma, normal3(id, step0 + (uint32_t)c, seed), disp);
+                        if (BROWNIAN) {                                            // the deviates drawn before the round loop
+                            const D3 xi = {sHit[0][tid], sHit[1][tid], sHit[2][tid]};
+                            disp = axpy(sigma, xi, disp);
+                        }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--unsorted", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--D", type=float, default=0.0, help="diffusion coefficient (Brownian kick on when > 0)")
+    ap.add_argument("--store-vel", action="store_true", help="also store the velocity per particle (output cycles)")
     args = ap.parse_args()
     import torch
     import bench
@@ -50,10 +52,13 @@ def main():
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
         p = lambda t: t.data_ptr()   # noqa: E731
-        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, args.warmup, args.flags)
+        vel = torch.empty(3 * n, dtype=torch.float64, device=dev) if args.store_vel else None
+        fl = args.flags | (2 if args.store_vel else 0)
+        pv = None if vel is None else vel.data_ptr()
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, pv, n, 1e-4, args.D, 0, args.warmup, fl)
         torch.cuda.synchronize()
         ctx.timing_enable(True)
-        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, args.warmup, args.steps, args.flags)
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, pv, n, 1e-4, args.D, args.warmup, args.steps, fl)
         launches, ms = ctx.timing_read()
         ctx.timing_enable(False)
         avg = ms / launches
