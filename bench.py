@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
     ap.add_argument("--exchange-interval", type=int, default=0,
                     help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
-    ap.add_argument("--rebalance-interval", type=int, default=8,
+    ap.add_argument("--rebalance-interval", type=int, default=16,
                     help="N>1: re-cut the cell ranges to equal particle counts + hand-off every that many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", choices=["time", "count"], default="time",
