@@ -177,6 +177,27 @@ class Context:
     def unpack_arrivals_dev(self, x, y, z, cell, gid, n_stay, recvbuf, n_recv):
         self._ck(self.lib.cpf_unpack_arrivals_dev(self.h, x, y, z, cell, gid, n_stay, recvbuf, n_recv))
 
+    def write_vtu(self, path: str) -> float:
+        """particle_%04d.vtu in the reference's layout, synchronously; returns the total kinetic energy."""
+        ke = C.c_double()
+        r = self.lib.cpf_write_vtu(self.h, str(path).encode(), C.byref(ke))
+        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+            self._ck(r)
+        return ke.value
+
+    def write_vtu_async(self, path: str) -> float:
+        """Same frame, formatted and written by a worker thread (one frame in flight per context)."""
+        ke = C.c_double()
+        r = self.lib.cpf_write_vtu_async(self.h, str(path).encode(), C.byref(ke))
+        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+            self._ck(r)
+        return ke.value
+
+    def write_vtu_wait(self):
+        r = self.lib.cpf_write_vtu_wait(self.h)
+        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+            self._ck(r)
+
     def timing_enable(self, on: bool = True):
         self._ck(self.lib.cpf_timing_enable(self.h, int(on)))
 

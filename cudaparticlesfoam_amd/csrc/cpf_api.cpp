@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -51,6 +52,12 @@ struct cpf_context {
     uint32_t lastSortStep = 0;
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h
+    // asynchronous output (cpf_write_vtu_async): one frame in flight
+    std::thread writer;
+    bool writerLive = false;
+    int writerStatus = CPF_OK;
+    std::vector<double> wXyzw, wVel;
+    std::vector<int32_t> wCell;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -61,6 +68,14 @@ namespace {
 
 std::string g_createError = "";
 std::mutex g_mutex;
+
+// Contexts with an output frame still being written.  A host that never calls cpf_destroy (the reference's
+// solvers simply return from main) must not lose its last frame: the registry's destructor runs at exit and
+// joins the workers.
+struct WriterRegistry {
+    std::vector<cpf_context*> live;
+    ~WriterRegistry();
+} g_writers;
 
 int fail(const cpf_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -170,6 +185,13 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
 
 }  // namespace
 
+namespace {
+WriterRegistry::~WriterRegistry() {
+    for (cpf_context* c : live)
+        if (c->writerLive && c->writer.joinable()) { c->writer.join(); c->writerLive = false; }
+}
+}  // namespace
+
 extern "C" {
 
 int cpf_abi_version(void) { return CPF_ABI_VERSION; }
@@ -204,6 +226,7 @@ int cpf_create(int device, cpf_context** out) {
 
 int cpf_destroy(cpf_context* ctx) {
     if (!ctx) return CPF_OK;
+    (void)cpf_write_vtu_wait(ctx);                                             // never lose a frame
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     freeMesh(ctx); freeCloud(ctx);
@@ -688,6 +711,48 @@ int cpf_stage_move(cpf_context* ctx, double* particles, double* disps, int64_t n
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, cpf::launch_stage_move(ctx->stream, particles, disps, n));
     return CPF_OK;
+}
+
+int cpf_write_vtu_wait(cpf_context* ctx) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    if (!ctx->writerLive) return CPF_OK;
+    ctx->writer.join();
+    ctx->writerLive = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mutex);
+        auto& v = g_writers.live;
+        v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+    }
+    const int r = ctx->writerStatus;
+    ctx->writerStatus = CPF_OK;
+    if (r != CPF_OK && r != CPF_ERR_STATE) return fail(ctx, r, "cpf_write_vtu_async: the frame could not be written");
+    return r;
+}
+
+int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE) {
+    CPF_REQUIRE(ctx, ctx && path, CPF_ERR_ARG, "null argument");
+    int r = cpf_write_vtu_wait(ctx);                       // one frame in flight; reports the previous frame's failure
+    if (r != CPF_OK && r != CPF_ERR_STATE) return r;
+    int64_t n = 0;
+    r = cpf_num_particles(ctx, &n);
+    if (r) return r;
+    ctx->wXyzw.resize((size_t)n * 4); ctx->wVel.resize((size_t)n * 4); ctx->wCell.resize((size_t)n);
+    r = cpf_get_particles(ctx, ctx->wXyzw.data(), ctx->wCell.data(), ctx->wVel.data());   // the snapshot (D2H)
+    if (r) return r;
+    double total = 0.0;                                    // known now, so callers can print it in the reference's order
+    for (int64_t i = 0; i < n; ++i) {
+        const double* v = &ctx->wVel[4 * (size_t)i];
+        total += 0.5 * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    }
+    if (totalKE) *totalKE = total;
+    const std::string file(path);
+    { std::lock_guard<std::mutex> lk(g_mutex); g_writers.live.push_back(ctx); }
+    ctx->writerLive = true;
+    ctx->writer = std::thread([ctx, file, n] {
+        ctx->writerStatus = cpf_write_vtu_arrays(file.c_str(), n, ctx->wXyzw.data(), ctx->wCell.data(), ctx->wVel.data(),
+                                                 nullptr);
+    });
+    return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
 }
 
 int cpf_timing_enable(cpf_context* ctx, int on) {

@@ -8,12 +8,132 @@
 //     reference's ParticleTetID is uninitialised memory in its default ConvexPoly build);
 //   * KEs holds the kinetic energy (the reference prints 0 for every non-zero KE);
 //   * no system("pause") on NaN: the function returns CPF_ERR_STATE instead.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cpf.h"
+
+namespace {
+
+// Formatting dominates the output path (printf of "%.15lf": 2.4 us per particle and frame on one core, 240 ms for
+// the tutorial's 1e5 particles against 10 ms of GPU time for the 1000 cycles between two frames), so every
+// DataArray is formatted in parallel: chunks of 32768 particles, one std::thread each, the texts written in order.
+// The bytes are those of the serial loop.
+constexpr long long kChunk = 32768;
+
+int writer_threads(long long n) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const long long want = (n + kChunk - 1) / kChunk;
+    return (int)std::max<long long>(1, std::min<long long>({want, (long long)(hw ? hw : 1), 16}));
+}
+
+// ---- "%.Nlf" without printf.  glibc prints the EXACT decimal expansion of the double, rounded half-to-even at the
+// last digit; so does this: x = m * 2^e with a 53-bit m, so m * 10^N (N <= 15) fits 128 bits, and the shift by e is
+// either exact (e >= 0) or a division by a power of two whose remainder decides the rounding.  Anything that is
+// not finite, or too large for the 128-bit product, goes through snprintf.  Checked against correctly rounded formatting on
+// 1.2 million doubles of every magnitude and the edge cases (tests/test_vtu_writer.py).  ~10x faster than printf.
+typedef unsigned __int128 u128;
+
+inline char* put_u64(char* p, unsigned long long v) {
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+template <int N>   // N fractional digits (6 or 15)
+inline void append_fixed(std::string& out, double x) {
+    static_assert(N == 6 || N == 15, "");
+    constexpr unsigned long long P10 = N == 6 ? 1000000ull : 1000000000000000ull;
+    unsigned long long bits; std::memcpy(&bits, &x, 8);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    if (be == 0x7ff || be >= 1023 + 63) {                 // inf / nan / |x| >= 2^63: the library's own text
+        char b[400];
+        const int k = std::snprintf(b, sizeof(b), N == 6 ? "%lf" : "%.15lf", x);
+        out.append(b, (size_t)k);
+        return;
+    }
+    const bool neg = (bits >> 63) != 0;
+    unsigned long long m = bits & ((1ull << 52) - 1);
+    int e;
+    if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }      // x = m * 2^e
+    u128 v = (u128)m * P10;                                                // < 2^53 * 2^50
+    u128 q;
+    if (e >= 0) q = v << e;                                                // |x| < 2^63 and 10^15 < 2^50: no overflow
+    else if (-e >= 128) q = 0;                                             // v < 2^103 <= half of 2^-e: rounds to 0
+    else {
+        const int sh = -e;
+        q = v >> sh;
+        const u128 rem = v & (((u128)1 << sh) - 1), half = (u128)1 << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) ++q;                    // round half to even, like glibc
+    }
+    unsigned long long ip, fp;
+    if ((unsigned long long)(q >> 64) == 0) {                               // |x| < 18446 (15 digits): plain 64-bit division
+        const unsigned long long q64 = (unsigned long long)q;
+        ip = q64 / P10; fp = q64 % P10;
+    } else {
+        ip = (unsigned long long)(q / P10); fp = (unsigned long long)(q % P10);
+    }
+    char b[48]; char* p = b;
+    if (neg) *p++ = '-';
+    p = put_u64(p, ip);
+    *p++ = '.';
+    for (int k = N - 1; k >= 0; --k) { p[k] = (char)('0' + (fp % 10)); fp /= 10; }
+    p += N;
+    out.append(b, (size_t)(p - b));
+}
+
+inline void append_int(std::string& out, long long v) {
+    char b[24]; char* p = b;
+    unsigned long long u = v < 0 ? (unsigned long long)(-(v + 1)) + 1ull : (unsigned long long)v;
+    if (v < 0) *p++ = '-';
+    p = put_u64(p, u);
+    *p++ = '\n';
+    out.append(b, (size_t)(p - b));
+}
+
+template <int N>
+inline void append_fixed3(std::string& out, double a, double b, double c) {
+    append_fixed<N>(out, a); out.push_back(' ');
+    append_fixed<N>(out, b); out.push_back(' ');
+    append_fixed<N>(out, c); out.push_back('\n');
+}
+
+// item(i, buf) appends the text of element i to buf
+template <typename F>
+bool write_array(FILE* fp, long long n, const F& item) {
+    const int T = writer_threads(n);
+    const long long nChunks = (n + kChunk - 1) / kChunk;
+    std::vector<std::string> text((size_t)T);
+    for (long long c0 = 0; c0 < nChunks; c0 += T) {
+        const int live = (int)std::min<long long>(T, nChunks - c0);
+        auto work = [&](int t) {
+            std::string& out = text[(size_t)t];
+            out.clear();
+            const long long i0 = (c0 + t) * kChunk, i1 = std::min(n, i0 + kChunk);
+            out.reserve((size_t)(i1 - i0) * 24);
+            for (long long i = i0; i < i1; ++i) item(i, out);
+        };
+        if (live == 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < live; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
+        for (int t = 0; t < live; ++t)
+            if (!text[(size_t)t].empty() && std::fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), fp) != text[(size_t)t].size())
+                return false;
+    }
+    return true;
+}
+
+}  // namespace
 
 extern "C" int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const int32_t* cell,
                                     const double* vel, double* totalKE) {
@@ -21,47 +141,46 @@ extern "C" int cpf_write_vtu_arrays(const char* path, int64_t n, const double* x
     FILE* fp = std::fopen(path, "w");
     if (!fp) return CPF_ERR_ARG;
     const long long N = (long long)n;
+    bool ok = true;
     std::fprintf(fp, "<VTKFile type='UnstructuredGrid' version='1.0' byte_order='LittleEndian' header_type='UInt64'>\n");
     std::fprintf(fp, "<UnstructuredGrid>\n");
     std::fprintf(fp, "<Piece NumberOfCells='%lld' NumberOfPoints='%lld'>\n", N, N);
     std::fprintf(fp, "<Points>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='3' type='Float64' Name='Position' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i)
-        std::fprintf(fp, "%.15lf %.15lf %.15lf\n", xyzw[4 * i], xyzw[4 * i + 1], xyzw[4 * i + 2]);
+    ok &= write_array(fp, N, [&](long long i, std::string& o) {
+        append_fixed3<15>(o, xyzw[4 * i], xyzw[4 * i + 1], xyzw[4 * i + 2]); });
     std::fprintf(fp, "</DataArray>\n</Points>\n<PointData>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='ParticleType' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) std::fprintf(fp, "%d\n", (int)xyzw[4 * i + 3]);
+    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, (int)xyzw[4 * i + 3]); });
     std::fprintf(fp, "</DataArray>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='ParticleID' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) std::fprintf(fp, "%lld\n", i);
+    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i); });
     std::fprintf(fp, "</DataArray>\n");
     for (const char* name : {"ParticleTetID", "ConvexTetID"}) {
         std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='%s' format='ascii'>\n", name);
-        for (long long i = 0; i < N; ++i) std::fprintf(fp, "%d\n", cell[i]);
+        ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, cell[i]); });
         std::fprintf(fp, "</DataArray>\n");
     }
     std::fprintf(fp, "<DataArray NumberOfComponents='3' type='Float32' Name='vels' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) {
-        if (std::isnan(vel[4 * i])) std::fprintf(fp, "%lf %lf %lf\n", 0.0, 0.0, 0.0);
-        else std::fprintf(fp, "%lf %lf %lf\n", vel[4 * i], vel[4 * i + 1], vel[4 * i + 2]);
-    }
+    ok &= write_array(fp, N, [&](long long i, std::string& o) {
+        if (std::isnan(vel[4 * i])) append_fixed3<6>(o, 0.0, 0.0, 0.0);
+        else append_fixed3<6>(o, vel[4 * i], vel[4 * i + 1], vel[4 * i + 2]); });
     std::fprintf(fp, "</DataArray>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Float32' Name='KEs' format='ascii'>\n");
+    auto keOf = [&](long long i) {
+        return 0.5 * (vel[4 * i] * vel[4 * i] + vel[4 * i + 1] * vel[4 * i + 1] + vel[4 * i + 2] * vel[4 * i + 2]); };
+    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_fixed<6>(o, keOf(i)); o.push_back('\n'); });
     double total = 0.0;
-    for (long long i = 0; i < N; ++i) {
-        const double ke = 0.5 * (vel[4 * i] * vel[4 * i] + vel[4 * i + 1] * vel[4 * i + 1] + vel[4 * i + 2] * vel[4 * i + 2]);
-        std::fprintf(fp, "%lf\n", ke);
-        total += ke;
-    }
+    for (long long i = 0; i < N; ++i) total += keOf(i);              // in index order, like the reference's running sum
     std::fprintf(fp, "</DataArray>\n</PointData>\n<Cells>\n");
     std::fprintf(fp, "<DataArray type='Int32' Name='connectivity' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) std::fprintf(fp, "%lld\n", i);
+    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i); });
     std::fprintf(fp, "</DataArray>\n<DataArray type='Int32' Name='offsets' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) std::fprintf(fp, "%lld\n", i + 1);
+    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i + 1); });
     std::fprintf(fp, "</DataArray>\n<DataArray type='UInt8' Name='types' format='ascii'>\n");
-    for (long long i = 0; i < N; ++i) std::fprintf(fp, "1\n");
+    ok &= write_array(fp, N, [&](long long, std::string& o) { o.append("1\n"); });
     std::fprintf(fp, "</DataArray>\n</Cells>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n");
-    const bool bad = std::ferror(fp) != 0;
+    const bool bad = !ok || std::ferror(fp) != 0;
     std::fclose(fp);
     if (totalKE) *totalKE = total;
     if (bad) return CPF_ERR_ARG;

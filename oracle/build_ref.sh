@@ -42,6 +42,10 @@ expect "$RTX/cuda/particles.cu"      660 "particleMoveKernel"
 expect "$RTX/query/RTQuery.cu"       35  "baryTetSearch"
 expect "$RTX/query/RTQuery.cu"       109 "RTreflection"
 expect "$RTX/query/RTQuery.cu"       221 "baryQueryDisp"
+expect "$RTX/cuda/utils.cpp"         144 "writeParticles2VTU"
+expect "$RTX/cuda/utils.cpp"         172 "Output particle into VTU file"
+expect "$RTX/cuda/utils.cpp"         217 "h_ctetIDs(numParticles)"
+expect "$RTX/cuda/utils.cpp"         282 "fclose(fp)"
 
 {
   sed -n '82,104p;108,156p;193,199p' "$RTX/cuda/DeviceTetMesh.cuh"   # det, tetBaryCoord, triNorm
@@ -53,6 +57,11 @@ expect "$RTX/query/RTQuery.cu"       221 "baryQueryDisp"
   sed -n '659,704p'                   "$RTX/cuda/particles.cu"         # particleMoveKernel (disp)
   sed -n '35,186p;189,248p'           "$RTX/query/RTQuery.cu"          # bary search, RT reflection, baryQuery(Disp)
 } > "$TMP/ref_extract.inc"
+# the body of writeParticles2VTU (host code: the on-disk format).  Its three cudaMemcpy device-to-host copies
+# (:151-170 and :218-221) are left out -- the driver passes host arrays -- everything that formats is the
+# reference's own text.
+sed -n '172,217p' "$RTX/cuda/utils.cpp" > "$TMP/ref_vtu_head.inc"
+sed -n '222,282p' "$RTX/cuda/utils.cpp" > "$TMP/ref_vtu_tail.inc"
 
 g++ -std=c++14 -O2 -fPIC -shared -fopenmp -ffp-contract=off -w \
     -I"$RTX" -I"$RTX/owl/owl/include" -I"$TMP" \

@@ -112,6 +112,18 @@ class RefLib(_TetApi):
         L.ref_cycles.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, C.c_int, _ip, _dp, _dp, _ip, _ip, _ip, C.c_int]
         L.ref_box_mesh.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _ip, C.c_int, C.c_int]
         L.ref_box_mesh.restype = C.c_int
+        L.ref_write_vtu.argtypes = [C.c_uint, _dp, _dp, _ip, C.c_int, _ip]
+
+    def write_vtu(self, directory, ti, particles, vels, tet_ids, convex_ids):
+        """The reference's writeParticles2VTU (cuda/utils.cpp:144-283) on host arrays: <directory>/particle_%04d.vtu."""
+        cwd = os.getcwd()
+        os.chdir(directory)
+        try:
+            self.lib.ref_write_vtu(int(ti), _c(particles, np.float64), _c(vels, np.float64), _c(tet_ids, np.int32),
+                                   int(np.asarray(tet_ids).shape[0]), _c(convex_ids, np.int32))
+        finally:
+            os.chdir(cwd)
+        return os.path.join(directory, "particle_%04d.vtu" % ti)
 
     def box_mesh(self, nx, ny, nz):
         nV = (nx + 1) * (ny + 1) * (nz + 1); nT = 6 * nx * ny * nz

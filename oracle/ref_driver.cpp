@@ -190,6 +190,21 @@ void ref_cycles(double* particles, int* tetIDs, double* vels, double* disps, dou
     });
 }
 
+// The reference's VTU writer (cuda/utils.cpp:144-283) on host arrays: writes ./particle_%04d.vtu (ti) in the current
+// directory, exactly as the solver does.  Only the device-to-host copies are replaced by the arguments.
+int ref_write_vtu(unsigned int ti, const double* particles /* [n][4] */, const double* vels /* [n][4] */,
+                  const int* tetIDs, int numParticles, const int* d_tetIDs_Convex) {
+    std::vector<Particle> hostParticles(numParticles);
+    std::vector<int> h_tetIDs(tetIDs, tetIDs + numParticles);
+    std::vector<vec4d> h_vels(numParticles);
+    std::memcpy(hostParticles.data(), particles, sizeof(Particle) * (size_t)numParticles);
+    std::memcpy(h_vels.data(), vels, sizeof(vec4d) * (size_t)numParticles);
+#include "ref_vtu_head.inc"            // utils.cpp:172-217, up to the declaration of h_ctetIDs
+            std::memcpy(h_ctetIDs.data(), d_tetIDs_Convex, sizeof(int) * (size_t)numParticles);   // for :218-221
+#include "ref_vtu_tail.inc"            // utils.cpp:222-282, through fclose(fp)
+    return 0;
+}
+
 int ref_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -817,3 +817,27 @@ def test_64bit_labels_give_the_same_tables(setup, gpu_ctx_factory):
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
     ctx.close()
+
+
+def test_async_vtu_frame_is_a_snapshot(setup, gpu_ctx_factory, tmp_path):
+    """cpf_write_vtu_async: the frame holds the cloud as it was at the call (the worker thread formats and writes
+    while the GPU steps on), the kinetic energy is known at once, and the bytes are those of the synchronous
+    writer; a second call waits for the first frame, cpf_write_vtu_wait for the last."""
+    pz, mesh = setup["pz"], setup["mesh"]
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(setup["pitz"]["U_analytic"])
+    n = 120_000
+    ctx.set_particles(_seed_points(pz, n, pz.DOMAIN_BOX, seed=808))
+    ctx.locate_initial()
+    from cudaparticlesfoam_amd import _lib as L
+    ctx.step(1e-4, 0.0, 3, L.STEP_STORE_VEL)
+    ke_sync = ctx.write_vtu(tmp_path / "sync.vtu")
+    ke_async = ctx.write_vtu_async(tmp_path / "async_a.vtu")
+    ctx.step(1e-4, 0.0, 25, L.STEP_STORE_VEL)                       # the cloud moves on while frame a is written
+    ke_b = ctx.write_vtu_async(tmp_path / "async_b.vtu")            # waits for frame a, snapshots again
+    ctx.write_vtu_wait()
+    a = open(tmp_path / "async_a.vtu", "rb").read()
+    assert a == open(tmp_path / "sync.vtu", "rb").read() and ke_async == ke_sync and len(a) > n * 100
+    b = open(tmp_path / "async_b.vtu", "rb").read()
+    assert b != a and b.endswith(b"</VTKFile>\n") and ke_b != ke_sync
+    ctx.write_vtu_wait()                                             # idempotent
