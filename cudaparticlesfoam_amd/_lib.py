@@ -33,6 +33,12 @@ class LibraryMissing(ImportError):
 _vp, _i64, _i32, _u32, _dbl, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_int
 _ctx = C.c_void_p
 
+class MeshPart(C.Structure):
+    """cpf_mesh_part (include/cpf.h): one rank's piece of a decomposed polyMesh."""
+    _fields_ = [("points", _vp), ("nPoints", _i64), ("faceOffsets", _vp), ("faceVerts", _vp), ("nFaces", _i64),
+                ("owner", _vp), ("neighbour", _vp), ("nInternalFaces", _i64), ("nCells", _i64), ("labelBytes", _int)]
+
+
 # name -> (restype, argtypes); mirrors include/cpf.h one to one
 SIGNATURES = {
     "cpf_abi_version": (_int, []),
@@ -44,6 +50,13 @@ SIGNATURES = {
     "cpf_synchronize": (_int, [_ctx]),
     "cpf_set_mesh": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
     "cpf_set_mesh_l64": (_int, [_ctx, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
+    "cpf_merge_mesh_parts": (_int, [C.POINTER(MeshPart), _int, C.POINTER(_vp)]),
+    "cpf_merge_last_error": (C.c_char_p, []),
+    "cpf_merged_mesh_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                                     C.POINTER(_i64)]),
+    "cpf_merged_mesh_copy": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cpf_merged_mesh_free": (None, [_vp]),
+    "cpf_set_mesh_parts": (_int, [_ctx, C.POINTER(MeshPart), _int]),
     "cpf_mesh_info": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "cpf_get_mesh_tables": (_int, [_ctx, _vp, _vp, _vp]),
     "cpf_set_velocity": (_int, [_ctx, _vp, _i64]),

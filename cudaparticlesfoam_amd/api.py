@@ -83,6 +83,16 @@ class Context:
                     int(mesh.n_cells)))
         self.n_cells = int(mesh.n_cells)
 
+    def set_mesh_parts(self, parts):
+        """Rank-direct ingest: ``parts`` = the pieces of a decomposed mesh in rank order (each exposes the PolyMesh
+        fields); they are stitched on the host (cpf_merge_mesh_parts) and uploaded as one mesh."""
+        arr, keep = pack_mesh_parts(parts)
+        r = self.lib.cpf_set_mesh_parts(self.h, arr, len(parts))
+        if r == L.CPF_ERR_MESH and not self.lib.cpf_last_error(self.h):
+            raise L.CpfError(r, (self.lib.cpf_merge_last_error() or b"").decode())
+        self._ck(r)
+        self.n_cells = int(sum(int(p.n_cells) for p in parts))
+
     def mesh_info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._ck(self.lib.cpf_mesh_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -211,6 +221,42 @@ class Context:
         a, b = C.c_int64(), C.c_double()
         self._ck(self.lib.cpf_timing_poll(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def pack_mesh_parts(parts):
+    """(ctypes array of cpf_mesh_part, the numpy arrays it points into)."""
+    arr = (L.MeshPart * len(parts))()
+    keep = []
+    for k, m in enumerate(parts):
+        lab = np.int64 if np.asarray(m.owner).dtype == np.int64 else np.int32
+        pts = np.ascontiguousarray(m.points, dtype=np.float64)
+        fo = np.ascontiguousarray(m.face_offsets, dtype=lab); fv = np.ascontiguousarray(m.face_verts, dtype=lab)
+        ow = np.ascontiguousarray(m.owner, dtype=lab); ne = np.ascontiguousarray(m.neighbour, dtype=lab)
+        keep += [pts, fo, fv, ow, ne]
+        arr[k] = L.MeshPart(pts.ctypes.data, pts.shape[0], fo.ctypes.data, fv.ctypes.data, ow.shape[0], ow.ctypes.data,
+                            ne.ctypes.data if ne.size else None, ne.shape[0], int(m.n_cells), 8 if lab == np.int64 else 4)
+    return arr, keep
+
+
+def merge_mesh_parts(parts):
+    """cpf_merge_mesh_parts on the host (no GPU): the stitched global mesh as a cases.PolyMesh (64-bit labels)."""
+    from .cases.polymesh import PolyMesh
+    lib = L.load()
+    arr, keep = pack_mesh_parts(parts)
+    h = C.c_void_p()
+    r = lib.cpf_merge_mesh_parts(arr, len(parts), C.byref(h))
+    if r != L.CPF_OK:
+        raise L.CpfError(r, (lib.cpf_merge_last_error() or b"").decode())
+    try:
+        n = [C.c_int64() for _ in range(5)]
+        lib.cpf_merged_mesh_sizes(h, *[C.byref(v) for v in n])
+        n_points, n_faces, n_fv, n_int, n_cells = (v.value for v in n)
+        pts = np.empty((n_points, 3)); fo = np.empty(n_faces + 1, np.int64); fv = np.empty(n_fv, np.int64)
+        ow = np.empty(n_faces, np.int64); ne = np.empty(n_int, np.int64)
+        lib.cpf_merged_mesh_copy(h, _ptr(pts), _ptr(fo), _ptr(fv), _ptr(ow), _ptr(ne))
+    finally:
+        lib.cpf_merged_mesh_free(h)
+    return PolyMesh(points=pts, face_offsets=fo, face_verts=fv, owner=ow, neighbour=ne, n_cells=int(n_cells))
 
 
 # ------------------------------------------------------------------------------------------------

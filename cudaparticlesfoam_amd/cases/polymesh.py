@@ -210,3 +210,41 @@ def build_polymesh_from_cells(points: np.ndarray, cell_face_loops: List[List[Tup
     return PolyMesh(np.ascontiguousarray(points, dtype=np.float64), np.asarray(offs, dtype=np.int32),
                     np.asarray(verts, dtype=np.int32), own_a[order].astype(np.int32),
                     nei_a[order_int].astype(np.int32), len(cell_face_loops), patches)
+
+
+def split_into_parts(mesh: "PolyMesh", n_parts: int) -> List["PolyMesh"]:
+    """What ``decomposePar`` hands the ranks, for contiguous cell ranges: piece p gets the cells
+    ``[p*nC/n_parts, (p+1)*nC/n_parts)`` with local cell ids, its own point list, its interior faces, then its
+    boundary faces -- the physical ones AND the faces cut by the decomposition (processor patches, oriented
+    outward from the piece like any boundary face).  Input of the rank-direct ingest (cpf_merge_mesh_parts)."""
+    nC = mesh.n_cells
+    cuts = [(p * nC) // n_parts for p in range(n_parts + 1)]
+    own = np.asarray(mesh.owner, dtype=np.int64)
+    nei = np.full(own.shape[0], -1, dtype=np.int64)
+    nei[: mesh.n_internal] = np.asarray(mesh.neighbour, dtype=np.int64)
+    fo = np.asarray(mesh.face_offsets, dtype=np.int64); fv = np.asarray(mesh.face_verts, dtype=np.int64)
+    parts = []
+    for p in range(n_parts):
+        lo, hi = cuts[p], cuts[p + 1]
+        o_in = (own >= lo) & (own < hi)
+        n_in = (nei >= lo) & (nei < hi)
+        interior = np.nonzero(o_in & n_in)[0]
+        as_owner = np.nonzero(o_in & ~n_in)[0]                  # physical boundary or cut face, we are the owner
+        as_neigh = np.nonzero(~o_in & n_in)[0]                  # cut face, we are the neighbour: flip it
+        faces, owners, neighs = [], [], []
+        for f in interior:
+            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(own[f] - lo); neighs.append(nei[f] - lo)
+        for f in as_owner:
+            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(own[f] - lo)
+        for f in as_neigh:
+            faces.append(fv[fo[f]:fo[f + 1]][::-1]); owners.append(nei[f] - lo)
+        used = np.unique(np.concatenate(faces)) if faces else np.zeros(0, np.int64)
+        local = np.full(mesh.n_points, -1, dtype=np.int64)
+        local[used] = np.arange(used.size)
+        offs = np.zeros(len(faces) + 1, dtype=np.int64)
+        np.cumsum([len(f) for f in faces], out=offs[1:])
+        verts = local[np.concatenate(faces)] if faces else np.zeros(0, np.int64)
+        parts.append(PolyMesh(points=np.asarray(mesh.points)[used].copy(), face_offsets=offs.astype(np.int32),
+                              face_verts=verts.astype(np.int32), owner=np.asarray(owners, dtype=np.int32),
+                              neighbour=np.asarray(neighs, dtype=np.int32), n_cells=hi - lo))
+    return parts

@@ -73,6 +73,37 @@ int cpf_synchronize(cpf_context* ctx);   /* replaces cudaDeviceSynchronize() aft
 /* ---------------------------------------------------------------------------------------------
  * mesh + velocity
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * rank-direct ingest of a decomposed mesh (replaces src/initCuda.H:207-371: gather-to-master of points, cell
+ * centres and 12 tets per cell, coincident points merged by a linear search per point)
+ * ------------------------------------------------------------------------------------------- */
+/* One rank's piece of the polyMesh, exactly as that rank's fvMesh holds it: processor patches are ordinary
+ * boundary faces of the piece.  labelBytes = sizeof(Foam::label) (4 or 8). */
+typedef struct cpf_mesh_part {
+    const double* points;      int64_t nPoints;          /* [nPoints][3] */
+    const void* faceOffsets;   const void* faceVerts;    /* [nFaces+1], flattened vertex lists */
+    int64_t nFaces;
+    const void* owner;         const void* neighbour;    /* [nFaces], [nInternalFaces] */
+    int64_t nInternalFaces;    int64_t nCells;
+    int labelBytes;
+} cpf_mesh_part;
+typedef struct cpf_merged_mesh cpf_merged_mesh;
+/* Stitches the pieces (in rank order) into the global mesh on the host; no GPU involved.  Points that coincide
+ * exactly become one (the reference's criterion, :341), two boundary faces of different pieces on the same points
+ * become one interior face, global cell id = cells of the preceding pieces + local id (globalIndex, :229-230; so
+ * the concatenated U slices are the global U), interior faces come out in upper-triangular order.
+ * CPF_ERR_MESH with the reason in cpf_merge_last_error(). */
+int cpf_merge_mesh_parts(const cpf_mesh_part* parts, int nParts, cpf_merged_mesh** out);
+const char* cpf_merge_last_error(void);
+int cpf_merged_mesh_sizes(const cpf_merged_mesh* m, int64_t* nPoints, int64_t* nFaces, int64_t* nFaceVerts,
+                          int64_t* nInternalFaces, int64_t* nCells);
+/* 64-bit labels out; any pointer may be NULL */
+int cpf_merged_mesh_copy(const cpf_merged_mesh* m, double* points, int64_t* faceOffsets, int64_t* faceVerts,
+                         int64_t* owner, int64_t* neighbour);
+void cpf_merged_mesh_free(cpf_merged_mesh* m);
+/* cpf_merge_mesh_parts + cpf_set_mesh_l64 */
+int cpf_set_mesh_parts(cpf_context* ctx, const cpf_mesh_part* parts, int nParts);
+
 /* Hand over the polyMesh.  Replaces src/initCuda.H:76-130 (polyMeshTetDecomposition loop,
  * HostTetMesh::getBoundaryMesh -- cuda/HostTetMesh.h:307-430 --, DeviceTetMesh::upload --
  * cuda/DeviceTetMesh.cuh:59-72) and the OptiX BVH build (src/initCuda.H:132-139).
