@@ -59,6 +59,8 @@ struct cpf_context {
     std::vector<double> wXyzw, wVel;
     std::vector<int32_t> wCell;
     // timing
+    int timingStride = 1;                       // "timing_stride": bracket every k-th step launch only
+    uint64_t timingLaunch = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> eventPool;
@@ -414,7 +416,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     const int cycPerLaunch = fuse ? nCycles : 1;
     for (int c = 0; c < nLaunch; ++c) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->timing) {
+        const bool timed = ctx->timing && (ctx->timingLaunch++ % (uint64_t)ctx->timingStride) == 0;
+        if (timed) {
             auto take = [&](hipEvent_t& ev) -> hipError_t {
                 if (!ctx->eventPool.empty()) { ev = ctx->eventPool.back(); ctx->eventPool.pop_back(); return hipSuccess; }
                 return hipEventCreate(&ev);
@@ -424,7 +427,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
         }
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                       reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant));
-        if (ctx->timing) {
+        if (timed) {
             CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             ctx->events.emplace_back(e0, e1);
         }
@@ -532,6 +535,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     if (k == "sort_interval") {
         CPF_REQUIRE(ctx, value >= 0 && value <= 1e9, CPF_ERR_ARG, "sort_interval must be >= 0 (0 = never)");
         ctx->sortInterval = (int)value;
+        return CPF_OK;
+    }
+    if (k == "timing_stride") {
+        CPF_REQUIRE(ctx, value >= 1 && value <= 1e6 && value == (int)value, CPF_ERR_ARG, "timing_stride must be an integer >= 1");
+        ctx->timingStride = (int)value;
         return CPF_OK;
     }
     if (k == "stats") {

@@ -171,6 +171,7 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference
  *                   has no such diagnostics, and they cost the step kernel a resident wave (0.16 -> 0.22 ms
  *                   per 1e7-particle launch)
+ *   "timing_stride" cpf_timing_enable brackets every k-th step launch only (default 1)
  *   "sort_interval" cpf_step re-sorts the context-owned cloud by cell every N cycles (default 50, 0 = never);
  *                   invisible to callers: cpf_get_particles always answers in particle-id order */
 int cpf_set_option(cpf_context* ctx, const char* key, double value);   /* Brownian stream; default 1591593751 (particles.cu:544) */
@@ -269,7 +270,8 @@ int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const 
 /* ---------------------------------------------------------------------------------------------
  * measurement
  * ------------------------------------------------------------------------------------------- */
-/* When enabled, every step-kernel launch is bracketed by a hipEvent pair on the launch stream. */
+/* When enabled, every step-kernel launch (every k-th with cpf_set_option "timing_stride" k: an event pair costs
+ * ~5 us of idle GPU between two back-to-back launches) is bracketed by a hipEvent pair on the launch stream. */
 int cpf_timing_enable(cpf_context* ctx, int on);
 /* Drains the recorded pairs: number of launches and their summed device time in ms. */
 int cpf_timing_read(cpf_context* ctx, int64_t* launches, double* total_ms);
