@@ -852,6 +852,39 @@ __global__ void gather3_kernel(const double* __restrict__ src, double* __restric
         dst[3 * i] = src[3 * j]; dst[3 * i + 1] = src[3 * j + 1]; dst[3 * i + 2] = src[3 * j + 2];
     }
 }
+// The sort's permutation applied to several arrays per launch (perm is read once, the scattered reads of one
+// particle's fields are in flight together), then one launch copies the staged arrays back.
+__global__ void gather_xyz_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                  const double* __restrict__ z, double* __restrict__ sx, double* __restrict__ sy,
+                                  double* __restrict__ sz, const int32_t* __restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const int64_t j = perm[i];
+        const double a = x[j], b = y[j], c = z[j];
+        sx[i] = a; sy[i] = b; sz[i] = c;
+    }
+}
+__global__ void copy_xyz_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
+                                const double* __restrict__ sx, const double* __restrict__ sy,
+                                const double* __restrict__ sz, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { x[i] = sx[i]; y[i] = sy[i]; z[i] = sz[i]; }
+}
+__global__ void gather_ids_kernel(const int32_t* __restrict__ cell, const int64_t* __restrict__ gid,
+                                  int32_t* __restrict__ sc, int64_t* __restrict__ sg,
+                                  const int32_t* __restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const int64_t j = perm[i];
+        sc[i] = cell[j];
+        if (gid) sg[i] = gid[j];
+    }
+}
+__global__ void copy_ids_kernel(int32_t* __restrict__ cell, int64_t* __restrict__ gid, const int32_t* __restrict__ sc,
+                                const int64_t* __restrict__ sg, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { cell[i] = sc[i]; if (gid) gid[i] = sg[i]; }
+}
 // AoS <-> SoA conversion for the reference-shaped accessors (Particle = double4)
 __global__ void unpack_xyz_kernel(const double* __restrict__ xyz, double* x, double* y, double* z, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1004,25 +1037,18 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     // endBit covers the cell bits + sub-cell bits; the all-ones key of lost/frozen particles sorts last
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keysIn, keysOut, idx, perm, (int)n, 0, endBit, st);
     if (e != hipSuccess) return e;
-    double* arrs[3] = {x, y, z};
-    for (double* a : arrs) {
-        hipLaunchKernelGGL((gather_kernel<double>), grid_for(n), dim3(kBlock), 0, st, a, stage, perm, n);
-        e = hipMemcpyAsync(a, stage, 8 * (size_t)n, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return e;
-    }
-    if (gid) {
-        hipLaunchKernelGGL((gather_kernel<int64_t>), grid_for(n), dim3(kBlock), 0, st, gid, (int64_t*)stage, perm, n);
-        e = hipMemcpyAsync(gid, stage, 8 * (size_t)n, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return e;
-    }
+    double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;          // the 24n-byte staging area
+    hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, perm, n);
+    hipLaunchKernelGGL(copy_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, n);
+    int64_t* sg = reinterpret_cast<int64_t*>(stage);                                  // 8n, then 4n for the cells
+    int32_t* sc = reinterpret_cast<int32_t*>(stage + n);
+    hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, sc, sg, perm, n);
+    hipLaunchKernelGGL(copy_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, sc, sg, n);
     if (vel3) {
         hipLaunchKernelGGL(gather3_kernel, grid_for(n), dim3(kBlock), 0, st, vel3, stage, perm, n);
         e = hipMemcpyAsync(vel3, stage, 24 * (size_t)n, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gather_kernel<int32_t>), grid_for(n), dim3(kBlock), 0, st, cell, (int32_t*)stage, perm, n);
-    e = hipMemcpyAsync(cell, stage, 4 * (size_t)n, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
