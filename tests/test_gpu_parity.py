@@ -867,3 +867,33 @@ def test_rank_direct_ingest_equals_whole_mesh_ingest(setup, gpu_ctx_factory, n_p
         c.step(1e-4, 0.0, 30)
         out.append(c.get_particles())
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+
+
+def test_empty_shard_entry_points(setup, gpu_ctx_factory):
+    """A rank whose cell range holds no particle calls every *_dev entry point with n = 0: nothing may be launched
+    with an empty grid, nothing written, no error."""
+    import torch
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+    mesh = setup["mesh"]
+    dev = torch.device("cuda", 0)
+    ctx = gpu_ctx_factory(); ctx.set_mesh(mesh); ctx.set_velocity(setup["pitz"]["U_uniform"])
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cloud = ShardedCloud(HipOps(ctx), [0, 100, mesh.n_cells], 1024, dev, rank=0, world=2, send_fraction=1.0)
+    sentinel = 123.5
+    cloud.x.fill_(sentinel); cloud.cell.fill_(7)
+    cloud.ops.step(cloud, 1e-4, 0.0, 0, 3, 0)
+    cloud.ops.step(cloud, 1e-4, 1e-6, 3, 2, L.STEP_FUSE_CYCLES)
+    cloud.ops.sort(cloud)
+    cloud.ops.locate(cloud)
+    cloud.ops.pack(cloud)
+    cloud.weights_dev = torch.ones(mesh.n_cells, dtype=torch.float64, device=dev)
+    cloud.ops.histogram(cloud, 1.0)
+    cloud.ops.cell_ranges(cloud)
+    cloud.ops.unpack(cloud, 0, cloud.recvbuf, 0)
+    cloud.ops.step_slice(cloud, 0, 0, 1e-4, 0.0, 0, 4, 0)
+    torch.cuda.synchronize()
+    assert int(cloud.nstay_dev.item()) == 0 and cloud.counts_dev[:2].tolist() == [0, 0]
+    assert float(cloud.weights_dev.abs().sum().item()) == 0.0
+    assert cloud.cell_lo_dev.tolist() == [0, 0, mesh.n_cells]            # no weight anywhere: all cuts at 0
+    assert bool((cloud.x == sentinel).all()) and bool((cloud.cell == 7).all())
