@@ -52,7 +52,7 @@ def parse():
                     help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
     return ap.parse_args()
