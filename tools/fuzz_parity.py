@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): randomised differential campaign, HIP (through the C-ABI) vs the CPU cell-walk
+statement, bit for bit.  Random graded/sheared hex blocks (tests/test_oracle_random._case), random cell-constant U,
+time steps that cross several cells and bounce off several walls; every case runs with the statistics on and off
+(two instantiations), plain and fused launches, sorted and unsorted clouds, and with exactly axis-aligned flow
+(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    import torch  # noqa: F401  (its HIP runtime first)
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import Context
+    from oracle import oracle as O
+    from test_oracle_random import _case
+    O.build()
+    cw = O.CellWalk()
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng, mesh, U, dt = _case(seed)
+        mode = seed % 4
+        if mode == 1:                                    # axis-aligned flow: whole families of faces have den == 0
+            amp = float(np.abs(U).max()) or 1.0
+            U = np.zeros_like(U); U[:, seed % 3] = rng.normal(size=U.shape[0]) * amp
+        if mode == 2:
+            dt = dt * 4                                  # many cells and walls per step
+        t = cw.build(mesh)
+        lo, hi = mesh.bounds()
+        n = int(rng.integers(1000, 60000))
+        xyz = rng.uniform(lo - 0.02 * (hi - lo), hi + 0.02 * (hi - lo), size=(n, 3))
+        ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+        x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
+        steps = [1, 5, 24]
+        for k in steps:
+            cw.step(x, y, z, c, dt, k, t, U, nthreads=cw.max_threads)
+        for stats in (0, 1):
+            for fused in (0, 1):
+                ctx = Context(0)
+                ctx.set_option("stats", stats)
+                ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+                ctx.locate_initial()
+                _, cell0 = ctx.get_particles()
+                ok = np.array_equal(cell0, ref0)
+                if (seed + fused) % 2 == 0:
+                    ctx.sort_by_cell()
+                for k in steps:
+                    ctx.step(dt, 0.0, k, L.STEP_FUSE_CYCLES if fused else 0)
+                xyzw, cell = ctx.get_particles()
+                ok = ok and np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) \
+                    and np.array_equal(xyzw[:, 2], z)
+                ctx.close()
+                if not ok:
+                    bad += 1
+                    nd = int((cell != c).sum())
+                    print("MISMATCH seed %d stats %d fused %d: %d cells differ, max |dx| %.3e" %
+                          (seed, stats, fused, nd, float(np.abs(xyzw[:, 0] - x).max())), flush=True)
+        if (seed - first) % 10 == 9:
+            print("... %d cases, %d mismatches, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+    print("fuzz done: %d cases x 4 configurations, %d mismatches" % (count, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
