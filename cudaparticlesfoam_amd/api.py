@@ -350,3 +350,77 @@ class CudaParticles:
 
     def close(self):
         self.ctx.close()
+
+
+class StagedCloud:
+    """The reference's stage-by-stage call surface on its own array layouts (Particle = double4 AoS,
+    vec4d disps / vels, int ids) -- cuda/common.h:32-77, query/ConvexQuery.h:33-46 -- over the
+    ``cpf_stage_*`` entry points.  Method names are the reference wrappers' names; ids are CELL ids
+    (reference: tet ids, cell = tet / 12).  Arrays live in device memory (``cpf_dev_alloc``); the
+    numpy accessors copy."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, int(n)
+        self._bufs = {}
+        for name, nbytes in (("P", 32 * n), ("vels", 32 * n), ("disps", 32 * n), ("ids", 4 * n)):
+            p = C.c_void_p()
+            ctx._ck(ctx.lib.cpf_dev_alloc(ctx.h, max(nbytes, 16), C.byref(p)))
+            ctx._ck(ctx.lib.cpf_dev_memset(ctx.h, p, 0, max(nbytes, 16)))
+            self._bufs[name] = p
+
+    def close(self):
+        for p in self._bufs.values():
+            self.ctx.lib.cpf_dev_free(self.ctx.h, p)
+        self._bufs = {}
+
+    def _put(self, name, a):
+        a = np.ascontiguousarray(a)
+        self.ctx._ck(self.ctx.lib.cpf_copy_to_device(self.ctx.h, self._bufs[name], _ptr(a), a.nbytes))
+
+    def _get(self, name, shape, dtype):
+        a = np.empty(shape, dtype)
+        self.ctx._ck(self.ctx.lib.cpf_copy_to_host(self.ctx.h, _ptr(a), self._bufs[name], a.nbytes))
+        return a
+
+    def set(self, xyzw=None, ids=None):
+        if xyzw is not None:
+            self._put("P", np.asarray(xyzw, np.float64).reshape(self.n, 4))
+        if ids is not None:
+            self._put("ids", np.asarray(ids, np.int32).reshape(self.n))
+
+    particles = property(lambda s: s._get("P", (s.n, 4), np.float64))
+    vels = property(lambda s: s._get("vels", (s.n, 4), np.float64))
+    disps = property(lambda s: s._get("disps", (s.n, 4), np.float64))
+    ids = property(lambda s: s._get("ids", (s.n,), np.int32))
+
+    def cudaInitParticles(self, lower, upper, order: int = 1):            # cuda/particles.cu:100-108
+        lo = np.ascontiguousarray(lower, dtype=np.float64); hi = np.ascontiguousarray(upper, dtype=np.float64)
+        self.ctx._ck(self.ctx.lib.cpf_stage_seed_box(self.ctx.h, self._bufs["P"], self.n, _ptr(lo), _ptr(hi), order))
+
+    def RTQuery(self):                                                    # query/RTQuery.cu:295-310
+        self.ctx._ck(self.ctx.lib.cpf_stage_locate_initial(self.ctx.h, self._bufs["P"], self._bufs["ids"], self.n))
+
+    def cudaReportParticles(self) -> int:                                 # cuda/particles.cu:763-775
+        out = C.c_int64()
+        self.ctx._ck(self.ctx.lib.cpf_stage_count_outside(self.ctx.h, self._bufs["ids"], self.n, C.byref(out)))
+        return out.value
+
+    def cudaAdvect(self, dt: float):                                      # cuda/particles.cu:403-448
+        b = self._bufs
+        self.ctx._ck(self.ctx.lib.cpf_stage_advect(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
+
+    def cudaBrownianMotion(self, dt: float, D: float, step: int):         # cuda/particles.cu:577-599
+        b = self._bufs
+        self.ctx._ck(self.ctx.lib.cpf_stage_brownian(self.ctx.h, b["P"], b["disps"], dt, self.n, D, step))
+
+    def convexTetQuery(self):                                             # query/ConvexQuery.cu:218-234
+        b = self._bufs
+        self.ctx._ck(self.ctx.lib.cpf_stage_locate(self.ctx.h, b["P"], b["disps"], b["ids"], self.n))
+
+    def convexWallReflect(self):                                          # query/ConvexQuery.cu:438-458
+        b = self._bufs
+        self.ctx._ck(self.ctx.lib.cpf_stage_reflect(self.ctx.h, b["ids"], b["P"], b["vels"], b["disps"], self.n))
+
+    def cudaMoveParticles(self):                                          # cuda/particles.cu:706-716
+        b = self._bufs
+        self.ctx._ck(self.ctx.lib.cpf_stage_move(self.ctx.h, b["P"], b["disps"], self.n))

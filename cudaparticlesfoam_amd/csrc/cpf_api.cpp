@@ -51,7 +51,8 @@ struct cpf_context {
     int sortInterval = 50;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
     uint32_t lastSortStep = 0;
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
-    int stepVariant = 3;                        // cpf_set_option("step_variant"), see include/cpf.h
+    int stepVariant = 4;                        // cpf_set_option("step_variant"), see include/cpf.h
+    cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
     // asynchronous output (cpf_write_vtu_async): one frame in flight
     std::thread writer;
     bool writerLive = false;
@@ -215,6 +216,13 @@ int cpf_create(int device, cpf_context** out) {
     e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->streamState.d_grab, cpf::kStreamGrabBytes);
+    if (e == hipSuccess) e = hipMemset(ctx->streamState.d_grab, 0, cpf::kStreamGrabBytes);
+    if (e == hipSuccess) {
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        if (e == hipSuccess && cus > 0) ctx->streamState.numCU = cus;
+    }
     if (e != hipSuccess) {
         std::string m = std::string("cpf_create: ") + hipGetErrorString(e);
         if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -232,7 +240,7 @@ int cpf_destroy(cpf_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     freeMesh(ctx); freeCloud(ctx);
-    freeDev(ctx->scratch); freeDev(ctx->d_counters);
+    freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -426,7 +434,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant));
+                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
+                                      &ctx->streamState));
         if (timed) {
             CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             ctx->events.emplace_back(e0, e1);
@@ -528,8 +537,27 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
     const std::string k(key);
     if (k == "step_variant") {
-        CPF_REQUIRE(ctx, value >= 0 && value <= 3 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..3");
+        CPF_REQUIRE(ctx, value >= 0 && value <= 4 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..4");
         ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    if (k == "stream_tiles_per_chunk") {
+        CPF_REQUIRE(ctx, value >= 1 && value <= 1024 && value == (int)value, CPF_ERR_ARG, "stream_tiles_per_chunk must be 1..1024");
+        ctx->streamState.tilesPerChunk = (int)value;
+        return CPF_OK;
+    }
+    if (k == "stream_tail_fraction") {
+        CPF_REQUIRE(ctx, value >= 0 && value <= 1, CPF_ERR_ARG, "stream_tail_fraction must be in [0, 1]");
+        ctx->streamState.tailFraction = value;
+        return CPF_OK;
+    }
+    if (k == "stream_debug") {
+        ctx->streamState.debug = (int)value;
+        return CPF_OK;
+    }
+    if (k == "stream_waves_per_cu") {
+        CPF_REQUIRE(ctx, value >= 0 && value <= 32 && value == (int)value, CPF_ERR_ARG, "stream_waves_per_cu must be 0..32 (0 = auto)");
+        ctx->streamState.wavesPerCU = (int)value;
         return CPF_OK;
     }
     if (k == "sort_interval") {

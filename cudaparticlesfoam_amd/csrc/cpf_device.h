@@ -29,9 +29,28 @@ struct GridView {
     const int32_t* binCells;
 };
 
+// Host-side state of the streaming step kernel (cpf_stream.hip): two sets of per-group chunk counters (a launch
+// uses one and zeroes the other for the launch after it on the same stream) and the tuning knobs.
+constexpr size_t kStreamGrabBytes = 2 * 256 * 16 * sizeof(unsigned);
+struct StreamState {
+    unsigned* d_grab = nullptr;
+    int parity = 0;
+    int numCU = 256;
+    int tilesPerChunk = 4;    // "stream_tiles_per_chunk"
+    int wavesPerCU = 0;       // "stream_waves_per_cu": 0 = what the occupancy query says
+    double tailFraction = 0.1;  // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch
+    int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
+};
+
+// ss == nullptr: the streaming variant is not available (falls back to the wave-cooperative kernel)
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
-                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant);
+                       bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
+                       StreamState* ss);
+hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                              double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
+                              bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                              StreamState& ss);
 hipError_t launch_locate_initial(hipStream_t st, const double* x, const double* y, const double* z, int32_t* cell,
                                  int64_t n, const MeshView& m, const GridView& g);
 hipError_t launch_seed_box(hipStream_t st, double* x, double* y, double* z, int64_t first, int64_t n,

@@ -1,0 +1,526 @@
+// Streaming step kernel (gfx950 / CDNA4, wave64) for all-hex meshes.
+//
+// Same fused cycle and the same per-particle arithmetic as step_kernel_coop (cpf_kernels.hip) -- advect -> Brownian
+// kick -> plane-exit walk -> wall reflect -> move, src/advect.H:96-161 -- organised around what the measurements of
+// that kernel say bounds it: a wave that walks has no HBM request in flight, so the particle
+// stream and the walk ADD instead of overlapping, and every round of the walk pays an L2 round trip for its records.
+//
+//   * The grid is persistent: single-wave workgroups, as many as the chip holds.  A wave works through CHUNKS of
+//     64-particle tiles; chunks are dealt per wave GROUP from per-group counters (see StreamArgs).
+//   * While a wave walks tile t, tile t+1 is on its way from HBM straight into the wave's LDS (global_load_lds: no
+//     destination register, so nothing the register allocator may copy, spill or reuse before the data lands) and
+//     the stores of tile t-1 have just been issued.  All of these are inline assembly: hipcc's s_waitcnt placement
+//     is a conservative data-flow over the memory operations it can SEE, and with them visible every round of the walk
+//     began with "s_waitcnt vmcnt(0)".  The kernel waits for them itself, once, where a tile ends; the only wait
+//     inside the walk is the counted one for records that were missing on chip (vmcnt(number of younger operations)).
+//   * The cell records a wave needs live in a per-wave LDS cache whose tags survive from round to round and from
+//     tile to tile.  The cloud is kept sorted by (cell, sub-box), a chunk sits in one or two cells and their
+//     downstream neighbours, so after a chunk's first tile almost every round finds all its records on chip and
+//     issues no memory request at all.  Tags live in ONE vector register (lane k = the cell in slot k): the lookup
+//     is a compare against the scalar cell id per distinct cell of the wave, the update one predicated move.
+//
+// Crossing particles are not compacted into dense waves: what compaction is meant to buy -- finished lanes' slots
+// going to particles whose loads are already in flight -- is what the prefetch does at tile granularity, and the
+// sort key (cell, position in the cell's box) keeps the lanes of a tile in step.
+#include "cpf_walk.h"
+
+#include <type_traits>
+
+namespace cpf {
+
+#ifndef CPF_STREAM_SLOTS
+#define CPF_STREAM_SLOTS 6
+#endif
+#ifndef CPF_STREAM_WAVES
+#define CPF_STREAM_WAVES 6
+#endif
+constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
+#ifndef CPF_STREAM_GROUPS
+#define CPF_STREAM_GROUPS 256
+#endif
+constexpr int kStreamGroups = CPF_STREAM_GROUPS;        // wave groups sharing a chunk counter (power of two, <= 256)
+constexpr int kStreamCounterStride = 16;                 // unsigned words between two counters (64 B)
+static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
+
+// ------------------------------------------------------------------------------------------------
+// memory operations the COMPILER must not keep books on (see the head of this file)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {           // byte address inside the workgroup's LDS
+    return (unsigned)(uintptr_t)(lds_cptr)p;
+}
+// a value the program knows to be wave-uniform, pinned to scalar registers (the "s" operands below need it)
+__device__ __forceinline__ unsigned uniform32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const unsigned lo = uniform32((unsigned)v), hi = uniform32((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// 16 bytes per active lane, global -> LDS[ldsDst + 16 * lane id], no register in between.  Pending LDS reads are
+// retired first (the DMA must not overtake a read of the bytes it replaces); M0 is restored (compiler-reserved).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned ldsDst) {
+    unsigned keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
+}
+// (s_nop 4: a scalar base the compiler has just restored from a spill lane with v_readlane must not be read by a
+// vector-memory instruction within five wait states; hipcc pads its own instructions, not the inside of an asm)
+__device__ __forceinline__ void async_store(double* base, unsigned byteOff, double v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" : : "v"(byteOff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_store(int32_t* base, unsigned byteOff, int v) {
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(byteOff), "v"(v), "s"(base) : "memory");
+}
+// returning atomic increment, complete when the statement ends (the caller masks it to one lane)
+__device__ __forceinline__ unsigned grab_sync(unsigned* base) {
+    unsigned r;
+    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(0u), "v"(1u), "s"(base) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+template <bool BROWNIAN, bool STORE_VEL, bool STATS>
+struct StreamOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? CPF_STREAM_WAVES : 1; };
+
+// Work distribution.  ONE global chunk counter does not work: returning atomics on one address are served at about
+// one per 12 ns chip-wide (measured: 78 125 grabs = 0.97 ms for a zero-cycle launch), and every wave's next grab
+// queues behind every other wave's.  So the waves form kStreamGroups groups (block id mod kStreamGroups; where a
+// wave runs does not matter), group g owns the chunks g, g + G, g + 2G, ... -- evenly spaced samples of the sorted
+// cloud, so every group sees the same mix of slow (inlet, fine cells) and fast regions -- and has its own counter,
+// 64 bytes from the next; within a group the chunks are dealt first come, first served -- the first one included: a
+// wave that only starts when others have finished (a grid larger than what is resident at once: the occupancy
+// query was one wave per CU too optimistic in the measurements) then finds its group's counter exhausted and exits,
+// instead of sitting on a statically assigned chunk until the end of the launch (measured: a 20 us tail).
+// The counter set is double-buffered: a launch zeroes the set the NEXT launch uses.
+struct StreamArgs {
+    unsigned* grab;        // this launch's kStreamGroups counters, kStreamCounterStride apart
+    unsigned* grabNext;    // the other set: zeroed here for the next launch on the stream
+    int wavesPerGroup;     // grid = kStreamGroups * wavesPerGroup single-wave workgroups
+    int tilesPerChunk;
+    unsigned bigChunks;    // chunks 0 .. bigChunks-1 have tilesPerChunk tiles; every chunk after them is ONE tile: the tail
+                           // of the launch is dealt in small pieces, so that all waves finish within a tile's time of
+                           // each other (measured with 4-tile chunks throughout: the last wave 20 us after the median)
+    int debug;             // diagnostics only (results are wrong): 1 = no stores, 2 = no loads after a wave's first tile
+};
+
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS>
+__global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_stream(
+    double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, int32_t* __restrict__ cell,
+    const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
+    int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
+    constexpr int NS = kStreamSlots;
+    constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
+    __shared__ double4 slots[NS][8];                 // the wave's record cache
+    __shared__ unsigned sCnt[4];
+    __shared__ double sLane[6][64];                  // per-lane end point E and last wall hit point (see step_kernel_coop)
+    // landing zone of the next tile: x[64] | y[64] | z[64] | cell[64] (int32) | gid[64] (Brownian only)
+    __shared__ double sPre[BROWNIAN ? 288 : 224];
+    double(*sE)[64] = sLane;
+    double(*sHit)[64] = sLane + 3;
+    const int lane = threadIdx.x;
+    const unsigned ul = threadIdx.x;                 // unsigned lane index: scalar base + 32-bit lane offset addressing
+    const unsigned preBase = uniform32(lds_addr(sPre));
+    const unsigned slotBase = uniform32(lds_addr(slots));
+    const int tpc = sa.tilesPerChunk;
+    const int64_t nTiles = (n + 63) >> 6;
+    const unsigned long long big = sa.bigChunks;
+    // first tile of chunk c, and how many of its tiles exist (0: the chunk lies past the end of the cloud)
+    auto chunk_first = [&](unsigned long long c) -> int64_t {
+        return c < big ? (int64_t)c * tpc : (int64_t)big * tpc + (int64_t)(c - big);
+    };
+    auto chunk_tiles = [&](unsigned long long c, int64_t firstTile) -> int {
+        const int64_t k = nTiles - firstTile;
+        const int64_t want = c < big ? (int64_t)tpc : (int64_t)1;
+        return (int)(k < 0 ? 0 : (k < want ? k : want));
+    };
+    StepStats st = {0, 0, 0, 0};
+#ifdef CPF_STREAM_TIMELINE
+    // diagnostic build only (tools/stream_timeline.py): per wave start / end time (100 MHz), tiles and rounds done,
+    // written to the `vel` array of a launch that does not store velocities
+    const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
+    unsigned tlTiles = 0, tlRounds = 0;
+#endif
+
+    for (unsigned k = blockIdx.x; k < (unsigned)kStreamGroups; k += gridDim.x)
+        if (lane == 0) sa.grabNext[k * kStreamCounterStride] = 0u;
+    const unsigned grp = blockIdx.x & (kStreamGroups - 1);
+    unsigned* const myGrab = sa.grab + grp * kStreamCounterStride;
+
+    // Requests tile t: full tiles by LDS-DMA (returns the number of memory operations issued), the cloud's last,
+    // partial tile by ordinary masked loads (complete when the function returns: 0).
+    auto prefetch = [&](int64_t t) __attribute__((always_inline)) -> int {
+        const int64_t b = uniform64(t * 64);
+        const int64_t left = n - b;
+        if (left >= 64) {
+            const char* s1 = (ul < 32u ? reinterpret_cast<const char*>(x + b) : reinterpret_cast<const char*>(y + b)) + (ul & 31u) * 16u;
+            glds16(s1, preBase);                                               // x -> [0, 512), y -> [512, 1024)
+            if (ul < 48u) {
+                const char* s2 = ul < 32u ? reinterpret_cast<const char*>(z + b) + ul * 16u
+                                          : reinterpret_cast<const char*>(cell + b) + (ul - 32u) * 16u;
+                glds16(s2, preBase + 1024u);                                   // z -> [1024, 1536), cell -> [1536, 1792)
+            }
+            if (BROWNIAN && gid != nullptr) {
+                if (ul < 32u) glds16(reinterpret_cast<const char*>(gid + b) + ul * 16u, preBase + 1792u);
+                return 3;
+            }
+            return 2;
+        }
+        const unsigned lim = (unsigned)(left - 1);
+        const unsigned l = ul < lim ? ul : lim;
+        const double vx = (x + b)[l], vy = (y + b)[l], vz = (z + b)[l];
+        const int vc = (cell + b)[l];
+        sPre[ul] = vx; sPre[64 + ul] = vy; sPre[128 + ul] = vz;
+        reinterpret_cast<int*>(sPre + 192)[ul] = vc;
+        if (BROWNIAN && gid != nullptr) reinterpret_cast<int64_t*>(sPre + 224)[ul] = (gid + b)[l];
+        return 0;
+    };
+
+    // chunk j of the group (j = what the group's counter returns) is chunk grp + G*j of the cloud
+    unsigned got0 = 0;
+    if (lane == 0) got0 = grab_sync(myGrab);
+    const unsigned long long chunk0 = (unsigned long long)grp + (unsigned long long)kStreamGroups * uniform32(got0);
+    if (chunk_tiles(chunk0, chunk_first(chunk0)) > 0) {
+        // tags of the record cache: lane k holds the cell id whose record sits in slot k (-1: none)
+        int tagv = -1;
+        unsigned fifo = 0;
+
+        int64_t tile = chunk_first(chunk0);
+        int tilesLeft = chunk_tiles(chunk0, tile);
+        (void)prefetch(tile);
+        wait_vmcnt<0>();
+
+        // results of the previous tile, stored one tile late
+        bool havePrev = false;
+        int64_t rtile = 0;
+        double rx = 0, ry = 0, rz = 0, rvx = 0, rvy = 0, rvz = 0;
+        int rc = 0;
+        bool rhad = false;
+        unsigned rlim = 63;
+
+        for (;;) {
+            tile = uniform64(tile);
+            // ---- take the tile out of the landing zone
+            const int64_t tileLeft = n - tile * 64;
+            const unsigned plim = (unsigned)(tileLeft < 64 ? tileLeft : (int64_t)64) - 1u;   // last lane with a particle slot
+            double px = sPre[ul], py = sPre[64 + ul], pz = sPre[128 + ul];
+            int pc = reinterpret_cast<const int*>(sPre + 192)[ul];
+            uint64_t pid = 0;
+            if (BROWNIAN) pid = gid ? (uint64_t) reinterpret_cast<const int64_t*>(sPre + 224)[ul] : (uint64_t)(tile * 64 + ul);
+            if (ul > plim) pc = CPF_CELL_FROZEN;
+
+            int cur = pc;
+            const bool hadParticle = cur >= 0;
+            bool valid = hadParticle;
+            D3 P = {px, py, pz}, v = {0, 0, 0};
+            const uint64_t id = pid;
+
+            // where the wave goes next
+            int64_t ntile = -1;
+            int ntilesLeft = 0;
+
+            // Once per tile, right after round 1's missing records have been REQUESTED: the next chunk if this is the
+            // chunk's last tile, the previous tile's stores, the next tile's loads.  Returns how many of these
+            // operations are certainly younger than the record requests: s_waitcnt vmcnt(that many) then lets
+            // exactly the records complete.
+            auto hook = [&]() __attribute__((always_inline)) -> int {
+                int younger = 0;
+                __builtin_amdgcn_sched_barrier(0);
+                if (tilesLeft > 1) {
+                    ntile = tile + 1;
+                    ntilesLeft = tilesLeft - 1;
+                } else {
+                    unsigned got = 0;
+                    if (lane == 0) got = grab_sync(myGrab);
+                    const unsigned j = uniform32(got);
+                    const unsigned long long nxt = (unsigned long long)grp + (unsigned long long)kStreamGroups * j;
+                    const int64_t ft = chunk_first(nxt);
+                    const int nt = chunk_tiles(nxt, ft);
+                    if (nt > 0) { ntile = ft; ntilesLeft = nt; }
+                }
+                if (havePrev && !(sa.debug & 1)) {
+                    const int64_t b = uniform64(rtile * 64);
+                    if (STORE_VEL && rhad) {
+                        double* vv = vel + 3 * b;
+                        async_store(vv, ul * 24u, rvx); async_store(vv + 1, ul * 24u, rvy); async_store(vv + 2, ul * 24u, rvz);
+                    }
+                    if (ul <= rlim) {
+                        async_store(x + b, ul * 8u, rx); async_store(y + b, ul * 8u, ry); async_store(z + b, ul * 8u, rz);
+                        async_store(cell + b, ul * 4u, rc);
+                    }
+                    younger += 4;
+                }
+                if (ntile >= 0 && !(sa.debug & 2)) younger += prefetch(ntile);
+                __builtin_amdgcn_sched_barrier(0);
+                return younger;
+            };
+
+            // ---- per-cycle walk state (step_kernel_coop's state machine)
+            bool busy = false, needAdvect = false, reflected = false, lostNow = false;
+            int token = INT32_MIN, h = 0, j = 0;
+            D3 S_ = P;
+
+            auto cycle_begin = [&](int c) __attribute__((always_inline)) {
+                if (valid && cur < 0) { cur = CPF_CELL_FROZEN; valid = false; }      // lost in the previous cycle: w = 0
+                busy = valid; needAdvect = busy; reflected = false; lostNow = false;
+                token = INT32_MIN; h = 0; j = 0;
+                S_ = P;
+                if (STATS && busy) ++st.steps;
+                if (BROWNIAN && busy) {                                              // see step_kernel_coop
+                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+                    sHit[0][lane] = xi.x; sHit[1][lane] = xi.y; sHit[2][lane] = xi.z;
+                }
+            };
+
+            auto round = [&](auto withHook) __attribute__((always_inline)) {
+#ifdef CPF_STREAM_TIMELINE
+                ++tlRounds;
+#endif
+                // ---- record cache lookup, one scalar iteration per DISTINCT cell of the busy lanes (one or two after
+                // a sort).  A round that finds every cell on chip (the common case) issues no memory request.
+                const unsigned long long busyMask = ballot64(busy);
+                int myslot = -1;
+                unsigned used = 0;
+                unsigned long long todo = busyMask, missLanes = 0ull;
+                while (todo != 0ull) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int ck = __builtin_amdgcn_readlane(cur, leader);
+                    const bool mine = cur == ck;
+                    const unsigned long long same = ballot64(mine) & busyMask;
+                    const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)ck, 32 /* eq */);
+                    if (hitTag != 0ull) {
+                        const int sl = __ffsll((long long)hitTag) - 1;
+                        used |= 1u << sl;
+                        if (mine) myslot = sl;
+                    } else {
+                        missLanes |= same;
+                    }
+                    todo &= ~same;
+                }
+                // ---- misses: up to four records per round, each a 256-byte LDS-DMA by lanes 0..15 straight into its
+                // slot; victims are taken oldest-first among the slots nobody reads this round
+                int nJobs = 0;
+                if (missLanes != 0ull) {
+#define CPF_JOB(J)                                                                                          \
+                    if (missLanes != 0ull && used != ALL) {                                                 \
+                        const int leader = __ffsll((long long)missLanes) - 1;                               \
+                        const int ck = __builtin_amdgcn_readlane(cur, leader);                              \
+                        const unsigned cand = ~used & ALL;                                                  \
+                        const unsigned hi = cand & (ALL << fifo) & ALL;                                     \
+                        const int victim = __ffs((int)(hi ? hi : cand)) - 1;                                \
+                        fifo = (unsigned)(victim + 1) == (unsigned)NS ? 0u : (unsigned)(victim + 1);          \
+                        used |= 1u << victim;                                                               \
+                        if (lane == victim) tagv = ck;                                                      \
+                        const bool mine = cur == ck;                                                        \
+                        if (mine) myslot = victim;                                                          \
+                        missLanes &= ~ballot64(mine);                                                       \
+                        if (ul < 16u)                                                                       \
+                            glds16(reinterpret_cast<const char*>(m.cellRec) + (int64_t)ck * 256 + ul * 16u,  \
+                                   uniform32(slotBase + (unsigned)victim * 256u));                          \
+                        nJobs = J + 1;                                                                      \
+                    }
+                    CPF_JOB(0) CPF_JOB(1) CPF_JOB(2) CPF_JOB(3)
+#undef CPF_JOB
+                }
+                int younger = 0;
+                if (decltype(withHook)::value) younger = hook();
+                if (nJobs != 0) {
+                    // the requested records are older than everything the hook issued: wait for exactly them
+                    if (younger >= 7) wait_vmcnt<7>();
+                    else if (younger == 6) wait_vmcnt<6>();
+                    else if (younger >= 4) wait_vmcnt<4>();
+                    else if (younger >= 2) wait_vmcnt<2>();
+                    else wait_vmcnt<0>();
+                }
+                // ---- every busy lane does one cell visit
+                if (busy) {
+                    int next, outSlot = 0;
+                    double4 wallPlane = {0, 0, 0, 0};
+                    D3 E = S_;
+                    if (!needAdvect) E = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                    if (myslot >= 0) {
+                        const double4* rec = &slots[0][0] + myslot * 8;
+                        if (needAdvect) {
+                            const double4 u = rec[6];
+                            v = {u.x, u.y, u.z};
+                            const D3 Pn = axpy(dt, v, P);                              // particles.cu:355-362
+                            D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                            if (BROWNIAN) {                                            // the deviates drawn in cycle_begin
+                                const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                                disp = axpy(sigma, xi, disp);
+                            }
+                            E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                            sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                            needAdvect = false;
+                        }
+                        next = trace_lds6(S_, E, cur, rec, token, outSlot);
+                        // the wall's plane is read HERE, where the record's address space is known: one expression
+                        // choosing between the LDS slot and the global record becomes a flat load (vmcnt + lgkmcnt 0)
+                        if (REFLECT && next < 0) wallPlane = rec[outSlot];
+                    } else {
+                        // no slot: more distinct new cells in the wave than the round can place (a cloud that is not
+                        // kept sorted).  Per-lane gathers keep such a wave moving.
+                        const double4* rec = m.cellRec + 8 * (int64_t)cur;
+                        if (needAdvect) {
+                            const double4 u = rec[6];
+                            v = {u.x, u.y, u.z};
+                            const D3 Pn = axpy(dt, v, P);
+                            D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                            if (BROWNIAN) {
+                                const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                                disp = axpy(sigma, xi, disp);
+                            }
+                            E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                            sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                            needAdvect = false;
+                        }
+                        next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                        // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending at
+                        // the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
+                        if (REFLECT && next < 0) {
+                            wallPlane = rec[outSlot];
+                            asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
+                        }
+                    }
+                    if (STATS) ++st.hops;
+                    if (next == cur) {
+                        busy = false;                                              // segment ends in this cell
+                    } else if (next < 0) {                                         // boundary face
+                        if (!REFLECT) { busy = false; lostNow = true; }
+                        else {
+                            // mirror end point and velocity about the wall (ConvexQuery.cu:286-309)
+                            sHit[0][lane] = S_.x; sHit[1][lane] = S_.y; sHit[2][lane] = S_.z;
+                            reflected = true; if (STATS) ++st.refl;
+                            const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
+                            const double sd = dot3(wallPlane, E) - wallPlane.w;
+                            E = axpy(-2.0 * sd, nn, E);
+                            sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                            v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
+                            token = next;
+                            h = 0;
+                            if (++j == kMaxReflect) { busy = false; lostNow = true; }  // still on a wall after 5 bounces
+                        }
+                    } else {
+                        token = cur;
+                        cur = next;
+                        if (++h == kMaxHops) busy = false;                             // hop cap: keep the last cell
+                    }
+                }
+            };
+
+            auto cycle_end = [&]() __attribute__((always_inline)) {
+                // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit; else P + disp == E
+                if (valid) {
+                    const D3 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                    if (reflected) {
+                        const D3 hit = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                        P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
+                    } else P = E;
+                    if (lostNow) { cur = CPF_CELL_LOST; if (STATS) ++st.lost; }
+                }
+            };
+
+            if (nCyc > 0) {
+                cycle_begin(0);
+                round(std::true_type{});                    // always runs (it carries the hook), even with no busy lane
+                while (ballot64(busy) != 0ull) round(std::false_type{});
+                cycle_end();
+                for (int c = 1; c < nCyc; ++c) {
+                    cycle_begin(c);
+                    while (ballot64(busy) != 0ull) round(std::false_type{});
+                    cycle_end();
+                }
+            } else {
+                (void)hook();                                // zero cycles: loads + stores only (bandwidth calibration)
+            }
+
+            // everything this tile's hook issued has landed (the next tile in LDS) or been accepted (the stores)
+            wait_vmcnt<0>();
+#ifdef CPF_STREAM_TIMELINE
+            ++tlTiles;
+#endif
+            // ---- this tile's results wait in registers until the next tile's hook.  Every lane of the tile stores
+            // x, y, z and the cell: a frozen or lost particle gets the bytes it was loaded with (and CPF_CELL_FROZEN),
+            // which keeps the NUMBER of stores per tile fixed -- the counted wait above needs it
+            rtile = tile; havePrev = true;
+            rx = P.x; ry = P.y; rz = P.z;
+            if (STORE_VEL) { rvx = v.x; rvy = v.y; rvz = v.z; }
+            rc = hadParticle ? cur : CPF_CELL_FROZEN;
+            rhad = hadParticle;
+            rlim = plim;
+            if (ntile < 0) break;
+            tile = ntile; tilesLeft = ntilesLeft;
+        }
+        // ---- the last tile's results
+        {
+            const int64_t b = rtile * 64;
+            if (ul <= rlim) { (x + b)[ul] = rx; (y + b)[ul] = ry; (z + b)[ul] = rz; (cell + b)[ul] = rc; }
+            if (STORE_VEL && rhad) {
+                double* vv = vel + 3 * b;
+                vv[3 * ul] = rvx; vv[3 * ul + 1] = rvy; vv[3 * ul + 2] = rvz;
+            }
+        }
+    }
+#ifdef CPF_STREAM_TIMELINE
+    if (!STORE_VEL && vel != nullptr && lane == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(vel) + 4 * (uint64_t)blockIdx.x;
+        o[0] = tl0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tlTiles; o[3] = tlRounds;
+    }
+#endif
+    if (STATS) flush_stats(st, counters, sCnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher: persistent grid sized by the occupancy of the instantiation
+// ------------------------------------------------------------------------------------------------
+template <bool B, bool R_, bool SV, bool ST>
+static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                                     double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
+                                     uint32_t seed, const MeshView& m, unsigned long long* counters, StreamState& ss) {
+    static int wavesPerCU = 0;                       // per instantiation; benign race (same value)
+    if (wavesPerCU == 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream<B, R_, SV, ST>, 64, 0);
+        if (e != hipSuccess) return e;
+        wavesPerCU = nb < 1 ? 1 : (nb > 32 ? 32 : nb);
+    }
+    const int64_t nTiles = (n + 63) >> 6;
+    const int64_t slotsOnChip = (int64_t)(ss.wavesPerCU > 0 ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
+    // small clouds: shorter chunks, so that every wave slot still gets several
+    int tpc = ss.tilesPerChunk;
+    while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc >>= 1;
+    // the first (1 - tailFraction) of the cloud in chunks of tpc tiles, the rest tile by tile
+    int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - ss.tailFraction));
+    if (tpc == 1 || bigChunks < 0) bigChunks = 0;
+    const int64_t nChunks = bigChunks + (nTiles - bigChunks * tpc);
+    int64_t R = slotsOnChip / kStreamGroups;                 // waves per group
+    const int64_t need = (nChunks + kStreamGroups - 1) / kStreamGroups;
+    if (R > need) R = need;
+    if (R < 1) R = 1;
+    unsigned* cur = ss.d_grab + (size_t)(ss.parity & 1) * kStreamGroups * kStreamCounterStride;
+    unsigned* nxt = ss.d_grab + (size_t)((ss.parity & 1) ^ 1) * kStreamGroups * kStreamCounterStride;
+    StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug};
+    hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
+                       gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
+    ss.parity ^= 1;
+    return hipGetLastError();
+}
+
+hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                              double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
+                              bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                              StreamState& ss) {
+#define CPF_STREAM_GO(B, R, SV, ST) \
+    return launch_stream_inst<B, R, SV, ST>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss)
+#define CPF_STREAM_SV(B, R)                                                                     \
+    do {                                                                                        \
+        if (storeVel) { if (counters) CPF_STREAM_GO(B, R, true, true); else CPF_STREAM_GO(B, R, true, false); } \
+        else { if (counters) CPF_STREAM_GO(B, R, false, true); else CPF_STREAM_GO(B, R, false, false); }        \
+    } while (0)
+    if (brown) { if (reflect) CPF_STREAM_SV(true, true); else CPF_STREAM_SV(true, false); }
+    else { if (reflect) CPF_STREAM_SV(false, true); else CPF_STREAM_SV(false, false); }
+#undef CPF_STREAM_SV
+#undef CPF_STREAM_GO
+}
+
+}  // namespace cpf

@@ -1,0 +1,241 @@
+// Device-side helpers shared by the step kernels (cpf_kernels.hip, cpf_stream.hip): the plane-exit test of one
+// cell visit in its three data-source flavours, the Philox/Box-Muller deviates and the statistics reduction.
+// Arithmetic contract: see the head of cpf_kernels.hip (explicit fma() only, -ffp-contract=off, IEEE division).
+#pragma once
+#include "cpf_device.h"
+
+namespace cpf {
+
+// Wave-wide vote on a bool.  HIP's ballot64(int) first turns the predicate into 0/1 in a VGPR and compares it
+// again (two VALU instructions per vote on a kernel that is VALU-issue bound); the builtin takes the i1 as is.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+
+__device__ __forceinline__ double dot3(const double4& n, const D3& v) {
+    return fma(n.z, v.z, fma(n.y, v.y, n.x * v.x));
+}
+__device__ __forceinline__ double dot3(const D3& n, const D3& v) {
+    return fma(n.z, v.z, fma(n.y, v.y, n.x * v.x));
+}
+// signed plane distance (Cf - P).n = d - n.P as one fma chain (<= 0 on the inner side of the face)
+__device__ __forceinline__ double plane_dist(const double4& pl, const D3& P) {
+    return fma(-pl.z, P.z, fma(-pl.y, P.y, fma(-pl.x, P.x, pl.w)));
+}
+__device__ __forceinline__ D3 axpy(double s, const D3& a, const D3& b) {
+    return {fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)};
+}
+
+constexpr double kTol = 1e-13;     // query/ConvexQuery.cu:42
+constexpr int kMaxHops = 50;       // query/ConvexQuery.cu:169
+constexpr int kMaxReflect = 5;     // query/ConvexQuery.cu:353
+
+// One cell of the walk: traceIntet (query/ConvexQuery.cu:32-131) on a polyhedral cell.
+// Exit through the face slot with the smallest admissible dT in (tol, 1]; the slot we came in
+// through (nbr == token) is skipped.  Returns the next cell (== cur: segment ends here; < 0:
+// boundary code) and advances S to the exit point.
+__device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const MeshView& m, int token,
+                                             int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur;
+    double dTmin = 1.1;
+    const int s0 = m.cellOff[cur], s1 = m.cellOff[cur + 1];
+    for (int s = s0; s < s1; ++s) {
+        const double4 pl = m.planes[s];
+        const double fd = plane_dist(pl, P0);           // (Cf - P0).n  (<= 0 inside)
+        double dT = fd / dot3(pl, Pd);
+        if (__builtin_isinf(dT)) dT = -1.0;             // segment parallel to the face
+        const int nb = m.nbr[s];
+        if (nb == token) continue;
+        if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) {
+            dTmin = dT;
+            next = nb;
+            S = axpy(dT, Pd, P0);
+            outSlot = s;
+        }
+    }
+    return next;
+}
+
+// Same test for meshes whose cells all have NF faces (every mesh the reference can run is all-hex,
+// src/initCuda.H:64): slot s of cell c is 6c+s, loads are issued back to back, and the IEEE
+// division is only executed for faces that can still be accepted.  The pre-filter is EXACT, not
+// approximate: with fd and den of equal sign, fl(fd/den) <= 1  <=>  |fd| <= |den| (1 is
+// representable and rounding is monotone; |fd| > |den| gives a quotient >= 1 + 2^-52), a zero or
+// opposite-sign pair can never give dT > tol, and den == 0 / NaN fall out of every comparison
+// exactly like the isinf -> -1 substitution of ConvexQuery.cu:89.
+// `pl`/`nb` may be wave-uniform pointers (scalar loads, one fetch per wave) or per-lane ones.
+template <int NF, bool SKIP_ZERO_DEN>
+__device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const double4* __restrict__ pl,
+                                           const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 1.1;
+#pragma unroll
+    for (int s = 0; s < NF; ++s) {
+        const double4 p = pl[s];
+        const double den = dot3(p, Pd);
+        // no lane of the wave moves across this face's plane (den == +-0 exactly, e.g. the front/back
+        // faces of a one-cell-thick mesh, or wall-parallel faces in aligned flow): dT would be +-inf
+        // (-> -1) or NaN, never accepted (ConvexQuery.cu:86-95), so the face costs nothing more
+        // (only worth a branch when the planes are already on chip: it would serialise global gathers)
+        if (SKIP_ZERO_DEN && ballot64(den != 0.0) == 0ull) continue;
+        const int bs = nb[s];
+        const double fd = plane_dist(p, P0);
+        // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
+        // NaNs that slip through give dT = 0 / NaN and fail dT > tol below, as in the reference
+        const bool c1 = fabs(fd) <= fabs(den), c2 = (__double2hiint(fd) ^ __double2hiint(den)) >= 0;
+        const bool c3 = fd < kTol, c4 = bs != token;
+        const bool cand = c1 && c2 && c3 && c4;
+        // wave-uniform skip: hipcc would otherwise if-convert and run the ~12-instruction IEEE division for
+        // every face of every lane; most faces have no candidate lane at all.  The vote is the AND of the four
+        // compare masks (scalar ALU); voting on `cand` itself makes the compiler rebuild it as 0/1 in a VGPR.
+        if ((ballot64(c1) & ballot64(c2) & ballot64(c3) & __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
+            if (cand) {
+                const double dT = fd / den;
+                if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
+            }
+        }
+    }
+    if (best >= 0) {                   // exit point of the LAST accepted face == the smallest dT
+        S = axpy(dTmin, Pd, P0);
+        outSlot = slotBase + best;
+    }
+    return next;
+}
+
+// The same six-face test for a hex record sitting in LDS (wave-cooperative kernel).  Identical arithmetic and
+// acceptance order; what differs is the SCHEDULE: the planes are fetched two at a time in straight-line code
+// before the wave-uniform skips, so a round pays three LDS round trips instead of six (the per-face branches keep
+// the compiler from hoisting the reads itself, and this kernel is bound by the length of each wave's dependent
+// chain, not by instruction issue).
+__device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0, const D3& Pd, int token, int s,
+                                          double& dTmin, int& next, int& best) {
+    const double den = dot3(p, Pd);
+    if (ballot64(den != 0.0) == 0ull) return;          // see trace_fixed: nobody crosses this plane
+    const double fd = plane_dist(p, P0);
+    // c2 only prunes divisions (a face the lane moves away from): "den < 0 or fd >= 0" holds whenever the exact
+    // condition "equal sign bits" can still lead to an accepted face, and whatever else slips through has a
+    // quotient <= 0 and fails dT > tol below, exactly as in the reference -- two compares instead of a 64-bit xor
+    // and an integer compare
+    const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
+    const bool c3 = fd < kTol, c4 = bs != token;
+    if ((ballot64(c1) & (ballot64(den < 0.0) | ballot64(fd >= 0.0)) & ballot64(c3) &
+         __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
+        if (c1 && c2 && c3 && c4) {
+            const double dT = fd / den;
+            if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
+        }
+    }
+}
+
+__device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 2.0;                 // any start value > 1 is equivalent (candidates have dT <= 1); 2.0 is an inline constant
+    const int2* nb = reinterpret_cast<const int2*>(rec + 7);
+    {
+        const double4 p0 = rec[0], p1 = rec[1];
+        const int2 b = nb[0];
+        face_test(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
+        face_test(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
+    }
+    {
+        const double4 p2 = rec[2], p3 = rec[3];
+        const int2 b = nb[1];
+        face_test(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
+        face_test(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
+    }
+    {
+        const double4 p4 = rec[4], p5 = rec[5];
+        const int2 b = nb[2];
+        face_test(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
+        face_test(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
+    }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        outSlot = best;
+    }
+    return next;
+}
+
+// step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
+enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4 };
+
+// Where a walk gets its mesh data from.  Every tracer runs the same arithmetic in the same order.
+template <int VARIANT>
+struct GlobalTracer {
+    const MeshView& m;
+    __device__ __forceinline__ int trace(D3& S, const D3& E, int cur, int token, int& outSlot) const {
+        if (VARIANT == kVariantGeneric) return trace_in_cell(S, E, cur, m, token, outSlot);
+        if (VARIANT == kVariantFixedScalar) {
+            // particles are kept sorted by cell, so most waves sit in ONE cell for their first visit:
+            // fetch that cell's planes once per wave through the scalar cache instead of 64 times
+            const int ucur = __builtin_amdgcn_readfirstlane(cur);
+            if (ballot64(cur != ucur) == 0ull)
+                return trace_fixed<6, false>(S, E, cur, m.planes + 6 * (int64_t)ucur, m.nbr + 6 * (int64_t)ucur, token,
+                                      outSlot, 6 * ucur);
+        }
+        return trace_fixed<6, false>(S, E, cur, m.planes + 6 * (int64_t)cur, m.nbr + 6 * (int64_t)cur, token, outSlot,
+                              6 * cur);
+    }
+    __device__ __forceinline__ double4 velocity(int cur) const { return m.U[cur]; }
+};
+
+// Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
+// 48-byte-per-particle cuRAND XORWOW state of cuda/particles.cu:524-575 with nothing at all.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ D3 normal3(uint64_t gid, uint32_t step, uint32_t seed) {
+    uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0u};
+    philox4x32_10(c, seed, 0x43504631u);
+    const double s = 1.0 / 4294967296.0;
+    const double u0 = ((double)c[0] + 0.5) * s, u1 = ((double)c[1] + 0.5) * s;
+    const double u2 = ((double)c[2] + 0.5) * s, u3 = ((double)c[3] + 0.5) * s;
+    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    double sn, cs;
+    // sincospi / cospi reduce the argument exactly (the CPU statement computes cos(2*pi*u) with libm: the two agree
+    // to a few ulp of the argument, far inside the 1e-12 the libm-vs-device log already differs by) and are 4 %
+    // of the Brownian kernel cheaper than sincos(2*pi*u)
+    sincospi(2.0 * u1, &sn, &cs);
+    return {r0 * cs, r0 * sn, r1 * cospi(2.0 * u3)};
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+struct StepStats { unsigned steps, hops, refl, lost; };
+
+// block-level counter reduction: 4 global atomics per block, sharded over kCounterSlots slots
+__device__ __forceinline__ void flush_stats(StepStats st, unsigned long long* __restrict__ counters, unsigned* sCnt) {
+    if (counters == nullptr) return;             // statistics switched off (cpf_set_option "stats" 0)
+    if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    st.steps = wave_sum(st.steps); st.hops = wave_sum(st.hops); st.refl = wave_sum(st.refl); st.lost = wave_sum(st.lost);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sCnt[0], st.steps); atomicAdd(&sCnt[1], st.hops);
+        atomicAdd(&sCnt[2], st.refl); atomicAdd(&sCnt[3], st.lost);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && sCnt[threadIdx.x])
+        atomicAdd(&counters[(blockIdx.x & (kCounterSlots - 1)) * 4 + threadIdx.x], (unsigned long long)sCnt[threadIdx.x]);
+}
+
+}  // namespace cpf

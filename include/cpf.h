@@ -167,7 +167,11 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "step_variant"  0 generic CSR walk (any polyhedral mesh; forced when a cell is not a hex)
  *                   1 all-hex fixed-slot walk, per-lane gathers
  *                   2 + wave-uniform plane fetches through the scalar cache
- *                   3 (default) wave-cooperative LDS cell cache on packed 256-byte cell records
+ *                   3 wave-cooperative LDS cell cache on packed 256-byte cell records, one block per 128 particles
+ *                   4 (default) streaming kernel: persistent waves, next tile prefetched into LDS while the current
+ *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip)
+ *   "stream_tiles_per_chunk" (4), "stream_tail_fraction" (0.1), "stream_waves_per_cu" (0 = occupancy query):
+ *                   work distribution of variant 4; "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference
  *                   has no such diagnostics, and they cost the step kernel a resident wave (0.16 -> 0.22 ms
  *                   per 1e7-particle launch)

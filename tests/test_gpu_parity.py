@@ -52,7 +52,7 @@ def test_initial_locate_matches_bruteforce(setup):
     assert n_out == int((ref < 0).sum()) and 0 < n_out < n
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
 def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     """Every kernel variant (generic CSR walk, all-hex fixed-slot walk, + wave-uniform scalar plane fetches,
@@ -86,7 +86,7 @@ def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     assert c1["cells_visited"] - c0["cells_visited"] == hops
     assert c1["reflections"] - c0["reflections"] == refl
     assert refl > 0   # the case does exercise wall reflection
-    ctx.set_option("step_variant", 3)
+    ctx.set_option("step_variant", 4)
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -693,7 +693,7 @@ def test_ragged_sizes(setup, n):
     ref_c = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t)
     x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref_c.copy()
     cw.step(x, y, z, c, 1e-4, 25, t, U)
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         ctx.set_option("step_variant", variant)
         ctx.set_particles(xyz)
         ctx.locate_initial()
@@ -701,7 +701,7 @@ def test_ragged_sizes(setup, n):
         ctx.step(1e-4, 0.0, 25)
         xyzw, cell = ctx.get_particles()
         assert np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y)
-    ctx.set_option("step_variant", 3)
+    ctx.set_option("step_variant", 4)
 
 
 def test_all_particles_outside_the_mesh(setup):

@@ -9,11 +9,13 @@ OUT=gpurun_out/pmc_sweep; rm -rf "$OUT"; mkdir -p "$OUT"
 SETS=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM_RD"
- "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM"
+ "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
+ "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH"
+ "GRBM_GUI_ACTIVE GRBM_COUNT"
 )
 k=0
 for S in "${SETS[@]}"; do
-  rocprofv3 --kernel-trace --pmc $S --output-format csv -d "$OUT/set$k" -- python3 tools/sweep.py --variants "$VARS" --steps 6 --warmup 2 "$@" > "$OUT/set$k.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $S --output-format csv -d "$OUT/set$k" -- python3 tools/sweep.py --no-floor --variants "$VARS" --steps 6 --warmup 2 "$@" > "$OUT/set$k.log" 2>&1
   k=$((k+1))
 done
 python3 - <<PY

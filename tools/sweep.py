@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--D", type=float, default=0.0, help="diffusion coefficient (Brownian kick on when > 0)")
     ap.add_argument("--store-vel", action="store_true", help="also store the velocity per particle (output cycles)")
+    ap.add_argument("--opt", action="append", default=[], help="cpf_set_option key=value (repeatable), e.g. stream_tiles_per_chunk=8")
+    ap.add_argument("--label", default="")
+    ap.add_argument("--no-floor", action="store_true", help="skip the zero-cycle launches (they would mix into PMC means)")
     args = ap.parse_args()
     import torch
     import bench
@@ -48,6 +51,9 @@ def main():
     rows = []
     if args.no_stats:
         ctx.set_option("stats", 0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, float(v))
     for v in [int(s) for s in args.variants.split(",")]:
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
@@ -67,9 +73,12 @@ def main():
             ref = (x, y, z, c)
         else:
             same = bool(torch.equal(x, ref[0]) and torch.equal(y, ref[1]) and torch.equal(z, ref[2]) and torch.equal(c, ref[3]))
-        rows.append(dict(variant=v, kernel_ms=round(avg, 4), gps=round(n / avg / 1e6, 2), gbs=round(56 * n / avg / 1e6, 1),
+        rows.append(dict(label=args.label, opts=args.opt, variant=v, kernel_ms=round(avg, 4), gps=round(n / avg / 1e6, 2), gbs=round(56 * n / avg / 1e6, 1),
                          identical_to_first=same))
         print(json.dumps(rows[-1]), flush=True)
+    if args.no_floor:
+        ctx.close()
+        return
     # IO floor: same loads/stores, zero cycles (no walk)
     from cudaparticlesfoam_amd import _lib as L
     x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
