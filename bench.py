@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mparticle-steps/s of the fused advect+locate+reflect+move cycle on the
-pitzDaily mesh (12 225 cells), uniform U = (10,0,0) m/s, dt = 1e-4 s, D = 0, 1e7 fp64 particles per GPU
-seeded over the whole fluid domain (BASELINE.json configs[2]).
+pitzDaily mesh (12 225 cells), uniform U = (10,0,0) m/s, dt = 1e-4 s, D = 0, fp64 particles seeded over the
+whole fluid domain.  --gpus 1: 1e7 particles (BASELINE.json configs[2]).  --gpus N > 1:
+the north star's scaling experiment, 1e8 particles IN TOTAL sharded over the N ranks (configs[3]; "strong").
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -34,8 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU (weak) / total (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--particles", type=float, default=None,
+                    help="particles per GPU (weak) / in total (strong); default 1e7 at --gpus 1, 1e8 in total at --gpus N > 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: weak at --gpus 1 (one GPU, 1e7), strong at --gpus N > 1 (1e8 in total)")
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
     ap.add_argument("--exchange-interval", type=int, default=0,
                     help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
@@ -55,7 +58,18 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
-    return ap.parse_args()
+    ap.add_argument("--steady-steps", type=int, default=-1,
+                    help="after the timed region: that many more steps (default: one full sort interval, N = 1 only) "
+                         "timed the same way, reported as ms_per_step_steady (the periodic re-sort included); 0 = skip")
+    ap.add_argument("--brownian-extra", type=int, default=20,
+                    help="after the timed region (N = 1): that many launches with the tutorial's D = 1.5e-5, reported "
+                         "as config.brownian; 0 = skip")
+    a = ap.parse_args()
+    if a.scaling is None:
+        a.scaling = "weak" if a.gpus == 1 else "strong"
+    if a.particles is None:
+        a.particles = 1e7 if (a.gpus == 1 or a.scaling == "weak") else 1e8
+    return a
 
 
 def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None):
@@ -216,6 +230,7 @@ def main():
     ctx.timing_enable(True)
     ctx.timing_read()                              # drop the warm-up launches' events
     handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
+    hhost0, ncomm0 = cloud.handoff_host_ms, len(cloud._comm_events)
     torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
     cloud.step(dt, args.steps)
@@ -226,6 +241,12 @@ def main():
     launches += cloud.kernel_launches - launches0; kernel_ms += cloud.kernel_ms - ms0
     psteps = cloud.particle_steps - psteps0
     ctx.timing_enable(False)
+    handoff_host_ms = cloud.handoff_host_ms - hhost0
+    comm_events = cloud._comm_events[ncomm0:]
+    handoff_comm_ms = 0.0
+    for a_, b_ in comm_events:
+        b_.synchronize(); handoff_comm_ms += a_.elapsed_time(b_)
+    rccl_ranks = dist.get_world_size() if (world > 1 or args.force_dist) else 1
     per_rank = [cloud.n]
     if world > 1:
         tn = torch.tensor([cloud.n], dtype=torch.int64, device=device)
@@ -258,6 +279,39 @@ def main():
                  "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
                  "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
 
+    # Outside the timed region, single GPU: (1) steady state -- one full sort interval, so the periodic re-sort the
+    # short window may miss is in; (2) the tutorial's diffusion coefficient (pitzDaily/system/cudaParticlesDict:
+    # diffusionCoeff 1.5e-5): another instantiation of the same kernel, never `value`.
+    steady = None
+    brown = None
+    if world == 1 and not args.force_dist:
+        k = args.steady_steps if args.steady_steps >= 0 else (0 if args.no_sort else args.sort_interval)
+        if k > 0:
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            cloud.step(dt, k)
+            torch.cuda.synchronize()
+            steady = {"steps": k, "ms_per_step": round((time.perf_counter() - ts) / k * 1e3, 4),
+                      "sorts_inside": (cloud.step_index // max(1, cloud.sort_interval)) -
+                                      ((cloud.step_index - k) // max(1, cloud.sort_interval)) if cloud.sort_interval else 0}
+        if args.brownian_extra > 0:
+            Db = 1.5e-5
+            cloud.step(dt, 3, D=Db)
+            torch.cuda.synchronize()
+            ctx.timing_enable(True); ctx.timing_read()
+            tb = time.perf_counter()
+            cloud.step(dt, args.brownian_extra, D=Db)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            lb, msb = ctx.timing_read()
+            ctx.timing_enable(False)
+            kb = msb / max(lb, 1)
+            bytes_b = ALGO_BYTES_PER_PARTICLE_STEP + 8          # + the 8-byte particle id the Philox counter needs
+            brown = {"D": Db, "ms_per_step": round(tb / args.brownian_extra * 1e3, 4), "kernel_avg_ms": round(kb, 4),
+                     "kernel": ctx.step_kernel_name(Db, 0), "algorithmic_bytes_per_particle_step": bytes_b,
+                     "achieved_GBs": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
+                     "frac": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kb > 0 else None}
+
     if rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
@@ -278,8 +332,13 @@ def main():
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "pitzDaily 12225-cell polyMesh (blockMeshDict restated), %s U, dt 1e-4, D 0, "
-                                   "%d fp64 particles/GPU seeded over the fluid domain, all boundaries reflecting"
-                                   % ("uniform (10,0,0)" if args.field == "uniform" else "analytic step-flow", n_local),
+                                   "%s, all boundaries reflecting"
+                                   % ("uniform (10,0,0)" if args.field == "uniform" else "analytic step-flow",
+                                      ("%d fp64 particles on one GPU seeded over the fluid domain (BASELINE configs[2])" % n_total)
+                                      if world == 1 else
+                                      ("%d fp64 particles in total sharded over %d GPUs by x-slab, mesh replicated, RCCL "
+                                       "all-to-all hand-off (BASELINE configs[3], %s scaling; --gpus 1 runs the 1e7 single-GPU "
+                                       "config)" % (n_total, world, args.scaling))),
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
                        "rebalance_interval": args.rebalance_interval if world > 1 else None,
@@ -288,14 +347,23 @@ def main():
                                    if (world > 1 or args.force_dist) else None),
                        "particles_per_rank_at_end": per_rank if world > 1 else None,
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
-                                                     if world > 1 else None),
+                                                     if (world > 1 or args.force_dist) else None),
+                       "rccl_ranks": rccl_ranks,
+                       "ms_in_handoff": ({"host_ms_total": round(handoff_host_ms, 3), "collectives_device_ms_total": round(handoff_comm_ms, 3),
+                                          "handoffs": len(comm_events),
+                                          "host_ms_per_step": round(handoff_host_ms / max(1, args.steps), 4)}
+                                         if (world > 1 or args.force_dist) else None),
+                       "ms_per_step_steady": steady, "brownian": brown,
                        "extra_fused_cycles": fused,
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
                        "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "cpf::step_kernel_coop<false,true,false,false>", "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
+                         "traffic_source": ("profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                            "this command, tools/profile_run.sh; not collected in this run)" if traffic is not None
+                                            else None),
+                         "kernel": ctx.step_kernel_name(0.0, 0), "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
                          "launches": launches, "launches_sampled_every": args.timing_stride, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PARTICLE_STEP * per_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,7 @@ SIGNATURES = {
     "cpf_get_counters": (_int, [_ctx, _vp]),
     "cpf_set_seed": (_int, [_ctx, _u32]),
     "cpf_set_option": (_int, [_ctx, C.c_char_p, _dbl]),
+    "cpf_step_kernel_name": (_int, [_ctx, _dbl, C.c_uint, C.c_char_p, C.c_size_t]),
     "cpf_step_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _u32, _int, C.c_uint]),
     "cpf_locate_initial_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),
     "cpf_seed_box_dev": (_int, [_ctx, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int]),

@@ -157,6 +157,11 @@ class Context:
     def set_option(self, key: str, value: float):
         self._ck(self.lib.cpf_set_option(self.h, key.encode(), float(value)))
 
+    def step_kernel_name(self, D: float = 0.0, flags: int = 0) -> str:
+        buf = C.create_string_buffer(200)
+        self._ck(self.lib.cpf_step_kernel_name(self.h, float(D), int(flags), buf, 200))
+        return buf.value.decode()
+
     def set_seed(self, seed: int):
         self._ck(self.lib.cpf_set_seed(self.h, seed & 0xFFFFFFFF))
 

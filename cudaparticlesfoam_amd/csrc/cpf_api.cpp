@@ -546,6 +546,22 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->streamState.tilesPerChunk = (int)value;
         return CPF_OK;
     }
+    if (k == "sort_key_bits") {
+        // sub-cell sort key layout: 100*bx + 10*by + bz bits for the position inside the cell's box along x, y, z
+        // (most significant axis first as chosen at mesh ingest); default chosen by cpf_set_mesh
+        CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "sort_key_bits: call cpf_set_mesh first");
+        const int v = (int)value, nb[3] = {v / 100, (v / 10) % 10, v % 10};
+        CPF_REQUIRE(ctx, value == v && v >= 0 && nb[0] <= 9 && nb[0] + nb[1] + nb[2] <= 12, CPF_ERR_ARG, "sort_key_bits: at most 12 bits");
+        for (int a = 0; a < 3; ++a) {
+            const float f = std::ldexp(1.0f, nb[a] - ctx->host.subBits[a]);
+            for (size_t c = 0; c < ctx->host.cellBox.size() / 6; ++c) ctx->host.cellBox[6 * c + 3 + a] *= f;
+            ctx->host.subBits[a] = nb[a];
+        }
+        CPF_HIP(ctx, hipSetDevice(ctx->device));
+        CPF_HIP(ctx, hipMemcpyAsync(ctx->d_cellBox, ctx->host.cellBox.data(), ctx->host.cellBox.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return CPF_OK;
+    }
     if (k == "stream_tail_fraction") {
         CPF_REQUIRE(ctx, value >= 0 && value <= 1, CPF_ERR_ARG, "stream_tail_fraction must be in [0, 1]");
         ctx->streamState.tailFraction = value;
@@ -575,6 +591,21 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         return CPF_OK;
     }
     return fail(ctx, CPF_ERR_ARG, "cpf_set_option: unknown key '" + k + "'");
+}
+
+int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes) {
+    CPF_REQUIRE(ctx, ctx && buf && bufBytes > 0, CPF_ERR_ARG, "null argument");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_step_kernel_name: call cpf_set_mesh first");
+    const cpf::MeshView m = meshView(ctx);
+    const int v = cpf::effective_step_variant(ctx->stepVariant, m, true);
+    const char* b[2] = {"false", "true"};
+    const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
+    char tmp[160];
+    if (v == 4) snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
+    else if (v == 3) snprintf(tmp, sizeof tmp, "cpf::step_kernel_coop<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
+    else snprintf(tmp, sizeof tmp, "cpf::step_kernel<%d, %s, %s, %s>", v, b[brown], b[reflect], b[sv]);
+    snprintf(buf, bufBytes, "%s", tmp);
+    return CPF_OK;
 }
 
 int cpf_set_seed(cpf_context* ctx, uint32_t seed) {

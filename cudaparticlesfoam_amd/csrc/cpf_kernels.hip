@@ -334,6 +334,14 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
     }
 }
 
+int effective_step_variant(int variant, const MeshView& m, bool haveStream) {
+    if (!m.allHex) return kVariantGeneric;                    // fixed-slot variants need 6 faces per cell
+    if (variant == kVariantStream && !haveStream) variant = kVariantCoop;
+    // the wave-cooperative kernel addresses records with a 32-bit byte offset (256 B x 2^24 cells)
+    if (variant == kVariantCoop && m.nCells > kCoopMaxCells) variant = haveStream ? kVariantStream : kVariantFixedScalar;
+    return variant;
+}
+
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                        bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
@@ -342,10 +350,7 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
-    if (!m.allHex) variant = kVariantGeneric;                 // fixed-slot variants need 6 faces per cell
-    if (variant == kVariantStream && !ss) variant = kVariantCoop;
-    // the wave-cooperative kernel addresses records with a 32-bit byte offset (256 B x 2^24 cells)
-    if (variant == kVariantCoop && m.nCells > kCoopMaxCells) variant = ss ? kVariantStream : kVariantFixedScalar;
+    variant = effective_step_variant(variant, m, ss != nullptr);
     switch (variant) {
         case kVariantStream:
             return launch_step_stream(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m,

@@ -200,19 +200,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+// Three N(0,1) deviates for (particle gid, step) from ONE Philox block (definition 2 of the transform; parity with the
+// reference's cuRAND stream is statistical by contract, SURVEY.md 8c, so the arithmetic is free): Box-Muller on
+// 23-bit uniforms u = ((w >> 9) + 0.5) * 2^-23 in (0, 1), evaluated with the fp32 hardware transcendentals
+// (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32, whose argument is in revolutions: no 2*pi, no range reduction) --
+// words 0,1 give two deviates (one log, one sqrt), words 2,3 the third.  The fp64 version this replaces (two log, two
+// sqrt, sincospi + cospi in double) was a third of the Brownian kernel's time and cost it its occupancy; the
+// kick itself, disp += sigma * xi, stays an fp64 fma.  oracle/cellwalk.c states the same transform with libm.
 __device__ __forceinline__ D3 normal3(uint64_t gid, uint32_t step, uint32_t seed) {
     uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0u};
     philox4x32_10(c, seed, 0x43504631u);
-    const double s = 1.0 / 4294967296.0;
-    const double u0 = ((double)c[0] + 0.5) * s, u1 = ((double)c[1] + 0.5) * s;
-    const double u2 = ((double)c[2] + 0.5) * s, u3 = ((double)c[3] + 0.5) * s;
-    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double sn, cs;
-    // sincospi / cospi reduce the argument exactly (the CPU statement computes cos(2*pi*u) with libm: the two agree
-    // to a few ulp of the argument, far inside the 1e-12 the libm-vs-device log already differs by) and are 4 %
-    // of the Brownian kernel cheaper than sincos(2*pi*u)
-    sincospi(2.0 * u1, &sn, &cs);
-    return {r0 * cs, r0 * sn, r1 * cospi(2.0 * u3)};
+    const float s = 1.0f / 8388608.0f;                                    // 2^-23
+    const float u0 = ((float)(c[0] >> 9) + 0.5f) * s, u1 = ((float)(c[1] >> 9) + 0.5f) * s;
+    const float u2 = ((float)(c[2] >> 9) + 0.5f) * s, u3 = ((float)(c[3] >> 9) + 0.5f) * s;
+    const float k = -1.3862943611198906f;                                 // -2 ln 2: -2 ln u = k * log2 u
+    const float r0 = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u0));
+    const float r1 = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u2));
+    return {(double)(r0 * __builtin_amdgcn_cosf(u1)), (double)(r0 * __builtin_amdgcn_sinf(u1)),
+            (double)(r1 * __builtin_amdgcn_cosf(u3))};
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {

@@ -15,6 +15,7 @@ therefore decoupled from the step cadence.
 from __future__ import annotations
 
 import contextlib
+import time
 from typing import Optional, Sequence
 
 import numpy as np
@@ -82,6 +83,14 @@ class HipOps:
 
     def __init__(self, ctx):
         self.ctx = ctx
+        # ShardedCloud mixes torch operations (copies, cat, collectives, reallocation) with the context's kernels:
+        # they are only ordered if both run on the SAME stream, so the context is put on torch's current stream
+        # here instead of leaving that to the caller
+        if torch.cuda.is_available():
+            ctx.set_stream(torch.cuda.current_stream(torch.device("cuda", ctx.device)).cuda_stream)
+
+    def set_velocity(self, U):
+        self.ctx.set_velocity(U)
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):
@@ -180,6 +189,8 @@ class ShardedCloud:
         self.exchanges = 0
         self.rebalances = 0
         self.grown = 0               # times the arrays had to be enlarged for arrivals
+        self.handoff_host_ms = 0.0   # host wall time spent in the re-cut / split / exchange calls (incl. their one sync)
+        self._comm_events = []       # (start, end) device events around the collectives of every hand-off
         self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
         self.sort_interval = 0       # 0 = never; else re-sort by cell every that many steps (coalescing)
         self.force_collectives = False   # run the hand-off path even with one rank (single-GPU smoke of the N>1 code)
@@ -197,6 +208,21 @@ class ShardedCloud:
             self.ops.locate(self)
         else:
             self.cell[:n].copy_(cell)
+
+    def set_velocity(self, U):
+        """New cell velocities (transient solvers, src/advect.H:44-57).  A hand-off still in flight is completed
+        FIRST: its arrivals replay the cycles they missed in one launch, and that replay must see the field those
+        cycles were stepped with, not the new one."""
+        self._finish_exchange()
+        self.ops.set_velocity(U)
+
+    def comm_ms(self) -> float:
+        """Device time of the hand-off collectives so far (counts all-gather + payload all-to-all, side stream)."""
+        tot = 0.0
+        for a, b in self._comm_events:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        return tot
 
     # -- the hot loop
     def step(self, dt: float, n_cycles: int = 1, D: float = 0.0, flags: int = 0):
@@ -256,12 +282,14 @@ class ShardedCloud:
     def _begin_exchange(self):
         """Split the shard on the compute stream: leavers into the send buffer, stayers compacted into
         [0, nStay), the stale tail marked inactive.  Counts and nStay stay in device memory for now."""
+        t_host = time.perf_counter()
         self.ops.pack(self)
         ev = None
         if self._side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
         self._pending = {"step": self.step_index, "event": ev}
+        self.handoff_host_ms += (time.perf_counter() - t_host) * 1e3
 
     def _finish_exchange(self):
         """Counts all-gather + payload all-to-all-v on the side stream (the compute stream keeps running the
@@ -273,6 +301,7 @@ class ShardedCloud:
         p = self._pending
         if p is None:
             return
+        t_host = time.perf_counter()
         self._pending = None
         W = self.world
         D = L.HANDOFF_DOUBLES
@@ -280,6 +309,7 @@ class ShardedCloud:
         with side:
             if self._side is not None:
                 self._side.wait_event(p["event"])
+                ev0 = torch.cuda.Event(enable_timing=True); ev0.record(self._side)
             meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
             rows = [torch.empty_like(meta) for _ in range(W)]
             self.comm.all_gather(rows, meta, group=self.group)
@@ -299,8 +329,9 @@ class ShardedCloud:
             self.comm.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
                                    [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
             if self._side is not None:
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=True)
                 done.record(self._side)
+                self._comm_events.append((ev0, done))
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_event(done)   # also orders the next pack after this all-to-all
         missed = self.step_index - p["step"]
@@ -318,6 +349,7 @@ class ShardedCloud:
         if self._sort_due:
             self._sort_due = False
             self.sort()
+        self.handoff_host_ms += (time.perf_counter() - t_host) * 1e3
 
     def rebalance(self, n_cells: Optional[int] = None):
         """Re-cut the ranges (see ``_recut``) and hand particles to their new owners, synchronously."""
@@ -337,6 +369,7 @@ class ShardedCloud:
         Legal at any time because the mesh is replicated.  For a cloud that drifts with the flow the
         equal-count cuts drift with it, so re-cutting hands over far fewer particles than keeping the
         ranges fixed would (and nothing piles up on the outlet rank)."""
+        t_host = time.perf_counter()
         n_cells = self.n_cells if n_cells is None else int(n_cells)
         if self.weights_dev is None or self.weights_dev.numel() != n_cells:
             self.weights_dev = torch.zeros(n_cells, dtype=torch.float64, device=self.device)
@@ -347,6 +380,7 @@ class ShardedCloud:
         self.comm.all_reduce(self.weights_dev, group=self.group)
         self.ops.cell_ranges(self)
         self.rebalances += 1
+        self.handoff_host_ms += (time.perf_counter() - t_host) * 1e3
 
     def enable_time_balancing(self, on: bool = True):
         """Re-cut by measured cost instead of by particle count (must be set the same on every rank)."""

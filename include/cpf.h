@@ -178,7 +178,11 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "timing_stride" cpf_timing_enable brackets every k-th step launch only (default 1)
  *   "sort_interval" cpf_step re-sorts the context-owned cloud by cell every N cycles (default 50, 0 = never);
  *                   invisible to callers: cpf_get_particles always answers in particle-id order */
-int cpf_set_option(cpf_context* ctx, const char* key, double value);   /* Brownian stream; default 1591593751 (particles.cu:544) */
+int cpf_set_option(cpf_context* ctx, const char* key, double value);
+/* Name of the kernel instantiation cpf_step / cpf_step_dev launches for this diffusion coefficient and these flags with
+ * the current mesh and options, as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false>"):
+ * lets a benchmark label its roofline with what actually ran. */
+int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes);   /* Brownian stream; default 1591593751 (particles.cu:544) */
 
 /* ---------------------------------------------------------------------------------------------
  * device-array level (framework hosts that own the particle arrays, multi-GPU sharding)

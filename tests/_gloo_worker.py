@@ -21,6 +21,7 @@ def main():
     overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 0               # steps the loop runs on while a hand-off is in flight
     capacity = int(sys.argv[6]) if len(sys.argv) > 6 else 0              # 0: room for the whole cloud on every rank
     slow_rank0 = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # > 0: balance by "measured" time, rank 0 that much slower
+    u_step = int(sys.argv[7]) if len(sys.argv) > 7 else 0                # > 0: the velocity field changes after that many steps
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -49,7 +50,12 @@ def main():
     cloud.sort_interval = 7 if overlap else 0
     if slow_rank0:
         cloud.enable_time_balancing()
-    cloud.step(0.2, 30)
+    if u_step:
+        cloud.step(0.2, u_step)
+        cloud.set_velocity(U[::-1].copy() * 0.5)          # a transient solver's new field, mid hand-off window
+        cloud.step(0.2, 30 - u_step)
+    else:
+        cloud.step(0.2, 30)
     if interval > 1:
         cloud.exchange()
     total1 = cloud.global_count()

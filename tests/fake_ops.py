@@ -19,6 +19,9 @@ class FakeOps:
     def enable_timing(self, s):
         pass
 
+    def set_velocity(self, U):
+        self.U = np.ascontiguousarray(U, dtype=np.float64)
+
     def step_time(self, s, wait):
         out = (self._launches, self._ms)
         self._launches, self._ms = 0, 0.0

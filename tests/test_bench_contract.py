@@ -30,6 +30,20 @@ def _check(line, need_cpu_baseline):
     return d
 
 
+def test_defaults_follow_the_north_star(monkeypatch):
+    """--gpus 1 is the 1e7 single-GPU config (BASELINE configs[2]); --gpus N > 1 is configs[3]: 1e8 particles in
+    total over the N ranks, i.e. strong scaling -- unless the caller says otherwise."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for argv, want in ((["bench.py"], ("weak", 1e7)), (["bench.py", "--gpus", "1"], ("weak", 1e7)),
+                       (["bench.py", "--gpus", "8"], ("strong", 1e8)), (["bench.py", "--gpus", "2"], ("strong", 1e8)),
+                       (["bench.py", "--gpus", "4", "--scaling", "weak"], ("weak", 1e7)),
+                       (["bench.py", "--gpus", "4", "--particles", "2e7"], ("strong", 2e7))):
+        monkeypatch.setattr(sys, "argv", argv)
+        a = bench.parse()
+        assert (a.scaling, a.particles) == want, (argv, a.scaling, a.particles)
+
+
 def test_committed_round_profile_follows_the_contract():
     line = open(os.path.join(ROOT, "profiles", "r01_bench_1gpu.json")).read().strip()
     d = _check(line, need_cpu_baseline=True)
@@ -53,3 +67,13 @@ def test_bench_runs_and_prints_one_json_line(extra):
     d = _check(lines[0], need_cpu_baseline=False)
     assert d["steps"] == 6 and d["warmup"] == 2 and d["config"]["particles_total"] == 200_000
     assert d["config"]["particles_after"] == 200_000                      # every boundary reflects: nobody is lost
+    assert d["roofline"]["kernel"] == "cpf::step_kernel_stream<false, true, false, false>"   # what really ran
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None      # other launch size than the PMC run
+    if extra:
+        h = d["config"]["ms_in_handoff"]
+        assert d["config"]["rccl_ranks"] == 1 and h["handoffs"] >= 1 and h["host_ms_total"] > 0
+        assert h["collectives_device_ms_total"] > 0 and d["config"]["handoff_fraction_per_step"] is not None
+    else:
+        b, st = d["config"]["brownian"], d["config"]["ms_per_step_steady"]
+        assert b["D"] == 1.5e-5 and b["kernel"] == "cpf::step_kernel_stream<true, true, false, false>" and 0 < b["frac"] < 1
+        assert st["steps"] == 100 and st["sorts_inside"] == 1 and st["ms_per_step"] > 0

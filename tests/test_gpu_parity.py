@@ -266,10 +266,12 @@ def test_brownian_statistics_and_stream(setup, gpu_ctx_factory):
     sigma = np.sqrt(2 * D * dt)
     assert np.abs(d.mean(0)).max() < 5 * sigma / np.sqrt(n)
     assert np.abs(d.var(0) / sigma ** 2 - 1).max() < 0.02
-    # same counter-based stream as the CPU statement (libm vs device log/cos: 1e-12 relative)
-    for g in (0, 1, 77, n - 1):
+    # same counter-based stream as the CPU statement (libm in float vs the fp32 hardware log2 / sin / cos: 1e-6)
+    worst = 0.0
+    for g in list(range(0, 2000)) + [n - 1]:
         xi = cw.normal3(g, 0, 1234)
-        assert np.allclose(d[g], xi * sigma, rtol=1e-11, atol=1e-18)
+        worst = max(worst, float(np.abs(d[g] / sigma - xi).max()))
+    assert worst < 2e-5, worst
 
 
 def test_call_order_errors(gpu_ctx_factory, pitz):

@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _single_process_answer(oracle_libs):
+def _single_process_answer(oracle_libs, u_step=0):
     from cudaparticlesfoam_amd.cases import box_mesh
     from cudaparticlesfoam_amd.parallel import x_slab_renumbering
     m0 = box_mesh(12, 5, 4)
@@ -29,7 +29,11 @@ def _single_process_answer(oracle_libs):
     xyz = np.random.default_rng(8).uniform([0, 0, 0], [12, 5, 4], size=(6000, 3))
     x, y, z = (xyz[:, k].copy() for k in range(3))
     c = cw.locate_initial(x, y, z, t)
-    cw.step(x, y, z, c, 0.2, 30, t, U)
+    if u_step:
+        cw.step(x, y, z, c, 0.2, u_step, t, U)
+        cw.step(x, y, z, c, 0.2, 30 - u_step, t, U[::-1].copy() * 0.5, step0=u_step)
+    else:
+        cw.step(x, y, z, c, 0.2, 30, t, U)
     return x, y, z, c
 
 
@@ -55,6 +59,22 @@ def test_shard_grows_when_arrivals_exceed_its_slack(tmp_path, oracle_libs):
         g = d["gid"]
         assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
         assert np.array_equal(d["cell"], c[g])
+
+
+def test_velocity_update_inside_a_handoff_window(tmp_path, oracle_libs):
+    """A transient solver sets a new U between two step() calls while a hand-off is still in flight (4 overlapped
+    steps): ShardedCloud.set_velocity completes the hand-off first, so the arrivals replay their missed cycles with
+    the field those cycles were stepped with -- same particles as one process."""
+    out = str(tmp_path / "uchg")
+    _run_workers(2, out, 0, 5, 0, 4, 0, 13)                 # re-cut + hand-off every 5 steps, 4 overlapped, U changes after 13
+    x, y, z, c = _single_process_answer(oracle_libs, u_step=13)
+    seen = np.zeros(6000, bool)
+    for r in range(2):
+        d = np.load(out + ".rank%d.npz" % r)
+        g = d["gid"]; seen[g] = True
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g])
+    assert seen.all()
 
 
 def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_libs):

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--particles", type=float, default=1e7)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--label", default="")
+    ap.add_argument("--pre-steps", type=int, default=5, help="steps after the sort and before the measured launch")
     args = ap.parse_args()
     import torch
     import bench
@@ -32,13 +33,13 @@ def main():
     n = int(args.particles)
     x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
     g = torch.arange(n, dtype=torch.int64, device=dev)
-    ctx.sort_by_cell_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), g.data_ptr(), n)
     ctx.set_option("stats", 0); ctx.set_option("step_variant", 4)
     for kv in args.opt:
         k, v = kv.split("="); ctx.set_option(k, float(v))
+    ctx.sort_by_cell_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), g.data_ptr(), n)
     tl = torch.zeros(4 * 16384, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
-    for _ in range(5):
+    for _ in range(args.pre_steps):
         ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, 1, 0)
     torch.cuda.synchronize()
     tl.zero_()
