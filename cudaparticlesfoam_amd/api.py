@@ -309,6 +309,9 @@ class CudaParticles:
         self.outOfDomain = self.ctx.locate_initial()       # RTQuery + cudaReportParticles
         self.ctx.sort_by_cell()
         if self.writer is not None:
+            # frame 0 carries the velocities of one advect and out-of-domain particles as inactive, like the reference
+            # (src/initCuda.H:184-201): a cycle of zero length (moves nothing, does not count as a step)
+            self.ctx.step(0.0, 0.0, 1, L.STEP_STORE_VEL)
             self._write(0)
 
     def _flags(self, store_vel: bool) -> int:

@@ -10,6 +10,8 @@
 #include "query/RTQuery.h"
 #include "optix/OptixQuery.h"
 
+#include <cstring>
+
 #include "fvCFD.H"
 #include "case_io.H"
 

@@ -451,7 +451,10 @@ int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags)
     int r = cpf_step_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel, ctx->n, dt, D, ctx->stepCounter,
                          nCycles, flags);
     if (r != CPF_OK) return r;
-    ctx->stepCounter += (uint32_t)nCycles;
+    // a cycle of zero length without a kick moves nothing: it is the frame-0 idiom (velocities of one advect in the
+    // first output file, out-of-domain particles frozen; src/initCuda.H:184-201) and not a step of the run, so the
+    // counter-based Brownian stream and the sort cadence do not see it
+    if (!(dt == 0.0 && D == 0.0)) ctx->stepCounter += (uint32_t)nCycles;
     // keep waves cell-coherent: particle ids (and stored velocities) travel with the particles, so callers
     // never see the reordering
     if (ctx->sortInterval > 0 && ctx->stepCounter - ctx->lastSortStep >= (uint32_t)ctx->sortInterval) {
@@ -592,6 +595,14 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     }
     return fail(ctx, CPF_ERR_ARG, "cpf_set_option: unknown key '" + k + "'");
 }
+
+}  // extern "C"   (helper for the other translation units, C++ linkage)
+namespace cpf {
+void set_context_error(cpf_context* ctx, const char* message) {
+    if (ctx) ctx->err = message ? message : "";
+}
+}  // namespace cpf
+extern "C" {
 
 int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes) {
     CPF_REQUIRE(ctx, ctx && buf && bufBytes > 0, CPF_ERR_ARG, "null argument");

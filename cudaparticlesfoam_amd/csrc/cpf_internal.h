@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include "cpf.h"
+
 namespace cpf {
 
 // Host-built connectivity, laid out exactly as it is uploaded (DESIGN.md "Data layout in HBM").
@@ -34,5 +36,8 @@ extern template std::string build_tables<int32_t>(const double*, int64_t, const 
                                                   const int32_t*, const int32_t*, int64_t, int64_t, HostTables&);
 extern template std::string build_tables<int64_t>(const double*, int64_t, const int64_t*, const int64_t*, int64_t,
                                                   const int64_t*, const int64_t*, int64_t, int64_t, HostTables&);
+
+// stores `message` as the context's last error (cpf_last_error); for entry points implemented outside cpf_api.cpp
+void set_context_error(cpf_context* ctx, const char* message);
 
 }  // namespace cpf

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "cpf.h"
+#include "cpf_internal.h"
 
 struct cpf_merged_mesh {
     std::vector<double> points;
@@ -68,6 +69,7 @@ std::string merge_impl(const cpf_mesh_part* parts, int nParts, cpf_merged_mesh& 
     std::vector<Face> interior, boundary;
     std::unordered_map<FaceKey, size_t, FaceHash> open;         // unmatched boundary faces -> index into `boundary`
     std::vector<char> boundaryDead;
+    std::vector<int> boundaryPiece;                             // which piece a boundary face came from
     int64_t cellBase = 0;
     for (int p = 0; p < nParts; ++p) {
         const cpf_mesh_part& m = parts[p];
@@ -119,10 +121,18 @@ std::string merge_impl(const cpf_mesh_part* parts, int nParts, cpf_merged_mesh& 
             FaceKey key{face.verts};
             std::sort(key.v.begin(), key.v.end());
             auto it = open.find(key);
-            if (it == open.end()) {
+            if (it != open.end() && boundaryPiece[it->second] == p) {
+                // two coincident boundary faces INSIDE one piece are a baffle (a zero-thickness wall, legal in
+                // OpenFOAM), not a processor patch: both stay boundary faces, particles reflect off either side
+                if (boundary[it->second].owner == face.owner) return where + "a cell has the same boundary face twice";
+                boundary.push_back(std::move(face));
+                boundaryDead.push_back(0);
+                boundaryPiece.push_back(p);
+            } else if (it == open.end()) {
                 open.emplace(std::move(key), boundary.size());
                 boundary.push_back(std::move(face));
                 boundaryDead.push_back(0);
+                boundaryPiece.push_back(p);
             } else {
                 // the other side of a processor patch: one interior face, oriented out of the lower cell
                 Face& first = boundary[it->second];
@@ -210,7 +220,10 @@ int cpf_set_mesh_parts(cpf_context* ctx, const cpf_mesh_part* parts, int nParts)
     if (!ctx) return CPF_ERR_ARG;
     cpf_merged_mesh* m = nullptr;
     const int r = cpf_merge_mesh_parts(parts, nParts, &m);
-    if (r != CPF_OK) return r;                                 // reason: cpf_merge_last_error()
+    if (r != CPF_OK) {                                         // the reason also becomes the context's last error
+        cpf::set_context_error(ctx, cpf_merge_last_error());
+        return r;
+    }
     const int s = cpf_set_mesh_l64(ctx, m->points.data(), (int64_t)(m->points.size() / 3), m->faceOffsets.data(),
                                    m->faceVerts.data(), (int64_t)m->owner.size(), m->owner.data(), m->neighbour.data(),
                                    m->nInternal, m->nCells);

@@ -150,7 +150,14 @@ int cpf_locate_initial(cpf_context* ctx, int64_t* nOutside);
  * ConvexPoly build = cudaAdvect (particles.cu:403-448) -> cudaBrownianMotion (:577-599) ->
  * convexTetQuery (query/ConvexQuery.cu:218-234) -> convexWallReflect (:438-458) ->
  * cudaMoveParticles (particles.cu:706-716), fused into one kernel launch per cycle.
- * D = diffusionCoeff (0 adds exactly nothing, as in the reference). */
+ * D = diffusionCoeff (0 adds exactly nothing, as in the reference).
+ * Validity domain of one cycle: a segment is followed through at most 50 CELLS (the reference: 50 TETS of its
+ * 12-per-cell decomposition, query/ConvexQuery.cu:169, i.e. about a dozen cells) and at most 5 wall reflections
+ * (:353); where both give up, both keep the particle in the last cell reached, but for steps that long (more than
+ * ~12 cells per cycle) the two stop in different cells.  The tutorials move a particle 1-3 cells per cycle.
+ * dt == 0 with D == 0 is the frame-0 idiom (src/initCuda.H:184-201): nothing moves, CPF_STEP_STORE_VEL stores
+ * U[cell], out-of-domain particles become inactive, and the call does not count as a step of the run (the
+ * counter-based Brownian stream and the sort cadence do not advance). */
 int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags);
 /* Reorder the cloud by containing cell (coalesced mesh reads); ids travel with the particles. */
 int cpf_sort_by_cell(cpf_context* ctx);

@@ -27,11 +27,12 @@ def _expected(pitz, gpu_ctx_factory, D=0.0, cycles=35):
     return xyzw, cell, n_out
 
 
-def _run(binary, case, cwd):
+def _run(binary, case, cwd, n=None, extra=()):
     subprocess.run(["make", "-C", COMPAT, "-s"], check=True)
-    r = subprocess.run([os.path.join(COMPAT, "bin", binary), case], cwd=cwd, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(COMPAT, "bin", binary), case] + list(extra), cwd=cwd, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    n = DICT["numParticles"]
+    n = DICT["numParticles"] if n is None else n
     xyzw = np.fromfile(os.path.join(cwd, "particles_out.f64")).reshape(n, 4)
     cell = np.fromfile(os.path.join(cwd, "cells_out.i32"), dtype=np.int32)
     return xyzw, cell, r.stdout
@@ -55,6 +56,70 @@ def test_replacement_fragments_match_python_host(tmp_path, pitz, gpu_ctx_factory
     names = [l.split("Name='")[1].split("'")[0] for l in text if "Name='" in l]
     assert names == ["Position", "ParticleType", "ParticleID", "ParticleTetID", "ConvexTetID", "vels", "KEs",
                      "connectivity", "offsets", "types"]
+
+
+def _vtu_array(path, name, width):
+    lines = open(path).read().splitlines()
+    k = next(i for i, l in enumerate(lines) if "Name='%s'" % name in l)
+    rows = []
+    for l in lines[k + 1:]:
+        if l.startswith("<"):
+            break
+        rows.append([float(v) for v in l.split()])
+    return np.array(rows).reshape(-1, width)
+
+
+def test_frame_zero_carries_velocities_and_inactive_particles(tmp_path, pitz):
+    """particle_0000.vtu like the reference's (src/initCuda.H:184-201 runs one cudaAdvect before the first frame):
+    vels = U[cell], and a particle seeded outside the mesh is ParticleType 0 (cuda/particles.cu:333-338)."""
+    from case_dump import dump_case
+    d = dict(DICT, numParticles=3000, seedingBox=((-0.0215, 0.03, 0.0001), (0.0, 0.0, -0.0001)))   # sticks out of the inlet
+    case = str(tmp_path / "case")
+    dump_case(case, pitz["mesh"], pitz["U_analytic"], d, 1.0, 1e-4)
+    xyzw, cell, out = _run("mockUncoupledFoam", case, str(tmp_path), n=3000)
+    f0 = str(tmp_path / "particle_0000.vtu")
+    vels = _vtu_array(f0, "vels", 3); ptype = _vtu_array(f0, "ParticleType", 1)[:, 0]
+    pos = _vtu_array(f0, "Position", 3)
+    n_out = int(out.split("Out-of-domain particles(-tetID) = ")[1].split()[0])
+    assert 0 < n_out < 3000 and int((ptype == 0).sum()) == n_out
+    inside = ptype == 1
+    assert np.abs(vels[inside]).max() > 1.0 and np.abs(vels[~inside]).max() == 0.0
+    # U[cell] of the frozen step flow at the particles' own positions: compare with the host-side field lookup
+    from cudaparticlesfoam_amd.api import Context
+    with Context(0) as ctx:
+        ctx.set_mesh(pitz["mesh"]); ctx.set_velocity(pitz["U_analytic"])
+        ctx.set_particles(pos); ctx.locate_initial()
+        _, c0 = ctx.get_particles()
+    assert np.array_equal(c0 >= 0, inside)
+    assert np.allclose(vels[inside], pitz["U_analytic"][c0[inside]], rtol=0, atol=5e-7)      # "%.6f"-style precision
+
+
+@pytest.mark.parametrize("n_procs", [2, 4])
+def test_parallel_fragments_equal_the_serial_run(tmp_path, pitz, n_procs):
+    """The Pstream branch of the fragments (src/initCuda.H:207-484, src/advect.H:59-84): every "rank" hands its piece
+    of the decomposed mesh and its U slice to the master through gatherList, the master stitches them
+    (cpf_set_mesh_parts) and drives the GPU alone.  One process plays the ranks (mock Pstream); particles and output
+    frames must equal the serial run's bit for bit."""
+    from case_dump import dump_case
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    mesh, U = pitz["mesh"], pitz["U_analytic"]
+    case = str(tmp_path / "case")
+    dump_case(case, mesh, U, DICT, 1.0, DELTA_T)
+    ser = tmp_path / "serial"; ser.mkdir()
+    xs, cs, outs = _run("mockUncoupledFoam", case, str(ser))
+    parts = split_into_parts(mesh, n_procs)
+    first = 0
+    for r, part in enumerate(parts):
+        dump_case(os.path.join(case, "processor%d" % r), part, U[first:first + part.n_cells], DICT, 1.0, DELTA_T)
+        first += part.n_cells
+    par = tmp_path / "parallel"; par.mkdir()
+    xp, cp, outp = _run("mockParallelFoam", case, str(par), extra=[str(n_procs)])
+    assert np.array_equal(xp, xs) and np.array_equal(cp, cs)
+    assert "nCycles: 35" in outp
+    frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
+    assert frames == ["particle_%04d.vtu" % k for k in (0, 1, 11, 21, 31)]
+    for f in frames:
+        assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
 
 
 def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):

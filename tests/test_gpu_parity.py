@@ -899,3 +899,17 @@ def test_empty_shard_entry_points(setup, gpu_ctx_factory):
     assert float(cloud.weights_dev.abs().sum().item()) == 0.0
     assert cloud.cell_lo_dev.tolist() == [0, 0, mesh.n_cells]            # no weight anywhere: all cuts at 0
     assert bool((cloud.x == sentinel).all()) and bool((cloud.cell == 7).all())
+
+
+def test_merge_failure_is_reported_through_the_context(setup, gpu_ctx_factory):
+    """cpf_set_mesh_parts with a broken piece: CPF_ERR_MESH and the stitcher's reason in cpf_last_error(ctx)."""
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    parts = split_into_parts(setup["mesh"], 2)
+    parts[1].owner = parts[1].owner.copy(); parts[1].owner[3] = 10 ** 6
+    ctx = gpu_ctx_factory()
+    with pytest.raises(L.CpfError) as e:
+        ctx.set_mesh_parts(parts)
+    assert e.value.status == L.CPF_ERR_MESH
+    msg = ctx.lib.cpf_last_error(ctx.h).decode()
+    assert "piece 1" in msg and "owner" in msg

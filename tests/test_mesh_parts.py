@@ -51,3 +51,30 @@ def test_merge_handles_64bit_labels_negative_zero_and_bad_input():
     assert e.value.status == L.CPF_ERR_MESH and "piece 0" in str(e.value) and "owner" in str(e.value)
     with pytest.raises(L.CpfError):
         merge_mesh_parts([])
+
+
+def test_a_baffle_inside_a_piece_stays_a_wall():
+    """Two coincident boundary faces owned by two different cells of ONE piece are a baffle (a zero-thickness wall),
+    not a processor patch: the stitcher must keep both as boundary faces.  Faces that coincide across DIFFERENT
+    pieces are the cuts of the decomposition and are joined."""
+    from cudaparticlesfoam_amd.cases.polymesh import PolyMesh
+    mesh = box_mesh(4, 1, 1)
+    ni = mesh.n_internal
+    # turn the interior face between cells 0 and 1 into a baffle: the same vertex loop twice, once per side
+    fo, fv = np.asarray(mesh.face_offsets), np.asarray(mesh.face_verts)
+    faces = [fv[fo[f]:fo[f + 1]] for f in range(mesh.n_faces)]
+    k = next(f for f in range(ni) if {int(mesh.owner[f]), int(mesh.neighbour[f])} == {0, 1})
+    keep = [f for f in range(ni) if f != k]
+    new_faces = [faces[f] for f in keep] + [faces[f] for f in range(ni, mesh.n_faces)] + [faces[k], faces[k][::-1]]
+    owner = [int(mesh.owner[f]) for f in keep] + [int(mesh.owner[f]) for f in range(ni, mesh.n_faces)] + [0, 1]
+    neigh = [int(mesh.neighbour[f]) for f in keep]
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in new_faces])]).astype(np.int32)
+    baffled = PolyMesh(points=mesh.points.copy(), face_offsets=offs, face_verts=np.concatenate(new_faces).astype(np.int32),
+                       owner=np.asarray(owner, np.int32), neighbour=np.asarray(neigh, np.int32), n_cells=mesh.n_cells)
+    merged = merge_mesh_parts([baffled])                       # one piece: nothing may be joined
+    assert merged.n_internal == ni - 1 and merged.n_faces == mesh.n_faces + 1
+    parts = split_into_parts(baffled, 2)                       # cells {0,1} | {2,3}: the baffle lies inside piece 0
+    merged2 = merge_mesh_parts(parts)
+    assert merged2.n_internal == ni - 1 and merged2.n_faces == mesh.n_faces + 1
+    pairs = set(zip(np.asarray(merged2.owner[:merged2.n_internal]).tolist(), np.asarray(merged2.neighbour).tolist()))
+    assert (0, 1) not in pairs and (1, 2) in pairs             # the cut between the pieces WAS re-joined

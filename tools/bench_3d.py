@@ -23,6 +23,10 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_mesh(mesh)
+    if os.environ.get("CPF_VARIANT"):
+        ctx.set_option("step_variant", int(os.environ["CPF_VARIANT"]))
+    for kv in os.environ.get("CPF_OPTS", "").split():
+        k_, v_ = kv.split("="); ctx.set_option(k_, float(v_))
     fields = {"diagonal (10,2,1)": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
               "swirl": np.stack([10.0 + 0 * c[:, 0], 4 * np.sin(40 * c[:, 2]), 4 * np.cos(40 * c[:, 1])], 1)}
     torch.manual_seed(7)
