@@ -149,6 +149,15 @@ def test_two_ranks_drifting_cuts_overlapped_handoff(pitz, oracle_libs):
     assert abs(out[0]["n"] - out[1]["n"]) < 0.25 * 400_000            # equal cost, so roughly equal counts here
 
 
+def test_two_ranks_at_2e7_particles(pitz, oracle_libs):
+    """The two-rank path at the bench's per-GPU size (2 x 1e7): re-cut + hand-off every 6 steps, 2 overlapped,
+    balanced by measured time -- still bit-identical to one process."""
+    out, cell = _run_two_ranks(pitz, oracle_libs, n_total=20_000_000, steps=12, rebalance=6, exchange=0, overlap=2,
+                               balance_by_time=True, capacity=20_000_000 + 64)
+    assert all(o["rebalances"] == 2 for o in out) and sum(o["handed"] for o in out) > 100_000
+    assert sum(o["n"] for o in out) == 20_000_000
+
+
 def test_two_ranks_fixed_ranges_growing_shard(pitz, oracle_libs):
     """Fixed x-slabs, hand-off every 2 steps with 1 overlapped: the flow piles the cloud up on the downstream
     rank, whose arrays (capacity barely above the initial half) must grow on the device."""
