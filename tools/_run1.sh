@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-tools/ab2.sh --variants 4 --no-floor 2>&1 | grep variant
+timeout -s KILL 900 tools/profile_run.sh r02 2>&1 | tail -30
+timeout -s KILL 600 tools/profile_3d.sh r02 2>&1 | tail -30

@@ -7,15 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(ROOT, "gpurun_out", label + "_summary.json")))
 # the timed launches run the statistics-off instantiation, the warm-up launches the statistics-on one: take the
 # instantiation with the most launches
-ks = max((k for k in d["kernels"] if "step_kernel" in k["kernel"]), key=lambda k: k["calls"])
-pmc = max(d["pmc"].values(), key=lambda v: v["dispatches"]); cal = list(d["calibration_zero_cycle_step"].values())[0]
+main = "<false, true, false, false>"     # no Brownian kick, reflecting walls, no stored velocity, statistics off
+ks = max((k for k in d["kernels"] if "step_kernel" in k["kernel"] and main in k["kernel"]), key=lambda k: k["calls"])
+pmc = max((v for k, v in d["pmc"].items() if main in k), key=lambda v: v["dispatches"])
+cal = max(d["calibration_zero_cycle_step"].values(), key=lambda v: v["dispatches"])
 n = 10_000_000
 ff = (28 * n) / (cal["FETCH_SIZE_KB"] * 1024); wf = (28 * n) / (cal["WRITE_SIZE_KB"] * 1024)
 hbm = pmc["FETCH_SIZE_KB"] * 1024 * ff + pmc["WRITE_SIZE_KB"] * 1024 * wf
 out = dict(label=label, kernel=ks["kernel"].split("(")[0], particles_per_launch=n,
            rocprofv3_kernel_trace=dict(calls=ks["calls"], avg_us=round(ks["avg_us"], 2), min_us=round(ks["min_us"], 2),
                                        max_us=round(ks["max_us"], 2), pct_of_gpu_time=round(ks["pct"], 1),
-                                       note="the 100 timed launches of the bench command (statistics-off instantiation); the 10 warm-up launches run the statistics-on instantiation and are listed separately in the kernel stats"),
+                                       note="every launch of the headline instantiation in the bench command: the 100 timed steps and the 100 steady-state steps that follow them; the 10 warm-up launches run the statistics-on instantiation and the tutorial-diffusion extra the Brownian one, both listed separately in the kernel stats"),
            pmc_raw=dict(FETCH_SIZE_KB=pmc["FETCH_SIZE_KB"], WRITE_SIZE_KB=pmc["WRITE_SIZE_KB"], dispatches=pmc["dispatches"]),
            calibration=dict(what="same kernel, zero cycles: 280 MB read + 280 MB written (known)",
                             FETCH_SIZE_KB=cal["FETCH_SIZE_KB"], WRITE_SIZE_KB=cal["WRITE_SIZE_KB"],
