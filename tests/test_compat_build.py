@@ -12,8 +12,12 @@ COMPAT = os.path.join(ROOT, "cudaparticlesfoam_amd", "compat")
 def test_fragments_and_shims_compile_and_link():
     r = subprocess.run(["make", "-C", COMPAT, "-B", "-s"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    for b in ("mockUncoupledFoam", "mockStagedFoam"):
+    for b in ("mockUncoupledFoam", "mockStagedFoam", "mockParallelFoam"):
         assert os.access(os.path.join(COMPAT, "bin", b), os.X_OK)
+    # the parallel (Pstream) branch of the fragments is compiled code: it binds the rank-direct ingest
+    par = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(COMPAT, "bin", "mockParallelFoam")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "cpf_set_mesh_parts" in par and "cpf_set_velocity" in par
     out = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(COMPAT, "bin", "mockUncoupledFoam")],
                          capture_output=True, text=True, check=True).stdout
     undefined = {l.split()[-1] for l in out.splitlines()}
