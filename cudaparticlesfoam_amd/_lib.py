@@ -90,6 +90,9 @@ SIGNATURES = {
     "cpf_stage_locate_initial": (_int, [_ctx, _vp, _vp, _i64]),
     "cpf_stage_count_outside": (_int, [_ctx, _vp, _i64, C.POINTER(_i64)]),
     "cpf_stage_advect": (_int, [_ctx, _vp, _vp, _vp, _vp, _dbl, _i64]),
+    "cpf_set_tets": (_int, [_ctx, _vp, _i64, _vp, _i64, _int]),
+    "cpf_set_vertex_velocity": (_int, [_ctx, _vp, _i64]),
+    "cpf_stage_advect_vertex": (_int, [_ctx, _vp, _vp, _vp, _vp, _dbl, _i64]),
     "cpf_stage_brownian": (_int, [_ctx, _vp, _vp, _dbl, _i64, _dbl, _u32]),
     "cpf_stage_locate": (_int, [_ctx, _vp, _vp, _vp, _i64]),
     "cpf_stage_reflect": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),

@@ -112,6 +112,16 @@ class Context:
             raise ValueError("U must be (nCells, 3)")
         self._ck(self.lib.cpf_set_velocity(self.h, _ptr(U), U.shape[0]))
 
+    def set_tets(self, positions, tets, tets_per_cell: int = 12):
+        """The tet decomposition the "VertexVelocity" advect mode needs (src/initCuda.H:86-124): positions =
+        mesh.points() ++ mesh.C(), tets [nCells * tets_per_cell][4] in cell order."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64); t = np.ascontiguousarray(tets, dtype=np.int32)
+        self._ck(self.lib.cpf_set_tets(self.h, _ptr(pos), pos.shape[0], _ptr(t), t.shape[0], int(tets_per_cell)))
+
+    def set_vertex_velocity(self, vertex_u):
+        u = np.ascontiguousarray(vertex_u, dtype=np.float64)
+        self._ck(self.lib.cpf_set_vertex_velocity(self.h, _ptr(u), u.shape[0]))
+
     def set_velocity_dev(self, ptr: int, n_cells: int):
         self._ck(self.lib.cpf_set_velocity_dev(self.h, C.c_void_p(ptr), n_cells))
 
@@ -413,9 +423,14 @@ class StagedCloud:
         self.ctx._ck(self.ctx.lib.cpf_stage_count_outside(self.ctx.h, self._bufs["ids"], self.n, C.byref(out)))
         return out.value
 
-    def cudaAdvect(self, dt: float):                                      # cuda/particles.cu:403-448
+    def cudaAdvect(self, dt: float, mode: str = "TetVelocity"):           # cuda/particles.cu:403-448
         b = self._bufs
-        self.ctx._ck(self.ctx.lib.cpf_stage_advect(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
+        if mode == "TetVelocity":
+            self.ctx._ck(self.ctx.lib.cpf_stage_advect(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
+        elif mode == "VertexVelocity":                                    # :428-437 -> particleAdvectKernel :244-313
+            self.ctx._ck(self.ctx.lib.cpf_stage_advect_vertex(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
+        else:
+            raise ValueError("cudaAdvect: mode must be TetVelocity or VertexVelocity")
 
     def cudaBrownianMotion(self, dt: float, D: float, step: int):         # cuda/particles.cu:577-599
         b = self._bufs

@@ -105,9 +105,16 @@ inline void cudaInitParticles(Particle* d_particles, int N, const box3d& worldBo
 inline void cudaAdvect(Particle* d_particles, int* d_tetIDs, vec4d* d_vels, vec4d* d_disp, double dt,
                        int numParticles, vec4i* /*d_tetIndices*/, vec3d* /*d_vertexPositions*/,
                        vec3d* /*d_velocities*/, std::string mode = "TetVelocity") {
-    if (mode != "TetVelocity") throw Error(CPF_ERR_ARG, "cudaAdvect: only \"TetVelocity\" (cell-constant U) is built");
     cpf_context* c = currentMesh().ctx;
-    check(c, cpf_stage_advect(c, &d_particles->x, d_tetIDs, &d_vels->x, &d_disp->x, dt, numParticles));
+    if (mode == "TetVelocity") {
+        check(c, cpf_stage_advect(c, &d_particles->x, d_tetIDs, &d_vels->x, &d_disp->x, dt, numParticles));
+    } else if (mode == "VertexVelocity") {
+        // needs the decomposition and the vertex velocities in the library: cpf_set_tets + cpf_set_vertex_velocity
+        check(c, cpf_stage_advect_vertex(c, &d_particles->x, d_tetIDs, &d_vels->x, &d_disp->x, dt, numParticles));
+    } else {
+        throw Error(CPF_ERR_ARG, "cudaAdvect: mode must be \"TetVelocity\" or \"VertexVelocity\" (cuda/particles.cu:417-447; "
+                                 "\"ConstantVelocity\" is not built)");
+    }
     check(c, cpf_synchronize(c));
 }
 

@@ -53,6 +53,9 @@ struct cpf_context {
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 4;                        // cpf_set_option("step_variant"), see include/cpf.h
     cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
+    // "VertexVelocity" advect only: the tet decomposition and one velocity per tet-mesh vertex
+    double* d_tetPos = nullptr; int32_t* d_tets = nullptr; double* d_vertVel = nullptr;
+    int64_t nTetVerts = 0, nTets = 0; int tetsPerCell = 0; bool haveVertVel = false;
     // asynchronous output (cpf_write_vtu_async): one frame in flight
     std::thread writer;
     bool writerLive = false;
@@ -241,6 +244,7 @@ int cpf_destroy(cpf_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     freeMesh(ctx); freeCloud(ctx);
     freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab);
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -761,6 +765,47 @@ int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, do
     CPF_STAGE_PRE("cpf_stage_advect", true);
     CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect: null array");
     CPF_HIP(ctx, cpf::launch_stage_advect(ctx->stream, particles, ids, vels, disps, dt, n, meshView(ctx)));
+    return CPF_OK;
+}
+int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, const int32_t* tets, int64_t nTets,
+                 int tetsPerCell) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_tets: call cpf_set_mesh first");
+    CPF_REQUIRE(ctx, positions && tets && nVerts > 0 && tetsPerCell > 0, CPF_ERR_ARG, "cpf_set_tets: bad arguments");
+    CPF_REQUIRE(ctx, nTets == (int64_t)tetsPerCell * ctx->host.nCells, CPF_ERR_MESH,
+                "cpf_set_tets: nTets must be tetsPerCell x nCells (tets in cell order, src/initCuda.H:99-105)");
+    for (int64_t k = 0; k < 4 * nTets; ++k)
+        CPF_REQUIRE(ctx, tets[k] >= 0 && tets[k] < nVerts, CPF_ERR_MESH, "cpf_set_tets: tet vertex out of range");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
+    ctx->haveVertVel = false;
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tetPos, (size_t)nVerts * 24));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tets, (size_t)nTets * 16));
+    CPF_HIP(ctx, hipMalloc((void**)&ctx->d_vertVel, (size_t)nVerts * 24));
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->d_tetPos, positions, (size_t)nVerts * 24, hipMemcpyHostToDevice, ctx->stream));
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->d_tets, tets, (size_t)nTets * 16, hipMemcpyHostToDevice, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nTetVerts = nVerts; ctx->nTets = nTets; ctx->tetsPerCell = tetsPerCell;
+    return CPF_OK;
+}
+int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVerts) {
+    CPF_REQUIRE(ctx, ctx && vertexU, CPF_ERR_ARG, "null argument");
+    CPF_REQUIRE(ctx, ctx->d_tets, CPF_ERR_STATE, "cpf_set_vertex_velocity: call cpf_set_tets first");
+    CPF_REQUIRE(ctx, nVerts == ctx->nTetVerts, CPF_ERR_ARG, "cpf_set_vertex_velocity: one velocity per tet-mesh vertex");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->d_vertVel, vertexU, (size_t)nVerts * 24, hipMemcpyHostToDevice, ctx->stream));
+    CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->haveVertVel = true;
+    return CPF_OK;
+}
+int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps,
+                            double dt, int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_advect_vertex", false);
+    CPF_REQUIRE(ctx, ctx->haveVertVel, CPF_ERR_STATE, "cpf_stage_advect_vertex: call cpf_set_tets and cpf_set_vertex_velocity first");
+    CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect_vertex: null array");
+    CPF_HIP(ctx, cpf::launch_stage_advect_vertex(ctx->stream, particles, ids, vels, disps, dt, n, ctx->d_tetPos, ctx->d_tets,
+                                                 ctx->tetsPerCell, ctx->d_vertVel));
     return CPF_OK;
 }
 int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,

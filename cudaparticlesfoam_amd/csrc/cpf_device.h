@@ -71,6 +71,9 @@ hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_
 // stage-by-stage kernels on the reference's AoS layouts
 hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                int64_t n, const MeshView& m);
+hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
+                                      int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
+                                      const double* vertVel);
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,
                                  uint32_t step, uint32_t seed);
 hipError_t launch_stage_locate(hipStream_t st, const double* P, const double* disps, int32_t* ids, int64_t n,

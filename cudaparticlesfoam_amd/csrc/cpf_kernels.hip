@@ -400,6 +400,49 @@ __global__ __launch_bounds__(kBlock) void stage_advect_kernel(double4* __restric
     disps[i] = make_double4(Pn.x - Pp.x, Pn.y - Pp.y, Pn.z - Pp.z, -1.0);
 }
 
+// "VertexVelocity" advect (cuda/particles.cu:244-313) on cell ids; see cpf_stage_advect_vertex in include/cpf.h.
+// Plain products and sums in the reference's order (no fma: the file is built with -ffp-contract=off), so that
+// oracle/cellwalk.c's cw_advect_vertex is reproduced bit for bit.
+__device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
+    const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
+    const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+    return d.x * c.x + d.y * c.y + d.z * c.z;
+}
+__global__ __launch_bounds__(kBlock) void stage_advect_vertex_kernel(double4* __restrict__ P, const int32_t* __restrict__ ids,
+                                                                     double4* __restrict__ vels, double4* __restrict__ disps,
+                                                                     double dt, int64_t n, const double* __restrict__ pos,
+                                                                     const int32_t* __restrict__ tets, int tetsPerCell,
+                                                                     const double* __restrict__ vertVel) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double4 p = P[i];
+    if (!p.w) return;
+    const int c = ids[i];
+    if (c < 0) { p.w = 0.0; P[i] = p; return; }                  // particles.cu:262-266
+    const D3 Pp = {p.x, p.y, p.z};
+    auto ld = [](const double* a, int v) { return D3{a[3 * (int64_t)v], a[3 * (int64_t)v + 1], a[3 * (int64_t)v + 2]}; };
+    int best = -1;
+    double bestMin = 0.0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (int k = 0; k < tetsPerCell; ++k) {
+        const int32_t* ix = tets + 4 * ((int64_t)c * tetsPerCell + k);
+        const D3 A = ld(pos, ix[0]), B = ld(pos, ix[1]), C = ld(pos, ix[2]), D = ld(pos, ix[3]);
+        const double den = det4(A, B, C, D);
+        if (den == 0.0) continue;                                 // a bad tet (particles.cu:275-278) cannot hold P
+        const double a = det4(Pp, B, C, D) * (1. / den), b = det4(A, Pp, C, D) * (1. / den);
+        const double cc = det4(A, B, Pp, D) * (1. / den), d = det4(A, B, C, Pp) * (1. / den);
+        const double m = fmin(fmin(a, b), fmin(cc, d));
+        if (best < 0 || m > bestMin) { best = k; bestMin = m; w0 = a; w1 = b; w2 = cc; w3 = d; }
+    }
+    if (best < 0) { p.w = 0.0; P[i] = p; return; }
+    const int32_t* ix = tets + 4 * ((int64_t)c * tetsPerCell + best);
+    const D3 vA = ld(vertVel, ix[0]), vB = ld(vertVel, ix[1]), vC = ld(vertVel, ix[2]), vD = ld(vertVel, ix[3]);
+    const D3 v = {((w0 * vA.x + w1 * vB.x) + w2 * vC.x) + w3 * vD.x, ((w0 * vA.y + w1 * vB.y) + w2 * vC.y) + w3 * vD.y,
+                  ((w0 * vA.z + w1 * vB.z) + w2 * vC.z) + w3 * vD.z};
+    const D3 Pn = {p.x + dt * v.x, p.y + dt * v.y, p.z + dt * v.z};
+    vels[i] = make_double4(v.x, v.y, v.z, -1.0);
+    disps[i] = make_double4(Pn.x - p.x, Pn.y - p.y, Pn.z - p.z, -1.0);
+}
+
 __global__ __launch_bounds__(kBlock) void stage_brownian_kernel(const double4* __restrict__ P,
                                                                 double4* __restrict__ disps, double sigma, int64_t n,
                                                                 uint32_t step, uint32_t seed) {
@@ -498,6 +541,14 @@ static inline dim3 grid_of(int64_t n) { return dim3((unsigned)((n + kBlock - 1) 
 hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                int64_t n, const MeshView& m) {
     if (n > 0) hipLaunchKernelGGL(stage_advect_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels, (double4*)disps, dt, n, m);
+    return hipGetLastError();
+}
+hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
+                                      int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
+                                      const double* vertVel) {
+    if (n > 0)
+        hipLaunchKernelGGL(stage_advect_vertex_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels,
+                           (double4*)disps, dt, n, pos, tets, tetsPerCell, vertVel);
     return hipGetLastError();
 }
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,

@@ -255,6 +255,19 @@ int cpf_stage_count_outside(cpf_context* ctx, const int32_t* ids, int64_t n, int
 /* cudaAdvect, "TetVelocity" mode (cuda/particles.cu:403-448 -> :316-373) */
 int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps, double dt,
                      int64_t n);
+/* cudaAdvect, "VertexVelocity" mode (cuda/particles.cu:428-437 -> particleAdvectKernel, :244-313): velocity at P =
+ * barycentric interpolation of VERTEX velocities in the tet that holds P.  The walk needs no tets, this mode does:
+ * cpf_set_tets hands over the decomposition the reference's fragment builds (src/initCuda.H:86-124: tetsPerCell tets
+ * per cell in cell order, vertex ids into positions = mesh.points() ++ mesh.C()), replacing DeviceTetMesh::upload of
+ * d_positions / d_indices (cuda/DeviceTetMesh.cuh:59-72); cpf_set_vertex_velocity replaces d_velocities for this mode
+ * (one vector per tet-mesh vertex).  ids are CELL ids: the kernel takes the tet of that cell whose smallest barycentric
+ * weight of P is largest (the interpolant is continuous across the tets of a cell), then weighs exactly like the
+ * reference (w_X = det(tet with X := P) * (1 / det(tet)); vel = wA*velA + wB*velB + wC*velC + wD*velD). */
+int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, const int32_t* tets, int64_t nTets,
+                 int tetsPerCell);
+int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVerts);
+int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps,
+                            double dt, int64_t n);
 /* cudaBrownianMotion (cuda/particles.cu:577-599); step selects the counter-based stream */
 int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,
                        uint32_t step);

@@ -37,6 +37,7 @@ expect "$RTX/query/ConvexQuery.cu"   136 "particleLocator"
 expect "$RTX/query/ConvexQuery.cu"   239 "reflectInTet"
 expect "$RTX/query/ConvexQuery.cu"   321 "convexReflector"
 expect "$RTX/cuda/particles.cu"      78  "initParticlesKernel"
+expect "$RTX/cuda/particles.cu"      245 "particleAdvectKernel(Particle"
 expect "$RTX/cuda/particles.cu"      317 "particleAdvectKernelTetVel"
 expect "$RTX/cuda/particles.cu"      660 "particleMoveKernel"
 expect "$RTX/query/RTQuery.cu"       35  "baryTetSearch"
@@ -53,6 +54,7 @@ expect "$RTX/cuda/utils.cpp"         282 "fclose(fp)"
   sed -n '32,131p;135,216p'           "$RTX/query/ConvexQuery.cu"      # traceIntet, particleLocator
   sed -n '239,317p;320,436p'          "$RTX/query/ConvexQuery.cu"      # reflectInTet, convexReflector
   sed -n '78,97p'                     "$RTX/cuda/particles.cu"         # initParticlesKernel
+  sed -n '244,313p'                   "$RTX/cuda/particles.cu"         # particleAdvectKernel ("VertexVelocity")
   sed -n '316,373p'                   "$RTX/cuda/particles.cu"         # particleAdvectKernelTetVel
   sed -n '659,704p'                   "$RTX/cuda/particles.cu"         # particleMoveKernel (disp)
   sed -n '35,186p;189,248p'           "$RTX/query/RTQuery.cu"          # bary search, RT reflection, baryQuery(Disp)

@@ -243,6 +243,50 @@ void cw_locate_initial(const double* px, const double* py, const double* pz, int
     }
 }
 
+/* "VertexVelocity" advect on CELL ids (what cpf_stage_advect_vertex implements): the product tracks cells, not tets,
+ * so the tet of the cell that holds P is found first -- the one whose smallest barycentric weight is largest, lowest
+ * index on ties -- and then weighted exactly like cuda/particles.cu:270-291.  The interpolant is continuous across
+ * the tets of a cell, so a particle on a shared tet face gets the same velocity (to rounding) from either side. */
+static double cw_det4(v3 A, v3 B, v3 Cc, v3 D) {
+    const v3 a = sub(B, A), b = sub(Cc, A), d = sub(D, A);
+    const v3 c = V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+    return d.x * c.x + d.y * c.y + d.z * c.z;
+}
+void cw_advect_vertex(double* P, const int* cells, double* vels, double* disps, double dt, int n, const int* tets,
+                      int tetsPerCell, const double* pos, const double* vertvel, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        double* p = P + 4 * i;
+        if (!p[3]) continue;
+        const int c = cells[i];
+        if (c < 0) { p[3] = 0.0; continue; }
+        const v3 Pp = V(p[0], p[1], p[2]);
+        int best = -1; double bestMin = 0.0, bw[4] = {0, 0, 0, 0};
+        for (int k = 0; k < tetsPerCell; ++k) {
+            const int* ix = tets + 4 * ((long long)c * tetsPerCell + k);
+            const v3 A = V(pos[3 * ix[0]], pos[3 * ix[0] + 1], pos[3 * ix[0] + 2]), B = V(pos[3 * ix[1]], pos[3 * ix[1] + 1], pos[3 * ix[1] + 2]);
+            const v3 Cc = V(pos[3 * ix[2]], pos[3 * ix[2] + 1], pos[3 * ix[2] + 2]), D = V(pos[3 * ix[3]], pos[3 * ix[3] + 1], pos[3 * ix[3] + 2]);
+            const double den = cw_det4(A, B, Cc, D);
+            if (den == 0.0) continue;
+            const double w[4] = {cw_det4(Pp, B, Cc, D) * (1. / den), cw_det4(A, Pp, Cc, D) * (1. / den),
+                                 cw_det4(A, B, Pp, D) * (1. / den), cw_det4(A, B, Cc, Pp) * (1. / den)};
+            double m = w[0]; for (int q = 1; q < 4; ++q) if (w[q] < m) m = w[q];
+            if (best < 0 || m > bestMin) { best = k; bestMin = m; for (int q = 0; q < 4; ++q) bw[q] = w[q]; }
+        }
+        if (best < 0) { p[3] = 0.0; continue; }                /* every tet of the cell degenerate */
+        const int* ix = tets + 4 * ((long long)c * tetsPerCell + best);
+        double vel[3];
+        for (int q = 0; q < 3; ++q)
+            vel[q] = ((bw[0] * vertvel[3 * ix[0] + q] + bw[1] * vertvel[3 * ix[1] + q]) + bw[2] * vertvel[3 * ix[2] + q]) +
+                     bw[3] * vertvel[3 * ix[3] + q];
+        for (int q = 0; q < 3; ++q) {
+            const double pn = p[q] + dt * vel[q];
+            vels[4 * i + q] = vel[q]; disps[4 * i + q] = pn - p[q];
+        }
+        vels[4 * i + 3] = -1.0; disps[4 * i + 3] = -1.0;
+    }
+}
+
 int cw_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

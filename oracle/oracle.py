@@ -104,6 +104,7 @@ class RefLib(_TetApi):
         L = self.lib
         L.ref_init_particles.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int]
         L.ref_advect.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, _dp, _dp, C.c_int]
+        L.ref_advect_vertex.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, _dp, _dp, C.c_int]
         L.ref_locate.argtypes = [_dp, _ip, _dp, C.c_int, _ip, _dp, _ip, _ip, _ip, C.c_int]
         L.ref_reflect.argtypes = [_dp, _ip, _dp, _dp, C.c_int, _ip, _dp, _ip, _ip, _ip, C.c_int]
         L.ref_move.argtypes = [_dp, _dp, _ip, C.c_int, C.c_int]
@@ -140,6 +141,9 @@ class RefLib(_TetApi):
     def advect(self, P, ids, vels, disps, dt, m: TetMeshTables, nthreads=1):
         self.lib.ref_advect(P, ids, vels, disps, dt, P.shape[0], m.tets, m.positions, m.tetvel, nthreads)
 
+    def advect_vertex(self, P, ids, vels, disps, dt, m: TetMeshTables, vertvel, nthreads=1):
+        self.lib.ref_advect_vertex(P, ids, vels, disps, dt, P.shape[0], m.tets, m.positions, _c(vertvel, np.float64), nthreads)
+
     def locate(self, P, ids, disps, m, nthreads=1):
         self.lib.ref_locate(P, ids, disps, P.shape[0], m.tets, m.positions, m.tetfacets, m.facets, m.faceinfo, nthreads)
 
@@ -168,6 +172,7 @@ class TetWalk(_TetApi):
         L = self.lib
         L.orc_init_particles.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int]
         L.orc_advect.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, _dp, _dp, C.c_int]
+        L.orc_advect_vertex.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, _dp, _dp, C.c_int]
         L.orc_locate.argtypes = [_dp, _ip, _dp, C.c_int, _dp, _ip, _ip, _ip, C.c_int]
         L.orc_reflect.argtypes = [_dp, _ip, _dp, _dp, C.c_int, _dp, _ip, _ip, _ip, C.c_int]
         L.orc_move.argtypes = [_dp, _dp, C.c_int, C.c_int]
@@ -181,6 +186,9 @@ class TetWalk(_TetApi):
 
     def advect(self, P, ids, vels, disps, dt, m, nthreads=1):
         self.lib.orc_advect(P, ids, vels, disps, dt, P.shape[0], m.tets, m.positions, m.tetvel, nthreads)
+
+    def advect_vertex(self, P, ids, vels, disps, dt, m, vertvel, nthreads=1):
+        self.lib.orc_advect_vertex(P, ids, vels, disps, dt, P.shape[0], m.tets, m.positions, _c(vertvel, np.float64), nthreads)
 
     def locate(self, P, ids, disps, m, nthreads=1):
         self.lib.orc_locate(P, ids, disps, P.shape[0], m.positions, m.tetfacets, m.facets, m.faceinfo, nthreads)
@@ -217,6 +225,7 @@ class CellWalk:
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
         L.cw_normal3.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _dp]
+        L.cw_advect_vertex.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, C.c_int, _dp, _dp, C.c_int]
         self.hw_threads = L.cw_max_threads()
         self.max_threads = usable_threads(self.hw_threads)
 
@@ -229,6 +238,11 @@ class CellWalk:
         if r != ncf:
             raise RuntimeError("cw_build")
         return CellTables(off, planes, nbr, mesh.n_cells)
+
+    def advect_vertex(self, P, cells, vels, disps, dt, tets, tets_per_cell, positions, vertvel, nthreads=1):
+        """cpf_stage_advect_vertex's CPU statement: "VertexVelocity" advect on cell ids (tets: [nCells*tpc][4])."""
+        self.lib.cw_advect_vertex(P, _c(cells, np.int32), vels, disps, dt, P.shape[0], _c(tets, np.int32), tets_per_cell,
+                                  _c(positions, np.float64), _c(vertvel, np.float64), nthreads)
 
     def step(self, x, y, z, cell, dt, cycles, t: CellTables, U, vel_out: Optional[np.ndarray] = None,
              nthreads=1, D=0.0, gid: Optional[np.ndarray] = None, step0=0, seed=0):

@@ -124,6 +124,15 @@ void ref_advect(double* particles, int* tetIDs, double* vels, double* disps, dou
     });
 }
 
+// particleAdvectKernel, the "VertexVelocity" mode (cuda/particles.cu:244-313)
+void ref_advect_vertex(double* particles, int* tetIDs, double* vels, double* disps, double dt, int n,
+                       const int* indices, const double* positions, const double* vertVel, int nthreads) {
+    launch(n, nthreads, [&] {
+        particleAdvectKernel((Particle*)particles, tetIDs, (vec4d*)vels, (vec4d*)disps, dt, n,
+                             (vec4i*)indices, (vec3d*)positions, (vec3d*)vertVel);
+    });
+}
+
 // particleLocator (query/ConvexQuery.cu:135-216)
 void ref_locate(double* particles, int* tetIDs, double* disps, int n, const int* indices,
                 const double* positions, const int* tetfacets, const int* facets, const int* faceinfos,

@@ -10,6 +10,9 @@ ConvexPoly build, diffusionCoeff 0):
   box_random                   : 10x9x8 hex box, random cell-constant U, 600 particles, dt 0.3,
                                  checkpoints after 1, 20, 100 cycles (heavy wall reflection)
   stages_box                   : every intermediate array of ONE cycle (after advect, locate, reflect, move)
+  vertex_box                   : "VertexVelocity" mode (particleAdvectKernel, cuda/particles.cu:244-313) on the same box:
+                                 random velocities on the tet-mesh vertices (points ++ cell centres), one cycle's
+                                 advect arrays and checkpoints after 1, 20, 60 cycles of advect -> locate -> reflect -> move
   face_table_box               : getBoundaryMesh tables of createBoxMesh(3,2,2)
   init_particles               : cudaInitParticles LCG<16> stream (g++ argument evaluation order)
 Usage: python tests/golden/make_golden.py   (from the repo root, in the container with /root/reference)
@@ -96,6 +99,24 @@ def main():
     ref.reflect(P, ids, disps, vels, m); st.update(ref_P=P.copy(), ref_tet=ids.copy(), ref_disp=disps.copy(), ref_vel=vels.copy())
     ref.move(P, disps, ids); st.update(mov_P=P.copy(), mov_disp=disps.copy())
     np.savez_compressed(os.path.join(HERE, "stages_box.npz"), **st)
+
+    # "VertexVelocity": barycentric interpolation of vertex velocities in the particle's tet
+    vv = np.random.default_rng(21).normal(size=(pos.shape[0], 3))
+    P = np.zeros((n, 4)); P[:, :3] = xb; P[:, 3] = 1
+    ids = (cb * 12).astype(np.int32); ref.bary_query(P, ids, m)
+    vels = np.zeros((n, 4)); disps = np.zeros((n, 4))
+    vx = dict(vertex_U=vv, xyz0=xb, tet0=ids.copy(), dt=np.float64(0.2), checkpoints=np.asarray((1, 20, 60)),
+              inputs_sha256=np.array(digest(bm.points, bm.face_verts, bm.owner, bm.neighbour, vv)))
+    done = 0
+    for k in (1, 20, 60):
+        for _ in range(k - done):
+            ref.advect_vertex(P, ids, vels, disps, 0.2, m, vv)
+            if done == 0 and _ == 0:
+                vx.update(adv_vel=vels.copy(), adv_disp=disps.copy())
+            ref.locate(P, ids, disps, m); ref.reflect(P, ids, disps, vels, m); ref.move(P, disps, ids)
+        done = k
+        vx["P_%d" % k] = P.copy(); vx["tet_%d" % k] = ids.copy(); vx["vel_%d" % k] = vels.copy()
+    np.savez_compressed(os.path.join(HERE, "vertex_box.npz"), **vx)
 
     bp, bt = ref.box_mesh(3, 2, 2)
     f, tf, fi = ref.face_table(bp, bt)

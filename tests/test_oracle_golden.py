@@ -112,3 +112,34 @@ def test_seeding_golden(oracle_libs):
     # the tutorial's seeding box has inverted y/z bounds (cudaParticlesDict:25): positions still land inside it
     lo = np.minimum(g["lower"], g["upper"]); hi = np.maximum(g["lower"], g["upper"])
     assert (P[:, :3] >= lo - 1e-15).all() and (P[:, :3] <= hi + 1e-15).all() and (P[:, 3] == 1).all()
+
+
+def test_vertex_velocity_golden(oracle_libs):
+    """"VertexVelocity" mode (particleAdvectKernel, cuda/particles.cu:244-313): the plain-C restatement reproduces the
+    reference's cycles bit for bit; the product's formulation on CELL ids (find the tet of the cell that holds P, then
+    weigh like the reference) gives the same velocities -- identical bits wherever it picks the reference's tet."""
+    from cudaparticlesfoam_amd.cases import box_mesh
+    from oracle.tetmesh import poly_to_tets
+    g = np.load(os.path.join(G, "vertex_box.npz"))
+    mesh = box_mesh(10, 9, 8)
+    assert str(g["inputs_sha256"]) == _digest(mesh.points, mesh.face_verts, mesh.owner, mesh.neighbour, g["vertex_U"])
+    tw, cw = oracle_libs.TetWalk(), oracle_libs.CellWalk()
+    pos, tets, tcell, _ = poly_to_tets(mesh, None, np.zeros((mesh.n_cells, 3)))
+    m = tw.tables(pos, tets, np.zeros((tets.shape[0], 3)))
+    n = g["xyz0"].shape[0]
+    P = np.zeros((n, 4)); P[:, :3] = g["xyz0"]; P[:, 3] = 1
+    ids = g["tet0"].copy(); vels = np.zeros((n, 4)); disps = np.zeros((n, 4))
+    # the product's stage on cell ids, first cycle
+    Pc = P.copy(); vc = np.zeros((n, 4)); dc = np.zeros((n, 4))
+    cw.advect_vertex(Pc, (ids // 12).astype(np.int32), vc, dc, float(g["dt"]), tets, 12, pos, g["vertex_U"])
+    same = (vc == g["adv_vel"]).all(1)
+    assert same.mean() > 0.99 and np.abs(vc - g["adv_vel"]).max() < 1e-13 and np.abs(dc - g["adv_disp"]).max() < 1e-13
+    done = 0
+    for k in g["checkpoints"]:
+        for c in range(int(k) - done):
+            tw.advect_vertex(P, ids, vels, disps, float(g["dt"]), m, g["vertex_U"])
+            if done == 0 and c == 0:
+                assert np.array_equal(vels, g["adv_vel"]) and np.array_equal(disps, g["adv_disp"])
+            tw.locate(P, ids, disps, m); tw.reflect(P, ids, disps, vels, m); tw.move(P, disps)
+        done = int(k)
+        assert np.array_equal(P, g["P_%d" % k]) and np.array_equal(ids, g["tet_%d" % k]) and np.array_equal(vels, g["vel_%d" % k])
