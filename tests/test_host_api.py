@@ -52,6 +52,9 @@ def test_subcycling_and_output_cadence(api):
     n = p.advect(300.0, 0.1)
     assert n == max(math.ceil(0.1 / 1e-4), 1) == 1000                          # advect.H:36
     steps = [c for c in p.ctx.calls if c[0] == "step"]
+    # frame 0 is written by a cycle of ZERO length that stores the velocities (src/initCuda.H:184-201); not a step of the run
+    assert steps[0][1:4] == (0.0, 0.0, 1) and steps[0][4] & L.STEP_STORE_VEL
+    steps = steps[1:]
     assert sum(c[3] for c in steps) == 1000 and all(abs(c[1] - 0.1 / 1000) < 1e-18 and c[2] == 1.5e-5 for c in steps)
     assert frames[1:] == [s + 1 for s in range(0, 1000, 10)]                   # step % saveInterval == 0 -> step+1
     # an output cycle runs alone with velocities stored; the 9 cycles up to the next output point are ONE launch
