@@ -544,7 +544,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
     const std::string k(key);
     if (k == "step_variant") {
-        CPF_REQUIRE(ctx, value >= 0 && value <= 4 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..4");
+        CPF_REQUIRE(ctx, value >= 0 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..5");
         ctx->stepVariant = (int)value;
         return CPF_OK;
     }
@@ -616,7 +616,9 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     const char* b[2] = {"false", "true"};
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
     char tmp[160];
-    if (v == 4) snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
+    if (v == 5 && !brown && !sv && !(flags & CPF_STEP_FUSE_CYCLES))
+        snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
+    else if (v == 4 || v == 5) snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
     else if (v == 3) snprintf(tmp, sizeof tmp, "cpf::step_kernel_coop<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
     else snprintf(tmp, sizeof tmp, "cpf::step_kernel<%d, %s, %s, %s>", v, b[brown], b[reflect], b[sv]);
     snprintf(buf, bufBytes, "%s", tmp);

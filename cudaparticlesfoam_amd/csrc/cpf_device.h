@@ -42,6 +42,8 @@ struct StreamState {
     int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
 };
 
+hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
+                             const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream);
 // ss == nullptr: the streaming variant is not available (falls back to the wave-cooperative kernel)

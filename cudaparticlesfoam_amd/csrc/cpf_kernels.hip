@@ -336,7 +336,7 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
 
 int effective_step_variant(int variant, const MeshView& m, bool haveStream) {
     if (!m.allHex) return kVariantGeneric;                    // fixed-slot variants need 6 faces per cell
-    if (variant == kVariantStream && !haveStream) variant = kVariantCoop;
+    if ((variant == kVariantStream || variant == kVariantAhead) && !haveStream) variant = kVariantCoop;
     // the wave-cooperative kernel addresses records with a 32-bit byte offset (256 B x 2^24 cells)
     if (variant == kVariantCoop && m.nCells > kCoopMaxCells) variant = haveStream ? kVariantStream : kVariantFixedScalar;
     return variant;
@@ -352,6 +352,10 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
     variant = effective_step_variant(variant, m, ss != nullptr);
     switch (variant) {
+        case kVariantAhead:
+            // lanes that run ahead into the next tile: one plain cycle per launch only; everything else streams
+            if (!brown && !storeVel && nCyc == 1) return launch_step_ahead(st, x, y, z, cell, n, dt, reflect, m, counters, *ss, vel);
+            [[fallthrough]];
         case kVariantStream:
             return launch_step_stream(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m,
                                       counters, *ss);

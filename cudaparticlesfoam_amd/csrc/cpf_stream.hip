@@ -22,7 +22,7 @@
 // Crossing particles are not compacted into dense waves: what compaction is meant to buy -- finished lanes' slots
 // going to particles whose loads are already in flight -- is what the prefetch does at tile granularity, and the
 // sort key (cell, position in the cell's box) keeps the lanes of a tile in step.
-#include "cpf_walk.h"
+#include "cpf_stream_ops.h"
 
 #include <type_traits>
 
@@ -35,74 +35,10 @@ namespace cpf {
 #define CPF_STREAM_WAVES 6
 #endif
 constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
-#ifndef CPF_STREAM_GROUPS
-#define CPF_STREAM_GROUPS 256
-#endif
-constexpr int kStreamGroups = CPF_STREAM_GROUPS;        // wave groups sharing a chunk counter (power of two, <= 256)
-constexpr int kStreamCounterStride = 16;                 // unsigned words between two counters (64 B)
 static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
-
-// ------------------------------------------------------------------------------------------------
-// memory operations the COMPILER must not keep books on (see the head of this file)
-// ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) const char* lds_cptr;
-__device__ __forceinline__ unsigned lds_addr(const void* p) {           // byte address inside the workgroup's LDS
-    return (unsigned)(uintptr_t)(lds_cptr)p;
-}
-// a value the program knows to be wave-uniform, pinned to scalar registers (the "s" operands below need it)
-__device__ __forceinline__ unsigned uniform32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ int64_t uniform64(int64_t v) {
-    const unsigned lo = uniform32((unsigned)v), hi = uniform32((unsigned)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-// 16 bytes per active lane, global -> LDS[ldsDst + 16 * lane id], no register in between.  Pending LDS reads are
-// retired first (the DMA must not overtake a read of the bytes it replaces); M0 is restored (compiler-reserved).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned ldsDst) {
-    unsigned keep;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
-}
-// (s_nop 4: a scalar base the compiler has just restored from a spill lane with v_readlane must not be read by a
-// vector-memory instruction within five wait states; hipcc pads its own instructions, not the inside of an asm)
-__device__ __forceinline__ void async_store(double* base, unsigned byteOff, double v) {
-    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" : : "v"(byteOff), "v"(v), "s"(base) : "memory");
-}
-__device__ __forceinline__ void async_store(int32_t* base, unsigned byteOff, int v) {
-    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(byteOff), "v"(v), "s"(base) : "memory");
-}
-// returning atomic increment, complete when the statement ends (the caller masks it to one lane)
-__device__ __forceinline__ unsigned grab_sync(unsigned* base) {
-    unsigned r;
-    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(0u), "v"(1u), "s"(base) : "memory");
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS>
 struct StreamOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? CPF_STREAM_WAVES : 1; };
-
-// Work distribution.  ONE global chunk counter does not work: returning atomics on one address are served at about
-// one per 12 ns chip-wide (measured: 78 125 grabs = 0.97 ms for a zero-cycle launch), and every wave's next grab
-// queues behind every other wave's.  So the waves form kStreamGroups groups (block id mod kStreamGroups; where a
-// wave runs does not matter), group g owns the chunks g, g + G, g + 2G, ... -- evenly spaced samples of the sorted
-// cloud, so every group sees the same mix of slow (inlet, fine cells) and fast regions -- and has its own counter,
-// 64 bytes from the next; within a group the chunks are dealt first come, first served -- the first one included: a
-// wave that only starts when others have finished (a grid larger than what is resident at once: the occupancy
-// query was one wave per CU too optimistic in the measurements) then finds its group's counter exhausted and exits,
-// instead of sitting on a statically assigned chunk until the end of the launch (measured: a 20 us tail).
-// The counter set is double-buffered: a launch zeroes the set the NEXT launch uses.
-struct StreamArgs {
-    unsigned* grab;        // this launch's kStreamGroups counters, kStreamCounterStride apart
-    unsigned* grabNext;    // the other set: zeroed here for the next launch on the stream
-    int wavesPerGroup;     // grid = kStreamGroups * wavesPerGroup single-wave workgroups
-    int tilesPerChunk;
-    unsigned bigChunks;    // chunks 0 .. bigChunks-1 have tilesPerChunk tiles; every chunk after them is ONE tile: the tail
-                           // of the launch is dealt in small pieces, so that all waves finish within a tile's time of
-                           // each other (measured with 4-tile chunks throughout: the last wave 20 us after the median)
-    int debug;             // diagnostics only (results are wrong): 1 = no stores, 2 = no loads after a wave's first tile
-};
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_stream(

@@ -177,6 +177,9 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   3 wave-cooperative LDS cell cache on packed 256-byte cell records, one block per 128 particles
  *                   4 (default) streaming kernel: persistent waves, next tile prefetched into LDS while the current
  *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip)
+ *                   5 experimental: variant 4 whose finished lanes start on the next tile at once (cpf_ahead.hip).
+ *                     Fewer rounds per tile but dearer rounds: measured SLOWER than 4 on every mesh;
+ *                     only the plain reflect / no-reflect step without Brownian or stored velocity, else 4 runs
  *   "stream_tiles_per_chunk" (4), "stream_tail_fraction" (0.1), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference

@@ -48,7 +48,7 @@ def main():
             outs = []
             if os.environ.get("CPF_CHECK_VERBOSE"):
                 print("combo", dict(field=field, n=n, D=D, noref=noref, sv=sv, stats=stats, fused=fused, tpc=tpc, il=il), flush=True)
-            for variant in (3, 4):
+            for variant in (3, int(os.environ.get("CPF_CHECK_VARIANT", "4"))):
                 ctx.set_option("step_variant", variant)
                 ctx.set_option("stats", stats)
                 ctx.set_option("stream_tiles_per_chunk", tpc)

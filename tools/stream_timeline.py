@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--label", default="")
     ap.add_argument("--pre-steps", type=int, default=5, help="steps after the sort and before the measured launch")
+    ap.add_argument("--variant", type=int, default=4)
+    ap.add_argument("--groups", action="store_true", help="also per-group (= per-CU) and per-XCD end times")
+    ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh of tools/bench_3d.py, swirl field")
     args = ap.parse_args()
     import torch
     import bench
@@ -25,15 +28,30 @@ def main():
     from cudaparticlesfoam_amd.cases import pitzdaily as pz
     from cudaparticlesfoam_amd.parallel import x_slab_renumbering
     dev = torch.device("cuda", 0)
-    mesh0 = pz.pitzdaily_mesh(); c0, _ = mesh0.cell_centres_volumes()
-    mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_mesh(mesh); ctx.set_velocity(pz.uniform_u(mesh))
     n = int(args.particles)
-    x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+    if args.mesh3d:
+        from cudaparticlesfoam_amd.cases import block_mesh
+        v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
+                      [0, 0.05, 0.05]], float)
+        mesh = block_mesh(v, [dict(hex=range(8), n=(64, 64, 60), simple=(2.0, 1.0, 0.5))])
+        cc, _ = mesh.cell_centres_volumes()
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1))
+        torch.manual_seed(7)
+        x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
+        y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+        z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+        c = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), n)
+    else:
+        mesh0 = pz.pitzdaily_mesh(); c0, _ = mesh0.cell_centres_volumes()
+        mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
+        ctx.set_mesh(mesh); ctx.set_velocity(pz.uniform_u(mesh))
+        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
     g = torch.arange(n, dtype=torch.int64, device=dev)
-    ctx.set_option("stats", 0); ctx.set_option("step_variant", 4)
+    ctx.set_option("stats", 0); ctx.set_option("step_variant", args.variant)
     for kv in args.opt:
         k, v = kv.split("="); ctx.set_option(k, float(v))
     ctx.sort_by_cell_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), g.data_ptr(), n)
@@ -47,7 +65,8 @@ def main():
     ctx.step_dev(p(x), p(y), p(z), p(c), None, p(tl), n, 1e-4, 0.0, 5, 1, 0)
     launches, ms = ctx.timing_read()
     t = tl.cpu().numpy().reshape(-1, 4)
-    t = t[t[:, 1] > 0]
+    idx = np.nonzero(t[:, 1] > 0)[0]
+    t = t[idx]
     t0, t1 = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
     base = t0.min()
     start = (t0 - base) * 10.0 / 1e3          # us (100 MHz ticks)
@@ -58,6 +77,23 @@ def main():
                tiles_pct=q(t[:, 2]), rounds_per_tile=round(float(t[:, 3].sum() / max(1, t[:, 2].sum())), 3),
                us_per_tile_pct=q((end - start) / np.maximum(t[:, 2], 1)),
                slot_busy_fraction=round(float((end - start).sum() / (t.shape[0] * end.max())), 3))
+    if args.groups:
+        # per chunk-counter group (block id mod 256 = one CU: blocks go round-robin over 8 XCDs x 32 CUs) and per XCD
+        grp = idx % 256
+        gend = np.array([end[grp == k].max() for k in range(256)])
+        gmin = np.array([end[grp == k].min() for k in range(256)])
+        gtiles = np.array([t[grp == k, 2].sum() for k in range(256)])
+        grounds = np.array([t[grp == k, 3].sum() for k in range(256)])
+        gus = np.array([((end - start)[grp == k]).sum() for k in range(256)]) / np.maximum(gtiles, 1)
+        out["group_last_end_pct"] = q(gend)
+        out["group_first_end_pct"] = q(gmin)
+        out["group_tiles_pct"] = q(gtiles)
+        out["group_rounds_per_tile_pct"] = q(grounds / np.maximum(gtiles, 1))
+        out["group_wave_us_per_tile_pct"] = q(gus)
+        out["corr_end_vs_rounds"] = round(float(np.corrcoef(gend, grounds)[0, 1]), 3)
+        out["corr_end_vs_us_per_round"] = round(float(np.corrcoef(gend, gus * gtiles / np.maximum(grounds, 1))[0, 1]), 3)
+        out["xcd_last_end"] = [round(float(gend[np.arange(256) % 8 == k].max()), 1) for k in range(8)]
+        out["xcd_mean_end"] = [round(float(gend[np.arange(256) % 8 == k].mean()), 1) for k in range(8)]
     print(json.dumps(out), flush=True)
     ctx.close()
 
