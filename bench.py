@@ -51,6 +51,11 @@ def parse():
                     help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight")
     ap.add_argument("--fused-extra", type=int, default=0,
                     help="after the timed region, also time this many launches of 8 fused cycles (extra field; 0 = skip)")
+    ap.add_argument("--spinup-ms", type=float, default=100.0,
+                    help="before the warm-up steps, keep the device busy this long with step launches on a SCRATCH copy "
+                         "of the cloud (discarded): an MI355X needs ~30 ms of load after an idle phase to reach its "
+                         "steady clocks (tools/drift_check.py: 0.148 -> 0.119 ms per launch of the same work), and the "
+                         "set-up before the timed region leaves it idle for seconds; 0 = off")
     ap.add_argument("--timing-stride", type=int, default=4,
                     help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms)")
     ap.add_argument("--force-dist", action="store_true",
@@ -218,10 +223,30 @@ def main():
             dist.barrier()
 
     dt = 1e-4
+    # Device spin-up (see --spinup-ms): the cloud itself is untouched, the W warm-up steps and the K timed steps below
+    # are the first steps it ever takes.
+    spinup = None
+    if args.spinup_ms > 0 and cloud.n > 0:
+        sp = lambda a: a.data_ptr()   # noqa: E731
+        sx, sy, sz, sc = (a[:cloud.n].clone() for a in (cloud.x, cloud.y, cloud.z, cloud.cell))
+        # (the statistics-on instantiation, like the warm-up steps: a profiler's per-kernel average of the headline
+        # instantiation then covers the timed launches and nothing else)
+        ctx.set_option("stats", 1)
+        torch.cuda.synchronize()
+        ts, launches = time.perf_counter(), 0
+        while (time.perf_counter() - ts) * 1e3 < args.spinup_ms:
+            for _ in range(40):
+                ctx.step_dev(sp(sx), sp(sy), sp(sz), sp(sc), None, None, cloud.n, dt, 0.0, 0, 1, 0)
+            launches += 40
+            torch.cuda.synchronize()
+        spinup = {"ms": round((time.perf_counter() - ts) * 1e3, 1), "launches": launches,
+                  "on": "a scratch copy of the rank's cloud, discarded; the cloud's own first steps are the warm-up steps"}
+        del sx, sy, sz, sc
     ctx.set_option("stats", 1)
+    counters0 = ctx.counters()
     cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
     torch.cuda.synchronize(); barrier()
-    counters = ctx.counters()
+    counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
     ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
     n_before = cloud.global_count()
     # live kernel timing for the roofline: HIP events around every 4th launch of the timed region (a pair around
@@ -291,7 +316,10 @@ def main():
             ts = time.perf_counter()
             cloud.step(dt, k)
             torch.cuda.synchronize()
+            # (not the same workload as the timed region any more: with every boundary reflecting and a uniform
+            # (10,0,0) field the cloud drifts towards the outlet wall, 1 mm per step, and piles up there)
             steady = {"steps": k, "ms_per_step": round((time.perf_counter() - ts) / k * 1e3, 4),
+                      "first_step": cloud.step_index - k,
                       "sorts_inside": (cloud.step_index // max(1, cloud.sort_interval)) -
                                       ((cloud.step_index - k) // max(1, cloud.sort_interval)) if cloud.sort_interval else 0}
         if args.brownian_extra > 0:
@@ -353,7 +381,7 @@ def main():
                                           "handoffs": len(comm_events),
                                           "host_ms_per_step": round(handoff_host_ms / max(1, args.steps), 4)}
                                          if (world > 1 or args.force_dist) else None),
-                       "ms_per_step_steady": steady, "brownian": brown,
+                       "ms_per_step_steady": steady, "brownian": brown, "device_spinup": spinup,
                        "extra_fused_cycles": fused,
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),

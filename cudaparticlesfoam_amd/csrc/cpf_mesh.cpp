@@ -57,7 +57,9 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
                          int64_t nCells, HostTables& out) {
     if (nCells <= 0 || nFaces <= 0 || nPoints <= 0) return "empty mesh";
     if (nInternal < 0 || nInternal > nFaces) return "nInternal out of range";
-    if (nCells > INT32_MAX - 2 || nFaces > INT32_MAX - 2) return "mesh too large for 32-bit cell/face ids";
+    // (boundary faces are coded -(face + 1) in the neighbour table; the few codes next to INT32_MIN are reserved:
+    // the walk's "no cell yet" token and the streaming kernel's "sat this round out")
+    if (nCells > INT32_MAX - 16 || nFaces > INT32_MAX - 16) return "mesh too large for 32-bit cell/face ids";
     if (faceOff[0] != 0) return "faceOffsets[0] != 0";
     for (int64_t f = 0; f < nFaces; ++f) {
         int64_t nv = (int64_t)faceOff[f + 1] - (int64_t)faceOff[f];

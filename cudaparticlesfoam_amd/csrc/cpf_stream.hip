@@ -36,6 +36,11 @@ namespace cpf {
 #endif
 constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
 static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
+#ifndef CPF_STREAM_GATHER_LANES
+#define CPF_STREAM_GATHER_LANES 32
+#endif
+constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a record slot from which a round gathers (0: always)
+constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS>
 struct StreamOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? CPF_STREAM_WAVES : 1; };
@@ -268,7 +273,13 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                     else if (younger >= 2) wait_vmcnt<2>();
                     else wait_vmcnt<0>();
                 }
-                // ---- every busy lane does one cell visit
+                // ---- every busy lane does one cell visit -- unless it was left without a record slot (more new cells
+                // than the round can place) in a round where few lanes were: the second and third round of a tile on a
+                // 3-D mesh, 5 ... 10 distinct cells.  Such a lane sits the round out (next = kSitOut) and its cell is
+                // placed in the next round; running the per-lane gather walk for a handful of lanes makes the whole
+                // wave pay a second trace (measured on the 3-D bench mesh: two of every three rounds did).  When many
+                // lanes are without a slot (a cloud that is not kept sorted) the gather walk keeps the wave moving.
+                const bool gatherRound = __popcll(missLanes) >= kStreamGatherLanes;
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane = {0, 0, 0, 0};
@@ -289,40 +300,44 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                             sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                             needAdvect = false;
                         }
-                        next = trace_lds6(S_, E, cur, rec, token, outSlot);
+                        next = trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
                         // the wall's plane is read HERE, where the record's address space is known: one expression
                         // choosing between the LDS slot and the global record becomes a flat load (vmcnt + lgkmcnt 0)
                         if (REFLECT && next < 0) wallPlane = rec[outSlot];
                     } else {
                         // no slot: more distinct new cells in the wave than the round can place (a cloud that is not
                         // kept sorted).  Per-lane gathers keep such a wave moving.
-                        const double4* rec = m.cellRec + 8 * (int64_t)cur;
-                        if (needAdvect) {
-                            const double4 u = rec[6];
-                            v = {u.x, u.y, u.z};
-                            const D3 Pn = axpy(dt, v, P);
-                            D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
-                            if (BROWNIAN) {
-                                const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
-                                disp = axpy(sigma, xi, disp);
+                        next = kSitOut;
+                        if (gatherRound) {
+                            const double4* rec = m.cellRec + 8 * (int64_t)cur;
+                            if (needAdvect) {
+                                const double4 u = rec[6];
+                                v = {u.x, u.y, u.z};
+                                const D3 Pn = axpy(dt, v, P);
+                                D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                                if (BROWNIAN) {
+                                    const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                                    disp = axpy(sigma, xi, disp);
+                                }
+                                E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                                sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                                needAdvect = false;
                             }
-                            E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
-                            sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                            needAdvect = false;
-                        }
-                        next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
-                        // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending at
-                        // the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
-                        if (REFLECT && next < 0) {
-                            wallPlane = rec[outSlot];
-                            asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
+                            next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                            // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
+                            // at the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
+                            if (REFLECT && next < 0) {
+                                wallPlane = rec[outSlot];
+                                asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
+                            }
                         }
                     }
-                    if (STATS) ++st.hops;
+                    if (STATS && next != kSitOut) ++st.hops;
                     if (next == cur) {
                         busy = false;                                              // segment ends in this cell
-                    } else if (next < 0) {                                         // boundary face
-                        if (!REFLECT) { busy = false; lostNow = true; }
+                    } else if (next < 0) {                                         // boundary face, or sitting this round out
+                        if (next == kSitOut) {
+                        } else if (!REFLECT) { busy = false; lostNow = true; }
                         else {
                             // mirror end point and velocity about the wall (ConvexQuery.cu:286-309)
                             sHit[0][lane] = S_.x; sHit[1][lane] = S_.y; sHit[2][lane] = S_.z;

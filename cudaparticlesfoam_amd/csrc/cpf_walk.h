@@ -114,10 +114,13 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
 // before the wave-uniform skips, so a round pays three LDS round trips instead of six (the per-face branches keep
 // the compiler from hoisting the reads itself, and this kernel is bound by the length of each wave's dependent
 // chain, not by instruction issue).
+// ZERO_SKIP: try the zero-denominator skip at all -- pointless (a compare and a branch per face) once every particle
+// has a displacement along every axis, i.e. with the Brownian kick; results are the same with or without it.
+template <bool ZERO_SKIP>
 __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0, const D3& Pd, int token, int s,
                                           double& dTmin, int& next, int& best) {
     const double den = dot3(p, Pd);
-    if (ballot64(den != 0.0) == 0ull) return;          // see trace_fixed: nobody crosses this plane
+    if (ZERO_SKIP && ballot64(den != 0.0) == 0ull) return;          // see trace_fixed: nobody crosses this plane
     const double fd = plane_dist(p, P0);
     // Cheap wave-uniform skip, exact test only where it can matter.  A lane can be accepted only if |fd| <= |den| with
     // equal signs and fd < tol: from inside (fd < 0) that means den <= fd; every other acceptable lane has fd >= 0
@@ -157,6 +160,7 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
 #else
 #define CPF_PIN_W(a, b)
 #endif
+template <bool ZERO_SKIP = true>
 __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
@@ -167,22 +171,22 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
         double4 p0 = rec[0], p1 = rec[1];
         const int2 b = nb[0];
         CPF_PIN_W(p0, p1)
-        face_test(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
-        face_test(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
+        face_test<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
+        face_test<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
     }
     {
         double4 p2 = rec[2], p3 = rec[3];
         const int2 b = nb[1];
         CPF_PIN_W(p2, p3)
-        face_test(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
-        face_test(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
+        face_test<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
+        face_test<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
     {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
         CPF_PIN_W(p4, p5)
-        face_test(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
-        face_test(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
+        face_test<ZERO_SKIP>(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
+        face_test<ZERO_SKIP>(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
     }
     if (best >= 0) {
         S = axpy(dTmin, Pd, P0);

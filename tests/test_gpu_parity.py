@@ -52,7 +52,7 @@ def test_initial_locate_matches_bruteforce(setup):
     assert n_out == int((ref < 0).sum()) and 0 < n_out < n
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
 def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     """Every kernel variant (generic CSR walk, all-hex fixed-slot walk, + wave-uniform scalar plane fetches,
@@ -695,7 +695,7 @@ def test_ragged_sizes(setup, n):
     ref_c = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t)
     x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref_c.copy()
     cw.step(x, y, z, c, 1e-4, 25, t, U)
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5):
         ctx.set_option("step_variant", variant)
         ctx.set_particles(xyz)
         ctx.locate_initial()

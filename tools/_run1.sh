@@ -1,17 +1,7 @@
 cd $GRAFT_REPO_ROOT
-T="timeout -s KILL 300"
-LIB=cudaparticlesfoam_amd/lib/libcudaParticleAdvection.so; cp $LIB /tmp/lib_orig.so
-CPF_CHECK_VARIANT=4 $T python tools/stream_check.py 2>&1 | tail -2
-for L in t0 t2 t3 t5 t0 t2 t3; do cp build_ab/lib_$L.so $LIB
-$T python tools/stream_timeline.py --label $L --groups 2>&1 | grep kernel_ms | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(d['label'], d['kernel_ms'], 'end', d['end_us_pct'], 'grp_last', d['group_last_end_pct'], 'busy', d['slot_busy_fraction'])"
-done
-cp build_ab/lib_t2.so $LIB
-for o in 0.05 0.2 0.3; do $T python tools/stream_timeline.py --label t2_tail$o --opt stream_tail_fraction=$o --groups 2>&1 | grep kernel_ms | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(d['label'], d['kernel_ms'], 'end', d['end_us_pct'], 'grp_last', d['group_last_end_pct'], 'busy', d['slot_busy_fraction'])"
-done
-cp /tmp/lib_orig.so $LIB
+mkdir -p gpurun_out
+timeout -s KILL 1700 python -m pytest tests -x -q -m gpu > gpurun_out/r02_gputest.log 2>&1; grep -E "passed|failed|error" gpurun_out/r02_gputest.log | tail -3
+timeout -s KILL 400 python bench.py > gpurun_out/r02_bench_1gpu.json 2> gpurun_out/r02_bench_1gpu.err; cut -c1-200 gpurun_out/r02_bench_1gpu.json
+timeout -s KILL 700 bash tools/profile_run.sh r02 > gpurun_out/r02_profile_run.log 2>&1; tail -2 gpurun_out/r02_profile_run.log | cut -c1-200
+timeout -s KILL 600 bash tools/profile_3d.sh r02 2>&1 | grep kernel_ms | cut -c1-200
+timeout -s KILL 300 python tools/bench_pimple.py 2>&1 | tail -1 | cut -c1-400

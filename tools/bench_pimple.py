@@ -37,6 +37,9 @@ def main():
     ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
     dt = 1e-4 / a.refine
     ctx.step_dev(p(x), p(y), p(z), p(c), p(g), None, n, dt, 0.0, 0, 5, 0); torch.cuda.synchronize()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _spinup import device_spinup
+    device_spinup(ctx, torch, x, y, z, c, n, dt)
     up = 0.0; ctx.timing_enable(True)
     torch.cuda.synchronize(); w0 = time.perf_counter()
     for e in range(a.eulerian_steps):

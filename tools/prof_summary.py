@@ -25,10 +25,17 @@ def kernel_stats(d):
         a = agg.setdefault(name, dict(calls=0, total_us=0.0, min_us=1e30, max_us=0.0, vgpr=r.get("VGPR_Count") or r.get("Arch_VGPR_Count"),
                                       sgpr=r.get("SGPR_Count"), lds=r.get("LDS_Block_Size"), wg=r.get("Workgroup_Size")))
         a["calls"] += 1; a["total_us"] += dur; a["min_us"] = min(a["min_us"], dur); a["max_us"] = max(a["max_us"], dur)
+        a.setdefault("_each", []).append((int(r["Start_Timestamp"]), dur))
     tot = sum(a["total_us"] for a in agg.values()) or 1.0
     lst = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["total_us"]):
+        each = [d_ for _, d_ in sorted(a.pop("_each"))]
         a = dict(a, kernel=name[:140], avg_us=a["total_us"] / a["calls"], pct=100 * a["total_us"] / tot)
+        # the LAST 100 launches of a kernel: for the step kernel of `bench.py --steady-steps 0 --brownian-extra 0` that
+        # is the timed region (what comes before is the device spin-up on a scratch copy and nothing comes after)
+        if len(each) > 100:
+            a["last100_avg_us"] = sum(each[-100:]) / 100.0
+            a["first100_avg_us"] = sum(each[:100]) / 100.0
         lst.append(a)
     return lst
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--label", default="")
     ap.add_argument("--pre-steps", type=int, default=5, help="steps after the sort and before the measured launch")
     ap.add_argument("--variant", type=int, default=4)
+    ap.add_argument("--D", type=float, default=0.0, help="diffusion coefficient of the measured launches")
     ap.add_argument("--groups", action="store_true", help="also per-group (= per-CU) and per-XCD end times")
     ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh of tools/bench_3d.py, swirl field")
     args = ap.parse_args()
@@ -58,11 +59,11 @@ def main():
     tl = torch.zeros(4 * 16384, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
     for _ in range(args.pre_steps):
-        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, 1, 0)
+        ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, 1e-4, args.D, 0, 1, 0)
     torch.cuda.synchronize()
     tl.zero_()
     ctx.timing_enable(True)
-    ctx.step_dev(p(x), p(y), p(z), p(c), None, p(tl), n, 1e-4, 0.0, 5, 1, 0)
+    ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, 1e-4, args.D, 5, 1, 0)
     launches, ms = ctx.timing_read()
     t = tl.cpu().numpy().reshape(-1, 4)
     idx = np.nonzero(t[:, 1] > 0)[0]
