@@ -93,3 +93,25 @@ def test_slab_bounding_boxes_tile_the_domain(pitz):
             assert a[0] <= prev_hi + 1e-12            # neighbouring slabs touch or overlap by one column
         prev_hi = b[0]
     assert abs(slab_bounding_box(mesh, 0, mesh.n_cells)[0][0] - mesh.points[:, 0].min()) < 1e-15
+
+
+def test_tjunction_counts_patches_and_geometry():
+    """The second tutorial (cudaParticlesPimpleFoam/TJunction): 4 blocks of 1 mm cells, three open patches."""
+    from cudaparticlesfoam_amd.cases import tjunction as tj
+    mesh = tj.tjunction_mesh()
+    assert (mesh.n_cells, mesh.n_points, mesh.n_faces, mesh.n_internal) == (tj.N_CELLS, tj.N_POINTS, tj.N_FACES, tj.N_INTERNAL)
+    assert {name: size for name, _, _, size in mesh.patches} == tj.PATCH_SIZES
+    c, v = mesh.cell_centres_volumes()
+    assert abs(v.sum() - (0.2 * 0.02 * 0.02 + 0.02 ** 3 + 2 * 0.02 * 0.2 * 0.02)) < 1e-15 and np.allclose(v, 1e-9)
+    fc, fa = mesh.face_centres_areas()
+    where = {name: (fc[s:s + k].min(0), fc[s:s + k].max(0)) for name, _, s, k in mesh.patches}
+    assert where["inlet"][1][0] == 0.0 and abs(where["outlet1"][1][1] + 0.21) < 1e-12 and abs(where["outlet2"][0][1] - 0.21) < 1e-12
+    nI = mesh.n_internal
+    assert (mesh.owner[:nI] < mesh.neighbour).all() and (((fc - c[mesh.owner]) * fa).sum(1) > 0).all()
+    off, _ = mesh.cell_faces()
+    assert (np.diff(off) == 6).all()
+    U = tj.split_flow_u(mesh, c, 0.3)
+    assert np.linalg.norm(U, axis=1).max() * tj.PARTICLE_DICT["dt"] < 1e-3      # under one cell per Lagrangian cycle
+    # the seeding box of the dict lies in the inlet duct
+    lo, hi = tj.PARTICLE_DICT["seedingBox"]
+    assert lo[0] >= 0 and hi[0] <= 0.2 and abs(lo[1]) <= 0.01 and abs(hi[1]) <= 0.01

@@ -19,6 +19,10 @@ def main():
     v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
                   [0, 0.05, 0.05]], float)
     mesh = block_mesh(v, [dict(hex=range(8), n=(64, 64, 60), simple=(2.0, 1.0, 0.5))])
+    tjunction = os.environ.get("CPF_TJUNCTION")           # the reference's TJunction tutorial mesh instead (248 000 cells)
+    if tjunction:
+        from cudaparticlesfoam_amd.cases import tjunction as tj
+        mesh = tj.tjunction_mesh()
     c, _ = mesh.cell_centres_volumes()
     dev = torch.device("cuda", 0)
     ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -27,12 +31,26 @@ def main():
         ctx.set_option("step_variant", int(os.environ["CPF_VARIANT"]))
     for kv in os.environ.get("CPF_OPTS", "").split():
         k_, v_ = kv.split("="); ctx.set_option(k_, float(v_))
-    fields = {"diagonal (10,2,1)": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
+    if tjunction:
+        fields = {"TJunction split flow u0=3": tj.split_flow_u(mesh, c, 0.5), "TJunction split flow u0=5": tj.split_flow_u(mesh, c, 0.5, u0=5.0)}
+        box = tj.DOMAIN_BOX
+    else:
+        box = ((0, 0, 0), (0.3, 0.05, 0.05))
+    fields = fields if tjunction else {"diagonal (10,2,1)": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
               "swirl": np.stack([10.0 + 0 * c[:, 0], 4 * np.sin(40 * c[:, 2]), 4 * np.cos(40 * c[:, 1])], 1)}
     torch.manual_seed(7)
-    x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
-    y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
-    z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+    if tjunction:
+        # uniform over the T: the duct (80 cm^3 ... in mm^3: 80 000) and the cross bar (168 000)
+        na = int(n * 80.0 / 248.0)
+        u = torch.rand((3, n), dtype=torch.float64, device=dev)
+        x = torch.where(torch.arange(n, device=dev) < na, u[0] * 0.2, 0.2 + u[0] * 0.02).contiguous()
+        y = torch.where(torch.arange(n, device=dev) < na, -0.01 + u[1] * 0.02, -0.21 + u[1] * 0.42).contiguous()
+        z = (u[2] * 0.02).contiguous()
+        del u
+    else:
+        x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
+        y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+        z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
     cell = torch.empty(n, dtype=torch.int32, device=dev); gid = torch.arange(n, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
     for name, U in fields.items():
