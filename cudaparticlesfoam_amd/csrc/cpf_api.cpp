@@ -53,6 +53,7 @@ struct cpf_context {
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = 4;                        // cpf_set_option("step_variant"), see include/cpf.h
     cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
+    int64_t lastStepN = -1;                     // particle count of the most recent step launch (cpf_step_kernel_name)
     // "VertexVelocity" advect only: the tet decomposition and one velocity per tet-mesh vertex
     double* d_tetPos = nullptr; int32_t* d_tets = nullptr; double* d_vertVel = nullptr;
     int64_t nTetVerts = 0, nTets = 0; int tetsPerCell = 0; bool haveVertVel = false;
@@ -437,6 +438,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
+        ctx->lastStepN = n;
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                       reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
                                       &ctx->streamState));
@@ -574,6 +576,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->streamState.tailFraction = value;
         return CPF_OK;
     }
+    if (k == "stream_lookup") {
+        CPF_REQUIRE(ctx, value >= -1 && value <= 1, CPF_ERR_ARG, "stream_lookup must be -1 (auto), 0 or 1");
+        ctx->streamState.lookup = (int)value;
+        return CPF_OK;
+    }
     if (k == "stream_debug") {
         ctx->streamState.debug = (int)value;
         return CPF_OK;
@@ -618,7 +625,11 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     char tmp[160];
     if (v == 5 && !brown && !sv && !(flags & CPF_STEP_FUSE_CYCLES))
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
-    else if (v == 4 || v == 5) snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
+    else if (v == 4 || v == 5) {
+        // (the record lookup is picked per launch from the particle count: the most recent launch's, else the owned cloud's)
+        const bool lf = cpf::stream_lookup_fixed(ctx->lastStepN >= 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState);
+        snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats], b[lf]);
+    }
     else if (v == 3) snprintf(tmp, sizeof tmp, "cpf::step_kernel_coop<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
     else snprintf(tmp, sizeof tmp, "cpf::step_kernel<%d, %s, %s, %s>", v, b[brown], b[reflect], b[sv]);
     snprintf(buf, bufBytes, "%s", tmp);

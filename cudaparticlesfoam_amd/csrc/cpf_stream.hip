@@ -45,7 +45,7 @@ constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS>
 struct StreamOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? CPF_STREAM_WAVES : 1; };
 
-template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS>
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, bool LOOKUP_FIXED>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_stream(
     double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, int32_t* __restrict__ cell,
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
@@ -217,26 +217,61 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 #ifdef CPF_STREAM_TIMELINE
                 ++tlRounds;
 #endif
-                // ---- record cache lookup, one scalar iteration per DISTINCT cell of the busy lanes (one or two after
-                // a sort).  A round that finds every cell on chip (the common case) issues no memory request.
+                // ---- record cache lookup, two ways (LOOKUP_FIXED, chosen per launch by stream_lookup_fixed()).  Few particles per cell
+                // (3-D meshes: 5-10 distinct cells per round): every lane compares its cell with the NS tags (tag k
+                // broadcast from lane k of tagv), a fixed, branch-free sequence of 3 vector instructions per tag.  Many
+                // particles per cell (pitzDaily: 1-3 distinct cells per round): one scalar iteration per DISTINCT cell
+                // of the busy lanes, ~7 vector + 14 scalar instructions each -- fewer VECTOR instructions there, and those
+                // are what that case is short of (measured: the fixed sequence costs pitzDaily 1.5-3 %, and saves the
+                // large meshes 4-7 %; both in ONE kernel behind a run-time flag: the worse of the two everywhere, hence
+                // the template parameter).  A round that finds every cell on chip (the common case) issues no memory request.
                 const unsigned long long busyMask = ballot64(busy);
                 int myslot = -1;
                 unsigned used = 0;
-                unsigned long long todo = busyMask, missLanes = 0ull;
-                while (todo != 0ull) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int ck = __builtin_amdgcn_readlane(cur, leader);
-                    const bool mine = cur == ck;
-                    const unsigned long long same = ballot64(mine) & busyMask;
-                    const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)ck, 32 /* eq */);
-                    if (hitTag != 0ull) {
-                        const int sl = __ffsll((long long)hitTag) - 1;
-                        used |= 1u << sl;
-                        if (mine) myslot = sl;
+                unsigned long long missLanes = busyMask;
+                if (LOOKUP_FIXED) {
+                    // (one cell for the whole wave -- nine first rounds of ten on a mesh with hundreds of particles per cell
+                    // -- needs one compare against the tag vector, not six against the cells)
+                    const int cell0 = __builtin_amdgcn_readlane(cur, __ffsll((long long)busyMask) - 1);
+                    const unsigned long long in0 = __builtin_amdgcn_uicmp((unsigned)cur, (unsigned)cell0, 32 /* eq */) & busyMask;
+                    if (in0 == busyMask) {
+                        const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)cell0, 32 /* eq */) & ALL;
+                        if (hitTag != 0ull) {
+                            myslot = __ffsll((long long)hitTag) - 1;
+                            used = (unsigned)hitTag;
+                            missLanes = 0ull;
+                        }
                     } else {
-                        missLanes |= same;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const int tk = __builtin_amdgcn_readlane(tagv, k);
+                            const unsigned long long eqK = __builtin_amdgcn_uicmp((unsigned)cur, (unsigned)tk, 32 /* eq */);
+                            const unsigned long long inK = eqK & busyMask;
+                            // (one select per tag on the compare's own mask; left alone, hipcc issues a second, inverted
+                            // compare per tag to get the constant into the operand slot it prefers)
+                            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(myslot) : "v"(myslot), "n"(k), "s"(eqK));
+                            used |= (inK != 0ull ? 1u : 0u) << k;
+                            missLanes &= ~inK;
+                        }
                     }
-                    todo &= ~same;
+                } else {
+                    unsigned long long todo = busyMask;
+                    missLanes = 0ull;
+                    while (todo != 0ull) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const int ck = __builtin_amdgcn_readlane(cur, leader);
+                        const bool mine = cur == ck;
+                        const unsigned long long same = ballot64(mine) & busyMask;
+                        const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)ck, 32 /* eq */);
+                        if (hitTag != 0ull) {
+                            const int sl = __ffsll((long long)hitTag) - 1;
+                            used |= 1u << sl;
+                            if (mine) myslot = sl;
+                        } else {
+                            missLanes |= same;
+                        }
+                        todo &= ~same;
+                    }
                 }
                 // ---- misses: up to four records per round, each a 256-byte LDS-DMA by lanes 0..15 straight into its
                 // slot; victims are taken oldest-first among the slots nobody reads this round
@@ -424,14 +459,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 // ------------------------------------------------------------------------------------------------
 // launcher: persistent grid sized by the occupancy of the instantiation
 // ------------------------------------------------------------------------------------------------
-template <bool B, bool R_, bool SV, bool ST>
+template <bool B, bool R_, bool SV, bool ST, bool LF>
 static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                                      double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
                                      uint32_t seed, const MeshView& m, unsigned long long* counters, StreamState& ss) {
     static int wavesPerCU = 0;                       // per instantiation; benign race (same value)
     if (wavesPerCU == 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream<B, R_, SV, ST>, 64, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream<B, R_, SV, ST, LF>, 64, 0);
         if (e != hipSuccess) return e;
         wavesPerCU = nb < 1 ? 1 : (nb > 32 ? 32 : nb);
     }
@@ -451,18 +486,27 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     unsigned* cur = ss.d_grab + (size_t)(ss.parity & 1) * kStreamGroups * kStreamCounterStride;
     unsigned* nxt = ss.d_grab + (size_t)((ss.parity & 1) ^ 1) * kStreamGroups * kStreamCounterStride;
     StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug};
-    hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
+    hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
                        gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
     ss.parity ^= 1;
     return hipGetLastError();
+}
+
+// few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
+bool stream_lookup_fixed(int64_t n, const MeshView& m, const StreamState& ss) {
+    return ss.lookup >= 0 ? ss.lookup != 0 : n < 128 * (int64_t)m.nCells;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
                               bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
                               StreamState& ss) {
-#define CPF_STREAM_GO(B, R, SV, ST) \
-    return launch_stream_inst<B, R, SV, ST>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss)
+    const bool lf = stream_lookup_fixed(n, m, ss);
+#define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
+    do {                                                                                                                     \
+        if (lf) return launch_stream_inst<B, R, SV, ST, true>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
+        return launch_stream_inst<B, R, SV, ST, false>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);         \
+    } while (0)
 #define CPF_STREAM_SV(B, R)                                                                     \
     do {                                                                                        \
         if (storeVel) { if (counters) CPF_STREAM_GO(B, R, true, true); else CPF_STREAM_GO(B, R, true, false); } \

@@ -181,7 +181,9 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                     Fewer rounds per tile but dearer rounds: measured SLOWER than 4 on every mesh;
  *                     only the plain reflect / no-reflect step without Brownian or stored velocity, else 4 runs
  *   "stream_tiles_per_chunk" (4), "stream_tail_fraction" (0.1), "stream_waves_per_cu" (0 = occupancy query):
- *                   work distribution of variant 4; "stream_debug" is a diagnostic (results are WRONG when non-zero)
+ *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
+ *                   distinct cells of a wave, 1 fixed tag compare): how a wave finds its cells in its record cache;
+ *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference
  *                   has no such diagnostics, and they cost the step kernel a resident wave (0.16 -> 0.22 ms
  *                   per 1e7-particle launch)
@@ -190,7 +192,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   invisible to callers: cpf_get_particles always answers in particle-id order */
 int cpf_set_option(cpf_context* ctx, const char* key, double value);
 /* Name of the kernel instantiation cpf_step / cpf_step_dev launches for this diffusion coefficient and these flags with
- * the current mesh and options, as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false>"):
+ * the current mesh and options (and the particle count of the most recent step launch, which picks the record lookup of
+ * the streaming kernel), as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false, false>"):
  * lets a benchmark label its roofline with what actually ran. */
 int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes);   /* Brownian stream; default 1591593751 (particles.cu:544) */
 

@@ -684,6 +684,59 @@ def test_config5_transient_velocity_on_refined_mesh(oracle_libs, gpu_ctx_factory
     assert upload / 5 < 0.05                        # 4.7 MB per refresh; the reference would move 56 MB
 
 
+@pytest.mark.parametrize("lookup", [0, 1])
+@pytest.mark.parametrize("sort", [True, False])
+def test_stream_record_lookup_methods(setup, lookup, sort):
+    """The streaming kernel finds a wave's cells in its record cache either by a loop over the distinct cells or by a
+    fixed compare against the tag vector (option stream_lookup; picked per launch from the particles per cell).  Both,
+    on a sorted cloud (1-3 cells per wave) and an unsorted one (up to 64: gather rounds, lanes sitting rounds out),
+    with and without the Brownian kick: bit-identical to the CPU statement."""
+    pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
+    U = setup["pitz"]["U_analytic"]
+    n = 60000
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=4242)
+    ctx.set_option("step_variant", 4)
+    ctx.set_option("stream_lookup", lookup)
+    ctx.set_option("sort_interval", 0 if not sort else 50)
+    ctx.set_velocity(U)
+    for D in (0.0, 1.5e-5):
+        ctx.set_particles(xyz)
+        ctx.locate_initial()
+        _, cell0 = ctx.get_particles()
+        if sort:
+            ctx.sort_by_cell()
+        x, y, z = (xyz[:, k].copy() for k in range(3))
+        c = cell0.copy()
+        name = ctx.step_kernel_name(D)
+        assert name.endswith(", %s>" % ("true" if lookup else "false")) and "step_kernel_stream" in name
+        if D == 0.0:
+            for k in (1, 12):
+                ctx.step(1e-4, D, k)
+                cw.step(x, y, z, c, 1e-4, k, t, U, nthreads=cw.max_threads)
+                xyzw, cell = ctx.get_particles()
+                assert np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y)
+        else:
+            # same (seed, gid, step) stream for both methods: explicit step numbers at the device-array level
+            import torch
+            dev = torch.device("cuda", 0)
+            xyzw, cell = ctx.get_particles()
+            order = np.argsort(cell, kind="stable") if sort else np.arange(n)
+            tx, ty, tz = (torch.from_numpy(xyzw[order, k].copy()).to(dev) for k in range(3))
+            tc = torch.from_numpy(cell[order].copy()).to(dev)
+            tg = torch.from_numpy(order.astype(np.int64)).to(dev)
+            torch.cuda.synchronize()
+            ctx.step_dev(tx.data_ptr(), ty.data_ptr(), tz.data_ptr(), tc.data_ptr(), tg.data_ptr(), None, n, 1e-4, D, 1000, 8, 0)
+            ctx.synchronize()
+            got = tuple(a.cpu().numpy() for a in (tx, ty, tz, tc))
+            ref = setup.setdefault("_lookup_ref", {})
+            if sort in ref:                                       # the two methods agree bit for bit with each other
+                assert all(np.array_equal(a, b) for a, b in zip(ref[sort], got))
+            else:
+                ref[sort] = got
+    ctx.set_option("stream_lookup", -1)
+    ctx.set_option("sort_interval", 50)
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000])
 def test_ragged_sizes(setup, n):
     """Cloud sizes around the wave (64) and block (256) boundaries, every kernel variant: no lane of a partial

@@ -7,13 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(ROOT, "gpurun_out", label + "_summary.json")))
 # the timed launches run the statistics-off instantiation, the warm-up launches the statistics-on one: take the
 # instantiation with the most launches
-main = "<false, true, false, false>"     # no Brownian kick, reflecting walls, no stored velocity, statistics off
+main = "<false, true, false, false, false>"     # no Brownian kick, reflecting walls, no stored velocity, statistics off
 ks = max((k for k in d["kernels"] if "step_kernel" in k["kernel"] and main in k["kernel"]), key=lambda k: k["calls"])
 pmc = max((v for k, v in d["pmc"].items() if main in k), key=lambda v: v["dispatches"])
 cal = max(d["calibration_zero_cycle_step"].values(), key=lambda v: v["dispatches"])
 n = 10_000_000
 ff = (28 * n) / (cal["FETCH_SIZE_KB"] * 1024); wf = (28 * n) / (cal["WRITE_SIZE_KB"] * 1024)
-spin = [k for k in d["kernels"] if "step_kernel" in k["kernel"] and "<false, true, false, true>" in k["kernel"]]
+spin = [k for k in d["kernels"] if "step_kernel" in k["kernel"] and "<false, true, false, true, false>" in k["kernel"]]
 hbm = pmc["FETCH_SIZE_KB"] * 1024 * ff + pmc["WRITE_SIZE_KB"] * 1024 * wf
 out = dict(label=label, kernel=ks["kernel"].split("(")[0], particles_per_launch=n,
            rocprofv3_kernel_trace=dict(calls=ks["calls"], avg_us=round(ks["avg_us"], 2), min_us=round(ks["min_us"], 2),

@@ -53,6 +53,8 @@ def main():
                 ctx.set_option("stats", stats)
                 ctx.set_option("stream_tiles_per_chunk", tpc)
                 ctx.set_option("stream_tail_fraction", il)
+                if os.environ.get("CPF_CHECK_LOOKUP"):
+                    ctx.set_option("stream_lookup", int(os.environ["CPF_CHECK_LOOKUP"]))
                 x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0_.clone()
                 vel = torch.zeros(3 * n, dtype=torch.float64, device=dev) if sv else None
                 cnt0 = ctx.counters()
