@@ -15,7 +15,7 @@ SETS=(
 )
 k=0
 for S in "${SETS[@]}"; do
-  rocprofv3 --kernel-trace --pmc $S --output-format csv -d "$OUT/set$k" -- python3 tools/sweep.py --no-floor --variants "$VARS" --steps 6 --warmup 2 "$@" > "$OUT/set$k.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $S --output-format csv -d "$OUT/set$k" -- python3 tools/sweep.py --no-floor --spinup-ms 0 --variants "$VARS" --steps 6 --warmup 2 "$@" > "$OUT/set$k.log" 2>&1
   k=$((k+1))
 done
 python3 - <<PY

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--store-vel", action="store_true", help="also store the velocity per particle (output cycles)")
     ap.add_argument("--opt", action="append", default=[], help="cpf_set_option key=value (repeatable), e.g. stream_tiles_per_chunk=8")
     ap.add_argument("--label", default="")
+    ap.add_argument("--spinup-ms", type=float, default=100.0)
     ap.add_argument("--no-floor", action="store_true", help="skip the zero-cycle launches (they would mix into PMC means)")
     args = ap.parse_args()
     import torch
@@ -61,6 +62,12 @@ def main():
         vel = torch.empty(3 * n, dtype=torch.float64, device=dev) if args.store_vel else None
         fl = args.flags | (2 if args.store_vel else 0)
         pv = None if vel is None else vel.data_ptr()
+        if args.spinup_ms > 0:                   # steady device clocks (tools/_spinup.py); PMC passes switch it off
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from _spinup import device_spinup
+            stats_on = not args.no_stats
+            device_spinup(ctx, torch, x, y, z, c, n, 1e-4, args.spinup_ms)
+            ctx.set_option("stats", 1 if stats_on else 0)
         ctx.step_dev(p(x), p(y), p(z), p(c), None, pv, n, 1e-4, args.D, 0, args.warmup, fl)
         torch.cuda.synchronize()
         ctx.timing_enable(True)
