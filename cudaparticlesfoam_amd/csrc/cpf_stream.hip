@@ -17,11 +17,15 @@
 //     tile to tile.  The cloud is kept sorted by (cell, sub-box), a chunk sits in one or two cells and their
 //     downstream neighbours, so after a chunk's first tile almost every round finds all its records on chip and
 //     issues no memory request at all.  Tags live in ONE vector register (lane k = the cell in slot k): the lookup
-//     is a compare against the scalar cell id per distinct cell of the wave, the update one predicated move.
+//     is a compare against the scalar cell id per distinct cell of the wave -- or, on meshes with few particles per
+//     cell, six compares of every lane's cell against the broadcast tags (template parameter LOOKUP_FIXED) -- the
+//     update one predicated move.
 //
 // Crossing particles are not compacted into dense waves: what compaction is meant to buy -- finished lanes' slots
 // going to particles whose loads are already in flight -- is what the prefetch does at tile granularity, and the
-// sort key (cell, position in the cell's box) keeps the lanes of a tile in step.
+// sort key (cell, position in the cell's box) keeps the lanes of a tile in step.  (The per-lane version of that idea,
+// lanes running ahead into the next tile, is step_kernel_ahead in cpf_ahead.hip: fewer rounds, dearer rounds,
+// slower on every mesh -- DESIGN.md 5.4.)
 #include "cpf_stream_ops.h"
 
 #include <type_traits>
