@@ -162,6 +162,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or args.force_dist:
+        # stdout belongs to the ONE JSON line.  This image exports NCCL_DEBUG=VERSION, which makes every rank print a
+        # five-line banner on stdout (NCCL_DEBUG_FILE does not move it): ask for warnings only instead, send whatever
+        # else RCCL logs to stderr, and print the JSON after everything else has been flushed (below)
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
@@ -400,11 +406,18 @@ def main():
             except Exception as e:          # the checker being absent must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
                                        "sample": "unavailable: %r" % (e,)}
-        print(json.dumps(out), flush=True)
     if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: anything a library left in C stdio's buffer goes out before it
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-PMC_CMD="tools/sweep.py --no-floor --spinup-ms 0 --variants 4 --steps 20 --warmup 2 --no-stats" timeout -s KILL 700 bash tools/pmc_3d.sh pitz > gpurun_out/r02_sq_pitz.txt 2>&1
-timeout -s KILL 700 bash tools/pmc_3d.sh m3d > gpurun_out/r02_sq_3d.txt 2>&1
-CPF_TJUNCTION=1 timeout -s KILL 700 bash tools/pmc_3d.sh tj > gpurun_out/r02_sq_tj.txt 2>&1
-grep -c "mean/launch" gpurun_out/r02_sq_pitz.txt gpurun_out/r02_sq_3d.txt gpurun_out/r02_sq_tj.txt
+timeout -s KILL 400 python bench.py --no-cpu-baseline --force-dist --particles 2e5 --steps 6 --warmup 2 > /tmp/out.txt 2> /tmp/err.txt
+echo "--- stdout lines: $(wc -l < /tmp/out.txt)"; cut -c1-100 /tmp/out.txt
+timeout -s KILL 400 python bench.py --no-cpu-baseline --force-dist 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], c['ms_in_handoff'], c['handoff_fraction_per_step'], c['exchange_interval'], c['rebalance_interval'], c['overlap_steps'])"
