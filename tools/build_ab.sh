@@ -12,7 +12,8 @@ BASE=$(basename $SRC .hip)
 OTHERS=$(ls $CS/build/*.o | grep -v "/$BASE.o")
 while [ $# -gt 1 ]; do
   NAME=$1; FLAGS=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Iinclude -I$CS $FLAGS -c $CS/$SRC -o /tmp/ab_$NAME.o
+  SF=""; [ "$BASE" = "cpf_stream" ] && SF="-mllvm --amdgpu-sched-strategy=max-ilp"      # as in csrc/Makefile
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off $SF -Iinclude -I$CS $FLAGS -c $CS/$SRC -o /tmp/ab_$NAME.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS /tmp/ab_$NAME.o -o build_ab/lib_$NAME.so
   echo "built build_ab/lib_$NAME.so ($FLAGS)"
 done

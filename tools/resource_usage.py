@@ -13,8 +13,9 @@ CS = os.path.join(ROOT, "cudaparticlesfoam_amd", "csrc")
 def collect():
     rows = []
     for src in ("cpf_stream.hip", "cpf_kernels.hip"):
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off",
-                            "-I" + os.path.join(ROOT, "include"), "-I" + CS, "-c", os.path.join(CS, src), "-o", "/dev/null",
+        extra = ["-mllvm", "--amdgpu-sched-strategy=max-ilp"] if src == "cpf_stream.hip" else []      # as in csrc/Makefile
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off"] + extra +
+                           ["-I" + os.path.join(ROOT, "include"), "-I" + CS, "-c", os.path.join(CS, src), "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         txt = re.sub(r" \[-Rpass-analysis=kernel-resource-usage\]", "", r.stderr)
         for b in re.split(r"(?=remark: [^\n]*Function Name:)", txt):
