@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout -s KILL 400 python bench.py > gpurun_out/r02_bench_1gpu.json 2> gpurun_out/r02_bench_1gpu.err; cut -c1-200 gpurun_out/r02_bench_1gpu.json
-timeout -s KILL 700 bash tools/profile_run.sh r02 > gpurun_out/r02_profile_run.log 2>&1; tail -2 gpurun_out/r02_profile_run.log | cut -c1-100
-timeout -s KILL 600 bash tools/profile_3d.sh r02 2>&1 | grep kernel_ms | cut -c1-200
-CPF_TJUNCTION=1 timeout -s KILL 300 python tools/bench_3d.py 2>&1 | grep kernel_ms | cut -c1-200
-timeout -s KILL 300 python tools/bench_pimple.py 2>&1 | tail -1 | cut -c1-300
+CPF_FUZZ_VARIANT=5 timeout -s KILL 600 python tools/fuzz_parity.py 200000 4000 2>&1 | tail -1
+CPF_FUZZ_VARIANT=3 timeout -s KILL 600 python tools/fuzz_parity.py 300000 4000 2>&1 | tail -1
+CPF_FUZZ_VARIANT=0 timeout -s KILL 600 python tools/fuzz_parity.py 400000 2000 2>&1 | tail -1
+timeout -s KILL 900 python tools/fuzz_parity.py 500000 20000 2>&1 | tail -1

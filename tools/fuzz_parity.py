@@ -47,6 +47,8 @@ def main():
             for fused in (0, 1):
                 ctx = Context(0)
                 ctx.set_option("stats", stats)
+                if os.environ.get("CPF_FUZZ_VARIANT"):
+                    ctx.set_option("step_variant", int(os.environ["CPF_FUZZ_VARIANT"]))
                 ctx.set_option("stream_lookup", (seed // 2 + stats) % 2)      # both record-lookup methods of the streaming kernel
                 ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
                 ctx.locate_initial()
