@@ -127,7 +127,6 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
     // (on or outside the plane: the face it came in through, or an entry point rounded across a neighbouring face).
     // (den <= fd) | (fd >= 0) is therefore a superset of the candidates -- two compares per face instead of five, two
     // scalar operations instead of five -- and the exact predicate below decides inside the branch.
-#ifndef CPF_FACE_TEST_OLD
     if (((ballot64(den <= fd) | ballot64(fd >= 0.0)) & __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
         // c2 only prunes divisions (a face the lane moves away from): "den < 0 or fd >= 0" holds whenever the exact
         // condition "equal sign bits" can still lead to an accepted face, and whatever else slips through has a
@@ -139,27 +138,10 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
             if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
         }
     }
-#else
-    const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
-    const bool c3 = fd < kTol, c4 = bs != token;
-    if ((ballot64(c1) & (ballot64(den < 0.0) | ballot64(fd >= 0.0)) & ballot64(c3) &
-         __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
-        if (c1 && c2 && c3 && c4) {
-            const double dT = fd / den;
-            if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
-        }
-    }
-#endif
 }
 
-// (CPF_PIN_W: with -DCPF_PIN_PLANE_W the plane offsets are requested together with the normals; without it the
-// compiler sinks their LDS reads behind the first wave-uniform skip of each pair -- one more LDS round trip on the
-// wave's dependent chain per pair, 16 bytes per lane less LDS traffic for skipped faces)
-#ifdef CPF_PIN_PLANE_W
-#define CPF_PIN_W(a, b) asm volatile("" : "+v"(a.w), "+v"(b.w));
-#else
-#define CPF_PIN_W(a, b)
-#endif
+// (requesting the plane offsets together with the normals -- the compiler sinks their LDS reads behind the first
+// wave-uniform skip of each pair -- was measured: no difference)
 template <bool ZERO_SKIP = true>
 __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
     const D3 P0 = S;
@@ -170,21 +152,18 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     {
         double4 p0 = rec[0], p1 = rec[1];
         const int2 b = nb[0];
-        CPF_PIN_W(p0, p1)
         face_test<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
         face_test<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
     }
     {
         double4 p2 = rec[2], p3 = rec[3];
         const int2 b = nb[1];
-        CPF_PIN_W(p2, p3)
         face_test<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
         face_test<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
     {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
-        CPF_PIN_W(p4, p5)
         face_test<ZERO_SKIP>(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
         face_test<ZERO_SKIP>(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
     }
