@@ -39,6 +39,7 @@ namespace cpf {
 #define CPF_STREAM_WAVES 6
 #endif
 constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
+constexpr int kSlotStride = 8;                          // double4 per slot = one 256-byte record, see `slots`
 static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
 #ifndef CPF_STREAM_GATHER_LANES
 #define CPF_STREAM_GATHER_LANES 32
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
     constexpr int NS = kStreamSlots;
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
-    __shared__ double4 slots[NS][8];                 // the wave's record cache
+    // the wave's record cache.  (256 bytes per slot is one full turn of the 64 LDS banks, so lanes reading the same plane
+    // of different slots conflict: 50 conflict cycles per tile on pitzDaily, 351 on the 3-D bench mesh.  Padding the
+    // slots to 288 bytes removes the conflicts and was SLOWER on every mesh, 3-4 %: the 192 bytes cost the 24th wave per
+    // CU, and with 5 padded slots instead of 6 -- same LDS as now -- the extra misses cost more than the conflicts.)
+    __shared__ double4 slots[NS][kSlotStride];
     __shared__ unsigned sCnt[4];
     __shared__ double sLane[6][64];                  // per-lane end point E and last wall hit point (see step_kernel_coop)
     // landing zone of the next tile: x[64] | y[64] | z[64] | cell[64] (int32) | gid[64] (Brownian only)
@@ -85,6 +90,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     // written to the `vel` array of a launch that does not store velocities
     const uint64_t tl0 = __builtin_amdgcn_s_memrealtime();
     unsigned tlTiles = 0, tlRounds = 0;
+    // time (100 MHz ticks) spent in the wait for missing records / in the wait that ends a tile, and rounds with a miss
+    unsigned tlWaitRec = 0, tlWaitEnd = 0, tlMissRounds = 0;
 #endif
 
     for (unsigned k = blockIdx.x; k < (unsigned)kStreamGroups; k += gridDim.x)
@@ -230,6 +237,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                 // large meshes 4-7 %; both in ONE kernel behind a run-time flag: the worse of the two everywhere, hence
                 // the template parameter).  A round that finds every cell on chip (the common case) issues no memory request.
                 const unsigned long long busyMask = ballot64(busy);
+                // the lane's parked end point, requested before the lookup: its LDS round trip hides behind it (1 %)
+                const D3 Epre = {sE[0][lane], sE[1][lane], sE[2][lane]};
                 int myslot = -1;
                 unsigned used = 0;
                 unsigned long long missLanes = busyMask;
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                         missLanes &= ~ballot64(mine);                                                       \
                         if (ul < 16u)                                                                       \
                             glds16(reinterpret_cast<const char*>(m.cellRec) + (int64_t)ck * 256 + ul * 16u,  \
-                                   uniform32(slotBase + (unsigned)victim * 256u));                          \
+                                   uniform32(slotBase + (unsigned)victim * (32u * kSlotStride)));                          \
                         nJobs = J + 1;                                                                      \
                     }
                     CPF_JOB(0) CPF_JOB(1) CPF_JOB(2) CPF_JOB(3)
@@ -304,6 +313,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                 }
                 int younger = 0;
                 if (decltype(withHook)::value) younger = hook();
+#ifdef CPF_STREAM_TIMELINE
+                const uint64_t tlw0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 if (nJobs != 0) {
                     // the requested records are older than everything the hook issued: wait for exactly them
                     if (younger >= 7) wait_vmcnt<7>();
@@ -311,6 +323,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                     else if (younger >= 4) wait_vmcnt<4>();
                     else if (younger >= 2) wait_vmcnt<2>();
                     else wait_vmcnt<0>();
+#ifdef CPF_STREAM_TIMELINE
+                    tlWaitRec += (unsigned)(__builtin_amdgcn_s_memrealtime() - tlw0); ++tlMissRounds;
+#endif
                 }
                 // ---- every busy lane does one cell visit -- unless it was left without a record slot (more new cells
                 // than the round can place) in a round where few lanes were: the second and third round of a tile on a
@@ -323,9 +338,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                     int next, outSlot = 0;
                     double4 wallPlane = {0, 0, 0, 0};
                     D3 E = S_;
-                    if (!needAdvect) E = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                    if (!needAdvect) E = Epre;
                     if (myslot >= 0) {
-                        const double4* rec = &slots[0][0] + myslot * 8;
+                        const double4* rec = &slots[0][0] + myslot * kSlotStride;
                         if (needAdvect) {
                             const double4 u = rec[6];
                             v = {u.x, u.y, u.z};
@@ -425,8 +440,12 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
             }
 
             // everything this tile's hook issued has landed (the next tile in LDS) or been accepted (the stores)
+#ifdef CPF_STREAM_TIMELINE
+            const uint64_t tle0 = __builtin_amdgcn_s_memrealtime();
+#endif
             wait_vmcnt<0>();
 #ifdef CPF_STREAM_TIMELINE
+            tlWaitEnd += (unsigned)(__builtin_amdgcn_s_memrealtime() - tle0);
             ++tlTiles;
 #endif
             // ---- this tile's results wait in registers until the next tile's hook.  Every lane of the tile stores
@@ -453,8 +472,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     }
 #ifdef CPF_STREAM_TIMELINE
     if (!STORE_VEL && vel != nullptr && lane == 0) {
-        uint64_t* o = reinterpret_cast<uint64_t*>(vel) + 4 * (uint64_t)blockIdx.x;
+        uint64_t* o = reinterpret_cast<uint64_t*>(vel) + 8 * (uint64_t)blockIdx.x;
         o[0] = tl0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tlTiles; o[3] = tlRounds;
+        o[4] = tlWaitRec; o[5] = tlWaitEnd; o[6] = tlMissRounds; o[7] = 0;
     }
 #endif
     if (STATS) flush_stats(st, counters, sCnt);

@@ -140,8 +140,11 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
     }
 }
 
-// (requesting the plane offsets together with the normals -- the compiler sinks their LDS reads behind the first
-// wave-uniform skip of each pair -- was measured: no difference)
+// The plane offsets are requested together with the normals (the empty asm pins them): left alone, the compiler sinks
+// their LDS reads behind the first wave-uniform skip of each pair -- one more LDS round trip on the wave's dependent
+// chain per pair.  Measured at steady clocks: 1-2 % on the 3-D meshes (no face is skipped there before its offset is
+// needed), nothing either way on pitzDaily.
+#define CPF_PIN_W(a, b) asm volatile("" : "+v"(a.w), "+v"(b.w));
 template <bool ZERO_SKIP = true>
 __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
     const D3 P0 = S;
@@ -152,18 +155,21 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     {
         double4 p0 = rec[0], p1 = rec[1];
         const int2 b = nb[0];
+        CPF_PIN_W(p0, p1)
         face_test<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
         face_test<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
     }
     {
         double4 p2 = rec[2], p3 = rec[3];
         const int2 b = nb[1];
+        CPF_PIN_W(p2, p3)
         face_test<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
         face_test<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
     {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
+        CPF_PIN_W(p4, p5)
         face_test<ZERO_SKIP>(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
         face_test<ZERO_SKIP>(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
     }

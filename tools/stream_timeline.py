@@ -56,7 +56,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("="); ctx.set_option(k, float(v))
     ctx.sort_by_cell_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), g.data_ptr(), n)
-    tl = torch.zeros(4 * 16384, dtype=torch.int64, device=dev)
+    tl = torch.zeros(8 * 16384, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
     for _ in range(args.pre_steps):
         ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, 1e-4, args.D, 0, 1, 0)
@@ -65,9 +65,12 @@ def main():
     ctx.timing_enable(True)
     ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, 1e-4, args.D, 5, 1, 0)
     launches, ms = ctx.timing_read()
-    t = tl.cpu().numpy().reshape(-1, 4)
+    raw = tl.cpu().numpy()
+    stride = 8 if args.variant == 4 else 4          # variant 4 builds also report waits: see below
+    t = raw[: (raw.size // stride) * stride].reshape(-1, stride)
     idx = np.nonzero(t[:, 1] > 0)[0]
     t = t[idx]
+    waits = t[:, 4:7] if stride == 8 else None      # ticks waited for missing records | at tile ends | rounds with a miss
     t0, t1 = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
     base = t0.min()
     start = (t0 - base) * 10.0 / 1e3          # us (100 MHz ticks)
@@ -78,6 +81,16 @@ def main():
                tiles_pct=q(t[:, 2]), rounds_per_tile=round(float(t[:, 3].sum() / max(1, t[:, 2].sum())), 3),
                us_per_tile_pct=q((end - start) / np.maximum(t[:, 2], 1)),
                slot_busy_fraction=round(float((end - start).sum() / (t.shape[0] * end.max())), 3))
+    if waits is not None and waits.any():
+        life = float((end - start).sum())
+        wrec = float(waits[:, 0].sum()) * 10.0 / 1e3
+        wend = float(waits[:, 1].sum()) * 10.0 / 1e3
+        miss_rounds = waits[:, 2].astype(np.float64)
+        out["wait_for_records_fraction_of_wave_time"] = round(wrec / life, 3)
+        out["wait_at_tile_end_fraction_of_wave_time"] = round(wend / life, 3)
+        out["miss_rounds_per_tile"] = round(float(miss_rounds.sum() / max(1, t[:, 2].sum())), 3)
+        out["us_per_record_wait"] = round(wrec / max(1.0, float(miss_rounds.sum())), 3)
+        out["us_per_tile_end_wait"] = round(wend / max(1.0, float(t[:, 2].sum())), 3)
     if args.groups:
         # per chunk-counter group (block id mod 256 = one CU: blocks go round-robin over 8 XCDs x 32 CUs) and per XCD
         grp = idx % 256
