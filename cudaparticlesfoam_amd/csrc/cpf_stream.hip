@@ -354,7 +354,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                             sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                             needAdvect = false;
                         }
-                        next = trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
+                        // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h; measured
+                        // 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for zero denominators)
+                        next = (LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot)
+                                                            : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
                         // the wall's plane is read HERE, where the record's address space is known: one expression
                         // choosing between the LDS slot and the global record becomes a flat load (vmcnt + lgkmcnt 0)
                         if (REFLECT && next < 0) wallPlane = rec[outSlot];

@@ -180,6 +180,47 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     return next;
 }
 
+// The same six face tests, two faces per wave-uniform decision: both denominators and both plane distances are computed
+// up front (four independent FMA chains instead of two short ones between branches), then ONE test decides whether either
+// face has a candidate lane.  No zero-denominator skip: a lane with den == 0 is a candidate only with fd >= 0, and is then
+// rejected by the exact predicate (|fd| <= |den| leaves fd == 0, whose quotient is NaN) exactly as in face_test.  More
+// vector instructions where faces used to be skipped for zero denominators (2-D cases), fewer branches and shorter
+// dependent chains everywhere: used where every face is live anyway (3-D meshes, the Brownian kick).
+__device__ __forceinline__ void face_accept(double den, double fd, int bs, int token, int s, double& dTmin, int& next, int& best) {
+    const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
+    const bool c3 = fd < kTol, c4 = bs != token;
+    if (c1 && c2 && c3 && c4) {
+        const double dT = fd / den;
+        if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
+    }
+}
+__device__ __forceinline__ void face_pair_test(const double4& pa, const double4& pb, int2 b, const D3& P0, const D3& Pd, int token,
+                                               int s, double& dTmin, int& next, int& best) {
+    const double denA = dot3(pa, Pd), denB = dot3(pb, Pd);
+    const double fdA = plane_dist(pa, P0), fdB = plane_dist(pb, P0);
+    const unsigned long long mA = (ballot64(denA <= fdA) | ballot64(fdA >= 0.0)) & __builtin_amdgcn_uicmp((unsigned)b.x, (unsigned)token, 33 /* ne */);
+    const unsigned long long mB = (ballot64(denB <= fdB) | ballot64(fdB >= 0.0)) & __builtin_amdgcn_uicmp((unsigned)b.y, (unsigned)token, 33 /* ne */);
+    if ((mA | mB) != 0ull) {
+        if (mA != 0ull) face_accept(denA, fdA, b.x, token, s, dTmin, next, best);
+        if (mB != 0ull) face_accept(denB, fdB, b.y, token, s + 1, dTmin, next, best);
+    }
+}
+__device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 2.0;
+    const int2* nb = reinterpret_cast<const int2*>(rec + 7);
+    { const double4 p0 = rec[0], p1 = rec[1]; face_pair_test(p0, p1, nb[0], P0, Pd, token, 0, dTmin, next, best); }
+    { const double4 p2 = rec[2], p3 = rec[3]; face_pair_test(p2, p3, nb[1], P0, Pd, token, 2, dTmin, next, best); }
+    { const double4 p4 = rec[4], p5 = rec[5]; face_pair_test(p4, p5, nb[2], P0, Pd, token, 4, dTmin, next, best); }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        outSlot = best;
+    }
+    return next;
+}
+
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
 enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4, kVariantAhead = 5 };
 
