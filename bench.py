@@ -49,8 +49,10 @@ def parse():
                     help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
     ap.add_argument("--overlap-steps", type=int, default=4,
                     help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight")
-    ap.add_argument("--fused-extra", type=int, default=0,
-                    help="after the timed region, also time this many launches of 8 fused cycles (extra field; 0 = skip)")
+    ap.add_argument("--fused-extra", type=int, default=10,
+                    help="after the timed region, also time this many launches of 8 fused cycles -- what the replacement "
+                         "advect.H does between two output points (extra field config.extra_fused_cycles, never `value`; "
+                         "0 = skip)")
     ap.add_argument("--spinup-ms", type=float, default=100.0,
                     help="before the warm-up steps, keep the device busy this long with step launches on a SCRATCH copy "
                          "of the cloud (discarded): an MI355X needs ~30 ms of load after an idle phase to reach its "

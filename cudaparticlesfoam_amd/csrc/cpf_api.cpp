@@ -51,9 +51,10 @@ struct cpf_context {
     int sortInterval = 50;                      // "sort_interval": cpf_step re-sorts the owned cloud by cell every N cycles
     uint32_t lastSortStep = 0;
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
-    int stepVariant = 4;                        // cpf_set_option("step_variant"), see include/cpf.h
+    int stepVariant = -1;                       // cpf_set_option("step_variant"), see include/cpf.h: -1 = choose per launch
     cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
     int64_t lastStepN = -1;                     // particle count of the most recent step launch (cpf_step_kernel_name)
+    int lastStepCycles = 1;                     // ... and its cycles per launch
     // "VertexVelocity" advect only: the tet decomposition and one velocity per tet-mesh vertex
     double* d_tetPos = nullptr; int32_t* d_tets = nullptr; double* d_vertVel = nullptr;
     int64_t nTetVerts = 0, nTets = 0; int tetsPerCell = 0; bool haveVertVel = false;
@@ -438,7 +439,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
-        ctx->lastStepN = n;
+        ctx->lastStepN = n; ctx->lastStepCycles = cycPerLaunch;
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                       reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
                                       &ctx->streamState));
@@ -546,7 +547,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     CPF_REQUIRE(ctx, ctx && key, CPF_ERR_ARG, "null argument");
     const std::string k(key);
     if (k == "step_variant") {
-        CPF_REQUIRE(ctx, value >= 0 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be 0..5");
+        CPF_REQUIRE(ctx, value >= -1 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be -1..5");
         ctx->stepVariant = (int)value;
         return CPF_OK;
     }
@@ -619,7 +620,8 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     CPF_REQUIRE(ctx, ctx && buf && bufBytes > 0, CPF_ERR_ARG, "null argument");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_step_kernel_name: call cpf_set_mesh first");
     const cpf::MeshView m = meshView(ctx);
-    const int v = cpf::effective_step_variant(ctx->stepVariant, m, true);
+    // (a fused launch's kernel depends on how many cycles it fuses: the most recent launch's count stands in)
+    const int v = cpf::effective_step_variant(ctx->stepVariant, m, true, (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1);
     const char* b[2] = {"false", "true"};
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
     char tmp[160];

@@ -47,7 +47,8 @@ hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, in
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
 bool stream_lookup_fixed(int64_t n, const MeshView& m, const StreamState& ss);
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
-int effective_step_variant(int variant, const MeshView& m, bool haveStream);
+int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch);
+constexpr int kFusedCoopCycles = 3;       // fused launches of this many cycles or more run the wave-cooperative kernel
 // ss == nullptr: the streaming variant is not available (falls back to the wave-cooperative kernel)
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,

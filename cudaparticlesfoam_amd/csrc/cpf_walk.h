@@ -222,7 +222,7 @@ __device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, co
 }
 
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
-enum { kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4, kVariantAhead = 5 };
+enum { kVariantAuto = -1, kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4, kVariantAhead = 5 };
 
 // Where a walk gets its mesh data from.  Every tracer runs the same arithmetic in the same order.
 template <int VARIANT>

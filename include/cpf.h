@@ -171,11 +171,14 @@ int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel
 int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
 int cpf_set_seed(cpf_context* ctx, uint32_t seed);
 /* tuning knobs, never semantics (every step variant is bit-identical):
- *   "step_variant"  0 generic CSR walk (any polyhedral mesh; forced when a cell is not a hex)
+ *   "step_variant"  -1 (default) chosen per launch: 4, but 3 for launches that fuse 3 or more cycles
+ *                     (CPF_STEP_FUSE_CYCLES: the particle stream is loaded and stored once per launch there, and kernel
+ *                     3's higher occupancy wins: 5-15 % per cycle)
+ *                   0 generic CSR walk (any polyhedral mesh; forced when a cell is not a hex)
  *                   1 all-hex fixed-slot walk, per-lane gathers
  *                   2 + wave-uniform plane fetches through the scalar cache
  *                   3 wave-cooperative LDS cell cache on packed 256-byte cell records, one block per 128 particles
- *                   4 (default) streaming kernel: persistent waves, next tile prefetched into LDS while the current
+ *                   4 streaming kernel: persistent waves, next tile prefetched into LDS while the current
  *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip)
  *                   5 experimental: variant 4 whose finished lanes start on the next tile at once (cpf_ahead.hip).
  *                     Fewer rounds per tile but dearer rounds: measured SLOWER than 4 on every mesh;

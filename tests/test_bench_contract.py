@@ -78,3 +78,5 @@ def test_bench_runs_and_prints_one_json_line(extra):
         b, st = d["config"]["brownian"], d["config"]["ms_per_step_steady"]
         assert b["D"] == 1.5e-5 and b["kernel"] == "cpf::step_kernel_stream<true, true, false, false, true>" and 0 < b["frac"] < 1
         assert st["steps"] == 100 and st["sorts_inside"] == 1 and st["ms_per_step"] > 0
+        f = d["config"]["extra_fused_cycles"]
+        assert f["cycles_per_launch"] == 8 and f["launches"] == 10 and f["Mparticle_steps_per_s"] > 0

@@ -86,7 +86,7 @@ def test_step_bit_exact_vs_cellwalk(setup, field, variant):
     assert c1["cells_visited"] - c0["cells_visited"] == hops
     assert c1["reflections"] - c0["reflections"] == refl
     assert refl > 0   # the case does exercise wall reflection
-    ctx.set_option("step_variant", 4)
+    ctx.set_option("step_variant", -1)
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -172,6 +172,32 @@ def test_fused_cycles_and_sort_do_not_change_results(setup, gpu_ctx_factory):
         ctx.close()
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+def test_kernel_choice_per_launch(setup):
+    """Default step_variant -1: single-cycle launches run the streaming kernel, launches that fuse three or more cycles
+    the wave-cooperative one (faster there); an explicit variant is obeyed.  Results are the same either way."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, ctx = setup["pz"], setup["ctx"]
+    ctx.set_velocity(setup["pitz"]["U_analytic"])
+    xyz = _seed_points(pz, 30000, pz.DOMAIN_BOX, seed=12)
+    got = []
+    for variant in (-1, 4, 3):
+        ctx.set_option("step_variant", variant)
+        ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
+        ctx.step(1e-4, 0.0, 2)
+        name1 = ctx.step_kernel_name(0.0, 0)
+        ctx.step(1e-4, 0.0, 2, L.STEP_FUSE_CYCLES)
+        name2 = ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES)
+        ctx.step(1e-4, 0.0, 9, L.STEP_FUSE_CYCLES)
+        name9 = ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES)
+        want = {-1: ("stream", "stream", "coop"), 4: ("stream", "stream", "stream"), 3: ("coop", "coop", "coop")}[variant]
+        assert tuple("coop" if "step_kernel_coop" in nm else "stream" if "step_kernel_stream" in nm else nm
+                     for nm in (name1, name2, name9)) == want
+        got.append(ctx.get_particles())
+    for g in got[1:]:
+        assert np.array_equal(g[0], got[0][0]) and np.array_equal(g[1], got[0][1])
+    ctx.set_option("step_variant", -1)
 
 
 def test_box_uniform_flow_known_answers(oracle_libs, gpu_ctx_factory):
@@ -735,6 +761,7 @@ def test_stream_record_lookup_methods(setup, lookup, sort):
                 ref[sort] = got
     ctx.set_option("stream_lookup", -1)
     ctx.set_option("sort_interval", 50)
+    ctx.set_option("step_variant", -1)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000])
@@ -756,7 +783,7 @@ def test_ragged_sizes(setup, n):
         ctx.step(1e-4, 0.0, 25)
         xyzw, cell = ctx.get_particles()
         assert np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y)
-    ctx.set_option("step_variant", 4)
+    ctx.set_option("step_variant", -1)
 
 
 def test_all_particles_outside_the_mesh(setup):

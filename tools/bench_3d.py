@@ -67,9 +67,10 @@ def main():
         from _spinup import device_spinup
         device_spinup(ctx, torch, x, y, z, cell, n, 1e-4)
         ctx.timing_enable(True); ctx.timing_read()
-        ctx.step_dev(p(x), p(y), p(z), p(cell), None, None, n, 1e-4, 0.0, 5, 20, 0)
+        fused = int(os.environ.get("CPF_FUSED", "0"))       # 20 cycles in ONE launch (CPF_STEP_FUSE_CYCLES) instead of 20 launches
+        ctx.step_dev(p(x), p(y), p(z), p(cell), None, None, n, 1e-4, 0.0, 5, 20, 4 if fused else 0)
         launches, ms = ctx.timing_read(); ctx.timing_enable(False)
-        k = ms / launches
+        k = ms / launches / (20 if fused else 1)
         print(json.dumps(dict(field=name, cells=mesh.n_cells, particles=n, kernel_ms=round(k, 4),
                               Gparticle_steps_per_s=round(n / k / 1e6, 2), roofline_GBs=round(56 * n / k / 1e6, 1),
                               visits_per_particle_step=round((c1["cells_visited"] - c0["cells_visited"]) /
