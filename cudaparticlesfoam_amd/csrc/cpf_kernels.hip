@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
         while (ballot64(busy) != 0ull) {
             // ---- distinct cells of the busy lanes -> slots (wave-uniform scalars)
             const unsigned long long busyMask = ballot64(busy);
+            const D3 Epre = {sE[0][tid], sE[1][tid], sE[2][tid]};                  // requested before the cell discovery: its LDS round trip hides behind it (2 %)
             unsigned long long todo = busyMask;
             int myslot = -1, c0 = -1, c1 = -1, c2 = -1, c3 = -1;
 #pragma unroll
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
             if (busy) {
                 int next, outSlot = 0;
                 D3 E = S;
-                if (!needAdvect) E = {sE[0][tid], sE[1][tid], sE[2][tid]};
+                if (!needAdvect) E = Epre;
                 if (myslot >= 0) {
                     const double4* rec = slots[myslot];
                     if (needAdvect) {
