@@ -292,6 +292,30 @@ def main():
     el = float(t.item())
     n_after = cloud.global_count()
 
+    # Outside the timed region, single GPU only, right after it (the cloud is still where the timed steps left it): the
+    # tutorial's diffusion coefficient (pitzDaily/system/cudaParticlesDict: diffusionCoeff 1.5e-5) -- another
+    # instantiation of the same kernel, never `value`.
+    brown = None
+    if world == 1 and not args.force_dist and args.brownian_extra > 0:
+        Db = 1.5e-5
+        cloud.step(dt, 3, D=Db)
+        torch.cuda.synchronize()
+        ctx.timing_enable(True); ctx.timing_read()
+        tb = time.perf_counter()
+        cloud.step(dt, args.brownian_extra, D=Db)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        lb, msb = ctx.timing_read()
+        ctx.timing_enable(False)
+        kb = msb / max(lb, 1)
+        bytes_b = ALGO_BYTES_PER_PARTICLE_STEP + 8          # + the 8-byte particle id the Philox counter needs
+        brown = {"D": Db, "ms_per_step": round(tb / args.brownian_extra * 1e3, 4), "kernel_avg_ms": round(kb, 4),
+                 "kernel": ctx.step_kernel_name(Db, 0), "algorithmic_bytes_per_particle_step": bytes_b,
+                 "achieved_GBs": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
+                 "frac": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kb > 0 else None}
+        if not args.no_sort:
+            cloud.sort()        # diffusion scrambles the order within a few dozen steps: the extras below start sorted again
+
     # Outside the timed region, single GPU only: the same cloud stepped with 8 cycles fused into one launch
     # (CPF_STEP_FUSE_CYCLES: what the replacement advect.H does between two output points; results identical,
     # tests/test_gpu_parity.py).  Reported as an extra, never as `value`.
@@ -312,11 +336,9 @@ def main():
                  "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
                  "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
 
-    # Outside the timed region, single GPU: (1) steady state -- one full sort interval, so the periodic re-sort the
-    # short window may miss is in; (2) the tutorial's diffusion coefficient (pitzDaily/system/cudaParticlesDict:
-    # diffusionCoeff 1.5e-5): another instantiation of the same kernel, never `value`.
+    # Outside the timed region, single GPU: steady state -- one full sort interval, so the periodic re-sort the short
+    # window may miss is in.
     steady = None
-    brown = None
     if world == 1 and not args.force_dist:
         k = args.steady_steps if args.steady_steps >= 0 else (0 if args.no_sort else args.sort_interval)
         if k > 0:
@@ -330,24 +352,6 @@ def main():
                       "first_step": cloud.step_index - k,
                       "sorts_inside": (cloud.step_index // max(1, cloud.sort_interval)) -
                                       ((cloud.step_index - k) // max(1, cloud.sort_interval)) if cloud.sort_interval else 0}
-        if args.brownian_extra > 0:
-            Db = 1.5e-5
-            cloud.step(dt, 3, D=Db)
-            torch.cuda.synchronize()
-            ctx.timing_enable(True); ctx.timing_read()
-            tb = time.perf_counter()
-            cloud.step(dt, args.brownian_extra, D=Db)
-            torch.cuda.synchronize()
-            tb = time.perf_counter() - tb
-            lb, msb = ctx.timing_read()
-            ctx.timing_enable(False)
-            kb = msb / max(lb, 1)
-            bytes_b = ALGO_BYTES_PER_PARTICLE_STEP + 8          # + the 8-byte particle id the Philox counter needs
-            brown = {"D": Db, "ms_per_step": round(tb / args.brownian_extra * 1e3, 4), "kernel_avg_ms": round(kb, 4),
-                     "kernel": ctx.step_kernel_name(Db, 0), "algorithmic_bytes_per_particle_step": bytes_b,
-                     "achieved_GBs": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
-                     "frac": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kb > 0 else None}
-
     if rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3

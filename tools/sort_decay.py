@@ -19,6 +19,8 @@ def main():
     from cudaparticlesfoam_amd.cases import pitzdaily as pz
     from cudaparticlesfoam_amd.parallel import x_slab_renumbering
     windows = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    D = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0          # diffusion coefficient of the measured steps
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 50             # steps per window
     dev = torch.device("cuda", 0)
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -37,8 +39,8 @@ def main():
         step, rows = 0, []
         for w in range(windows):
             ctx.timing_enable(True); ctx.timing_read()
-            for _ in range(50):
-                ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, step, 1, 0); step += 1
+            for _ in range(W):
+                ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if D > 0 else None, None, n, 1e-4, D, step, 1, 0); step += 1
             launches, ms = ctx.timing_read(); ctx.timing_enable(False)
             rows.append(round(ms / max(1, launches), 4))
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -46,10 +48,10 @@ def main():
             ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
         torch.cuda.synchronize(); sort_ms = (time.perf_counter() - t0) / 5 * 1e3
         ctx.timing_enable(True); ctx.timing_read()
-        for _ in range(50):
-            ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, step, 1, 0); step += 1
+        for _ in range(W):
+            ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if D > 0 else None, None, n, 1e-4, D, step, 1, 0); step += 1
         launches, ms = ctx.timing_read(); ctx.timing_enable(False)
-        print(json.dumps(dict(field=name, kernel_ms_per_50_step_window_since_the_sort=rows, sort_ms=round(sort_ms, 3),
+        print(json.dumps(dict(field=name, D=D, steps_per_window=W, kernel_ms_per_window_since_the_sort=rows, sort_ms=round(sort_ms, 3),
                               kernel_ms_right_after_a_new_sort=round(ms / max(1, launches), 4))), flush=True)
     ctx.close()
 
