@@ -21,6 +21,7 @@ def main():
     windows = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     D = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0          # diffusion coefficient of the measured steps
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 50             # steps per window
+    opts = [kv.split("=") for kv in sys.argv[4:]]                 # context options, e.g. sort_key_bits=110
     dev = torch.device("cuda", 0)
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -30,6 +31,8 @@ def main():
     ctx.set_mesh(mesh)
     p = lambda t: t.data_ptr()   # noqa: E731
     ctx.set_option("timing_stride", 4)
+    for k_, v_ in opts:
+        ctx.set_option(k_, float(v_))
     for name, U in (("uniform", pz.uniform_u(mesh)), ("analytic", pz.analytic_step_u(mesh, centres))):
         ctx.set_velocity(U)
         x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
@@ -51,7 +54,7 @@ def main():
         for _ in range(W):
             ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if D > 0 else None, None, n, 1e-4, D, step, 1, 0); step += 1
         launches, ms = ctx.timing_read(); ctx.timing_enable(False)
-        print(json.dumps(dict(field=name, D=D, steps_per_window=W, kernel_ms_per_window_since_the_sort=rows, sort_ms=round(sort_ms, 3),
+        print(json.dumps(dict(field=name, opts=sys.argv[4:], D=D, steps_per_window=W, kernel_ms_per_window_since_the_sort=rows, sort_ms=round(sort_ms, 3),
                               kernel_ms_right_after_a_new_sort=round(ms / max(1, launches), 4))), flush=True)
     ctx.close()
 
