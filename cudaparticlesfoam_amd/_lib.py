@@ -77,6 +77,7 @@ SIGNATURES = {
     "cpf_locate_initial_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),
     "cpf_seed_box_dev": (_int, [_ctx, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "cpf_sort_by_cell_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "cpf_sort_by_cell_dev_to": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "cpf_pack_leavers_dev": (_int, [_ctx, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int, _int, _vp, _i64, _vp, _vp]),
     "cpf_cell_histogram_dev": (_int, [_ctx, _vp, _i64, _dbl, _vp]),
     "cpf_cell_ranges_dev": (_int, [_ctx, _vp, _int, _vp]),

@@ -189,6 +189,9 @@ class Context:
     def sort_by_cell_dev(self, x, y, z, cell, gid, n):
         self._ck(self.lib.cpf_sort_by_cell_dev(self.h, x, y, z, cell, gid, n))
 
+    def sort_by_cell_dev_to(self, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, n):
+        self._ck(self.lib.cpf_sort_by_cell_dev_to(self.h, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, n))
+
     def pack_leavers_dev(self, x, y, z, cell, gid, n, cell_lo, n_ranks, my_rank, sendbuf, send_cap, counts, n_stay):
         self._ck(self.lib.cpf_pack_leavers_dev(self.h, x, y, z, cell, gid, n, cell_lo, n_ranks, my_rank, sendbuf,
                                                send_cap, counts, n_stay))

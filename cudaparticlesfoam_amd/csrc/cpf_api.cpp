@@ -38,6 +38,11 @@ struct cpf_context {
     double *x = nullptr, *y = nullptr, *z = nullptr, *vel = nullptr;
     int32_t* cell = nullptr;
     int64_t* gid = nullptr;
+    // second set of x, y, z, cell, gid: the sort writes the reordered cloud there and the sets swap roles (no copy back);
+    // allocated by the first sort
+    double *x2 = nullptr, *y2 = nullptr, *z2 = nullptr;
+    int32_t* cell2 = nullptr;
+    int64_t* gid2 = nullptr;
     bool located = false;
     // scratch
     void* scratch = nullptr;
@@ -145,6 +150,7 @@ void freeMesh(cpf_context* c) {
 }
 void freeCloud(cpf_context* c) {
     freeDev(c->x); freeDev(c->y); freeDev(c->z); freeDev(c->vel); freeDev(c->cell); freeDev(c->gid);
+    freeDev(c->x2); freeDev(c->y2); freeDev(c->z2); freeDev(c->cell2); freeDev(c->gid2);
     c->cap = c->n = 0; c->located = false;
 }
 
@@ -465,7 +471,7 @@ int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags)
     // keep waves cell-coherent: particle ids (and stored velocities) travel with the particles, so callers
     // never see the reordering
     if (ctx->sortInterval > 0 && ctx->stepCounter - ctx->lastSortStep >= (uint32_t)ctx->sortInterval) {
-        r = cpf_sort_by_cell_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n);
+        r = cpf_sort_by_cell(ctx);
         ctx->lastSortStep = ctx->stepCounter;
     }
     return r;
@@ -480,26 +486,69 @@ int cpf_seed_box_dev(cpf_context* ctx, double* x, double* y, double* z, int64_t 
     return CPF_OK;
 }
 
-int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n) {
-    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+namespace {
+// in place (ox == nullptr) or into the out arrays
+int sortImpl(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n, double* ox, double* oy,
+             double* oz, int32_t* ocell, int64_t* ogid, double* vel3) {
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_sort_by_cell: call cpf_set_mesh first");
     CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (x && y && z && cell)), CPF_ERR_ARG, "cpf_sort_by_cell: bad arguments");
     CPF_REQUIRE(ctx, ctx->host.nCells < ((int64_t)1 << 26) - 2, CPF_ERR_STATE, "cpf_sort_by_cell: more than 2^26 cells");
-    if (n <= 1) return CPF_OK;
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     const int endBit = sortEndBit(ctx);
     int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
     if (r) return r;
-    CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, x == ctx->x ? ctx->vel : nullptr, n, endBit,
-                                   ctx->d_cellBox, ctx->host.subBits, ctx->host.subOrder, ctx->scratch,
-                                   ctx->scratchBytes));
+    CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, vel3, n, endBit, ctx->d_cellBox, ctx->host.subBits,
+                                   ctx->host.subOrder, ctx->scratch, ctx->scratchBytes, ox, oy, oz, ocell, ogid));
     return CPF_OK;
+}
+}  // namespace
+
+int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    if (n <= 1) return CPF_OK;
+    return sortImpl(ctx, x, y, z, cell, gid, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int cpf_sort_by_cell_dev_to(cpf_context* ctx, const double* x, const double* y, const double* z, const int32_t* cell,
+                            const int64_t* gid, double* ox, double* oy, double* oz, int32_t* ocell, int64_t* ogid, int64_t n) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, n == 0 || (ox && oy && oz && ocell && (ogid || !gid)), CPF_ERR_ARG, "cpf_sort_by_cell_dev_to: null output array");
+    CPF_REQUIRE(ctx, n == 0 || (ox != x && oy != y && oz != z && ocell != cell), CPF_ERR_ARG, "cpf_sort_by_cell_dev_to: outputs alias inputs");
+    if (n <= 0) return CPF_OK;
+    if (n == 1) {           // nothing to sort, but the contract is "the cloud is in the out arrays"
+        CPF_HIP(ctx, hipSetDevice(ctx->device));
+        CPF_HIP(ctx, hipMemcpyAsync(ox, x, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CPF_HIP(ctx, hipMemcpyAsync(oy, y, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CPF_HIP(ctx, hipMemcpyAsync(oz, z, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CPF_HIP(ctx, hipMemcpyAsync(ocell, cell, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (gid) CPF_HIP(ctx, hipMemcpyAsync(ogid, gid, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return CPF_OK;
+    }
+    return sortImpl(ctx, const_cast<double*>(x), const_cast<double*>(y), const_cast<double*>(z), const_cast<int32_t*>(cell),
+                    const_cast<int64_t*>(gid), n, ox, oy, oz, ocell, ogid, nullptr);
 }
 
 int cpf_sort_by_cell(cpf_context* ctx) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->n > 0 && ctx->located, CPF_ERR_STATE, "cpf_sort_by_cell: no located particles");
-    return cpf_sort_by_cell_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n);
+    if (ctx->n <= 1) return CPF_OK;
+    // the context's own cloud: sorted into its second set of arrays, then the sets swap roles
+    if (ctx->x2 == nullptr) {
+        CPF_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t c = (size_t)ctx->cap;
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->x2, c * 8));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->y2, c * 8));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->z2, c * 8));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->cell2, c * 4));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->gid2, c * 8));
+        CPF_HIP(ctx, hipMemsetAsync(ctx->cell2, 0xFF, c * 4, ctx->stream));
+    }
+    int r = sortImpl(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n, ctx->x2, ctx->y2, ctx->z2, ctx->cell2, ctx->gid2,
+                     ctx->vel);
+    if (r) return r;
+    std::swap(ctx->x, ctx->x2); std::swap(ctx->y, ctx->y2); std::swap(ctx->z, ctx->z2);
+    std::swap(ctx->cell, ctx->cell2); std::swap(ctx->gid, ctx->gid2);
+    return CPF_OK;
 }
 
 int cpf_num_particles(const cpf_context* ctx, int64_t* n) {

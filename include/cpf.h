@@ -216,6 +216,12 @@ int cpf_seed_box_dev(cpf_context* ctx, double* x, double* y, double* z, int64_t 
  * buffers owned by the context. */
 int cpf_sort_by_cell_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                          int64_t n);
+/* The same order written into a second set of arrays (none may alias its input; gid / ogid nullable together); the
+ * inputs are left as they are.  No staging and no copy back: a fifth less time than the in-place form -- for hosts
+ * that keep two sets of arrays and swap them (cpf_sort_by_cell does so for the context's own cloud). */
+int cpf_sort_by_cell_dev_to(cpf_context* ctx, const double* x, const double* y, const double* z, const int32_t* cell,
+                            const int64_t* gid, double* ox, double* oy, double* oz, int32_t* ocell, int64_t* ogid,
+                            int64_t n);
 /* Multi-GPU hand-off (no reference counterpart: SURVEY.md 8e).  Rank r owns cells
  * [cellLo[r], cellLo[r+1]).  Partitions the n particles into stay / leave: stayers are
  * left in / moved into [0, nStay) (holes left by leavers are filled from the tail, so only

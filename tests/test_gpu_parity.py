@@ -886,6 +886,35 @@ def test_sort_orders_by_cell_then_position(setup):
     ctx.use_own_stream()
 
 
+def test_out_of_place_sort_equals_in_place(setup):
+    """cpf_sort_by_cell_dev_to writes the order cpf_sort_by_cell_dev produces into a second set of arrays and leaves its
+    inputs alone; n = 0 and n = 1 included; aliasing is refused."""
+    import torch
+    from cudaparticlesfoam_amd._lib import CpfError
+    pz, ctx = setup["pz"], setup["ctx"]
+    dev = torch.device("cuda", 0)
+    for n in (0, 1, 70001):
+        xyz = _seed_points(pz, max(n, 1), pz.DOMAIN_BOX, seed=31 + n)[:n]
+        x, y, z = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+        c = torch.empty(n, dtype=torch.int32, device=dev)
+        g = torch.arange(n, dtype=torch.int64, device=dev)
+        p = lambda t: t.data_ptr() if t.numel() else 0   # noqa: E731
+        if n:
+            ctx.locate_initial_dev(p(x), p(y), p(z), p(c), n)
+        torch.cuda.synchronize()
+        keep = [t.clone() for t in (x, y, z, c, g)]
+        out = [torch.zeros_like(t) for t in (x, y, z, c, g)]
+        ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), *(p(t) for t in out), n)
+        ctx.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(keep, (x, y, z, c, g)))          # inputs untouched
+        ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
+        ctx.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, (x, y, z, c, g)))
+        if n > 1:
+            with pytest.raises(CpfError):
+                ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), p(x), p(out[1]), p(out[2]), p(out[3]), p(out[4]), n)
+
+
 def test_64bit_labels_give_the_same_tables(setup, gpu_ctx_factory):
     """cpf_set_mesh_l64 (OpenFOAM built with WM_LABEL_SIZE=64) == cpf_set_mesh."""
     import copy

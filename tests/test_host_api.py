@@ -10,6 +10,7 @@ class RecorderContext:
     def __init__(self, device=0):
         self.calls = []
 
+    def set_option(self, key, value): self.calls.append(("set_option", key, value))
     def set_mesh(self, mesh): self.calls.append(("set_mesh",))
     def set_velocity(self, U): self.calls.append(("set_velocity", np.asarray(U).shape))
     def seed_box(self, n, lo, hi, order=1): self.calls.append(("seed_box", n, tuple(lo), tuple(hi), order))
@@ -37,7 +38,9 @@ def test_dictionary_defaults_match_the_fragment(api):
         (1000, 0.0, 1e05, 1e-4, 5.7e-6, 10)
     assert p.seedingBox == ((0.0, 0.0, 0.0), (30.0, 30.0, 30.0))
     kinds = [c[0] for c in p.ctx.calls]
-    assert kinds == ["set_mesh", "set_velocity", "seed_box", "locate_initial", "sort"]
+    # (default diffusionCoeff 5.7e-6 > 0: the run asks for the shorter sort cadence first)
+    assert kinds == ["set_option", "set_mesh", "set_velocity", "seed_box", "locate_initial", "sort"]
+    assert p.ctx.calls[0] == ("set_option", "sort_interval", 25)
     assert p.outOfDomain == 3
 
 
