@@ -626,6 +626,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->streamState.tailFraction = value;
         return CPF_OK;
     }
+    if (k == "coop_max_cells") {
+        CPF_REQUIRE(ctx, value >= 0 && value <= (1 << 24), CPF_ERR_ARG, "coop_max_cells must be in [0, 2^24]");
+        ctx->streamState.coopMaxCells = (int)value;
+        return CPF_OK;
+    }
     if (k == "stream_lookup") {
         CPF_REQUIRE(ctx, value >= -1 && value <= 1, CPF_ERR_ARG, "stream_lookup must be -1 (auto), 0 or 1");
         ctx->streamState.lookup = (int)value;
@@ -670,7 +675,8 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_step_kernel_name: call cpf_set_mesh first");
     const cpf::MeshView m = meshView(ctx);
     // (a fused launch's kernel depends on how many cycles it fuses: the most recent launch's count stands in)
-    const int v = cpf::effective_step_variant(ctx->stepVariant, m, true, (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1);
+    const int v = cpf::effective_step_variant(ctx->stepVariant, m, true, (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1,
+                                              ctx->streamState.coopMaxCells);
     const char* b[2] = {"false", "true"};
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
     char tmp[160];

@@ -38,6 +38,7 @@ struct StreamState {
     int numCU = 256;
     int tilesPerChunk = 4;    // "stream_tiles_per_chunk"
     int wavesPerCU = 0;       // "stream_waves_per_cu": 0 = what the occupancy query says
+    int coopMaxCells = 0;     // "coop_max_cells": test hook, lowers the wave-cooperative kernel's 2^24-cell limit (0 = the limit)
     int lookup = -1;          // "stream_lookup": 0 loop over distinct cells, 1 fixed tag compare, -1 = by particles per cell
     double tailFraction = 0.1;  // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch
     int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
@@ -47,7 +48,7 @@ hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, in
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
 bool stream_lookup_fixed(int64_t n, const MeshView& m, const StreamState& ss);
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
-int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch);
+int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 3;       // fused launches of this many cycles or more run the wave-cooperative kernel
 // ss == nullptr: the streaming variant is not available (falls back to the wave-cooperative kernel)
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,

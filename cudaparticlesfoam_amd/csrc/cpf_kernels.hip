@@ -335,17 +335,18 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
     }
 }
 
-int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch) {
+int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells) {
+    if (coopMaxCells <= 0 || coopMaxCells > kCoopMaxCells) coopMaxCells = kCoopMaxCells;
     if (!m.allHex) return kVariantGeneric;                    // fixed-slot variants need 6 faces per cell
     // Several cycles fused into one launch (CPF_STEP_FUSE_CYCLES: what advect.H does between two output points): the
     // particle stream is loaded and stored once per launch, so hiding it behind the walk buys nothing, and the
     // wave-cooperative kernel's 8 waves per SIMD (the streaming kernel: 6) win -- measured per cycle, pitzDaily:
     // 2 cycles per launch equal, 3: 5 %, 8: 10 %, 32: 13 %; 3-D bench mesh, 20 cycles: 15 %; TJunction: 1-5 %
     if (variant == kVariantAuto)
-        variant = (haveStream && !(cyclesPerLaunch >= kFusedCoopCycles && m.nCells <= kCoopMaxCells)) ? kVariantStream : kVariantCoop;
+        variant = (haveStream && !(cyclesPerLaunch >= kFusedCoopCycles && m.nCells <= coopMaxCells)) ? kVariantStream : kVariantCoop;
     if ((variant == kVariantStream || variant == kVariantAhead) && !haveStream) variant = kVariantCoop;
     // the wave-cooperative kernel addresses records with a 32-bit byte offset (256 B x 2^24 cells)
-    if (variant == kVariantCoop && m.nCells > kCoopMaxCells) variant = haveStream ? kVariantStream : kVariantFixedScalar;
+    if (variant == kVariantCoop && m.nCells > coopMaxCells) variant = haveStream ? kVariantStream : kVariantFixedScalar;
     return variant;
 }
 
@@ -357,7 +358,7 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
-    variant = effective_step_variant(variant, m, ss != nullptr, nCyc);
+    variant = effective_step_variant(variant, m, ss != nullptr, nCyc, ss ? ss->coopMaxCells : 0);
     switch (variant) {
         case kVariantAhead:
             // lanes that run ahead into the next tile: one plain cycle per launch only; everything else streams

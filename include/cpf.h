@@ -187,6 +187,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare): how a wave finds its cells in its record cache;
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
+ *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
+ *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference
  *                   has no such diagnostics, and they cost the step kernel a resident wave (0.16 -> 0.22 ms
  *                   per 1e7-particle launch)

@@ -200,6 +200,31 @@ def test_kernel_choice_per_launch(setup):
     ctx.set_option("step_variant", -1)
 
 
+def test_coop_kernel_cell_limit_guard(setup):
+    """The wave-cooperative kernel addresses cell records with 32-bit byte offsets (256 B x 2^24 cells).  Above that limit
+    the streaming kernel runs instead, for an explicit step_variant 3 and for fused launches alike; the test hook
+    coop_max_cells moves the limit below pitzDaily's 12 225 cells so that the switch can be seen, results unchanged."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, ctx = setup["pz"], setup["ctx"]
+    ctx.set_velocity(setup["pitz"]["U_analytic"])
+    xyz = _seed_points(pz, 20000, pz.DOMAIN_BOX, seed=77)
+    got = []
+    for limit in (0, 5000):
+        ctx.set_option("coop_max_cells", limit)
+        names = []
+        for variant in (3, -1):
+            ctx.set_option("step_variant", variant)
+            ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
+            ctx.step(1e-4, 0.0, 6, L.STEP_FUSE_CYCLES)
+            names.append(ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES))
+            got.append(ctx.get_particles())
+        assert all(("step_kernel_coop" in nm) == (limit == 0) for nm in names), names
+        assert all(("step_kernel_stream" in nm) == (limit != 0) for nm in names), names
+    for g in got[1:]:
+        assert np.array_equal(g[0], got[0][0]) and np.array_equal(g[1], got[0][1])
+    ctx.set_option("coop_max_cells", 0); ctx.set_option("step_variant", -1)
+
+
 def test_box_uniform_flow_known_answers(oracle_libs, gpu_ctx_factory):
     """Uniform U in a box: P_k = P_0 + k*dt*U until the first wall; specular reflection at x = L."""
     from cudaparticlesfoam_amd.cases import box_mesh
