@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (and 3), gloo: the sharded cloud's host logic -- ownership, counts exchange,
+"""CPU, world_size 2, 3 and 8, gloo: the sharded cloud's host logic -- ownership, counts exchange,
 variable-size all-to-all, append -- gives the same per-particle results as one process."""
 import os
 import socket
@@ -93,7 +93,8 @@ def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_lib
 
 
 @pytest.mark.parametrize("world,interval,rebalance,overlap", [(2, 1, 0, 0), (2, 4, 0, 0), (3, 1, 0, 0), (2, 4, 10, 0),
-                                                             (3, 0, 5, 0), (2, 0, 5, 3), (3, 4, 0, 4), (2, 0, 6, 10)])
+                                                             (3, 0, 5, 0), (2, 0, 5, 3), (3, 4, 0, 4), (2, 0, 6, 10),
+                                                             (8, 0, 15, 4)])     # eight ranks, overlapped hand-offs like the bench (the run is 30 steps: 15 divides it)
 def test_sharded_equals_single_process(world, interval, rebalance, overlap, tmp_path, oracle_libs):
     """overlap > 0: the step loop keeps running for that many cycles after the split while counts and payload
     travel; the arrivals then replay the cycles they missed (same per-particle Philox stream, same result)."""
