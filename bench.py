@@ -4,13 +4,18 @@ pitzDaily mesh (12 225 cells), uniform U = (10,0,0) m/s, dt = 1e-4 s, D = 0, fp6
 whole fluid domain.  --gpus 1: 1e7 particles (BASELINE.json configs[2]).  --gpus N > 1:
 the north star's scaling experiment, 1e8 particles IN TOTAL sharded over the N ranks (configs[3]; "strong").
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks as a child process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one Lagrangian cycle of the whole cloud (one launch of the fused kernel per rank,
 plus, when N > 1, the ownership re-cut + hand-off every --rebalance-interval steps).  Inputs are resident in HBM when the
 timed region starts.  Rank 0 prints ONE JSON line.
+
+Layout: `run(args, M)` is the measurement; everything it needs from the machine -- device, context, collectives,
+seeding, the single-GPU extras -- comes from `M` (`GpuMachine`: one MI355X per rank, RCCL).  tests/ drive the same
+`run()` with a CPU stand-in for `M` over gloo to check the N > 1 orchestration and the JSON contract without a GPU;
+this script itself has no CPU path.
 """
 from __future__ import annotations
 
@@ -30,7 +35,7 @@ ALGO_BYTES_PER_PARTICLE_STEP = 56      # fp64 SoA: read x,y,z (24) + cell (4), w
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -62,6 +67,9 @@ def parse():
                     help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by "
+                         "itself when no launcher set WORLD_SIZE)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
@@ -71,37 +79,17 @@ def parse():
     ap.add_argument("--brownian-extra", type=int, default=20,
                     help="after the timed region (N = 1): that many launches with the tutorial's D = 1.5e-5, reported "
                          "as config.brownian; 0 = skip")
-    a = ap.parse_args()
+    ap.add_argument("--anchor-particles", type=float, default=1e8,
+                    help="after the timed region (N = 1): the strong-scaling experiment's total cloud (what --gpus N > 1 "
+                         "shards) stepped on this ONE GPU, reported as config.strong_anchor_1e8 -- the N = 1 point of "
+                         "the strong-scaling curve, never `value`; 0 = skip")
+    ap.add_argument("--anchor-steps", type=int, default=10)
+    a = ap.parse_args(argv)
     if a.scaling is None:
         a.scaling = "weak" if a.gpus == 1 else "strong"
     if a.particles is None:
         a.particles = 1e7 if (a.gpus == 1 or a.scaling == "weak") else 1e8
     return a
-
-
-def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None):
-    """n points uniform in `box`, rejection-resampled until located in a cell (SURVEY.md 8d config 3);
-    with cell_range=(lo, hi) only points whose cell lies in [lo, hi) are kept (a rank seeding its own slab)."""
-    g = torch.Generator(device=device); g.manual_seed(seed)
-    lo = torch.tensor(box[0], dtype=torch.float64, device=device)
-    ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
-    xs, ys, zs, cs = [], [], [], []
-    have = 0
-    while have < n:
-        m = int((n - have) * 1.35) + 1024
-        u = torch.rand((3, m), generator=g, dtype=torch.float64, device=device)
-        x = (lo[0] + u[0] * ext[0]).contiguous(); y = (lo[1] + u[1] * ext[1]).contiguous()
-        z = (lo[2] + u[2] * ext[2]).contiguous()
-        c = torch.empty(m, dtype=torch.int32, device=device)
-        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
-        torch.cuda.synchronize()
-        keep = c >= 0
-        if cell_range is not None:
-            keep &= (c >= cell_range[0]) & (c < cell_range[1])
-        xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
-        have += int(keep.sum())
-    cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
-    return cat(xs), cat(ys), cat(zs), cat(cs)
 
 
 def cpu_baseline(mesh, centres, U, seconds):
@@ -144,97 +132,115 @@ def cpu_baseline(mesh, centres, U, seconds):
                        "particles, %.1f s" % (n, cycles, el))
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    import torch
-    import torch.distributed as dist
-    from cudaparticlesfoam_amd import _lib as L
-    from cudaparticlesfoam_amd.api import Context
-    from cudaparticlesfoam_amd.cases import pitzdaily as pz
-    from cudaparticlesfoam_amd.parallel import (HipOps, ShardedCloud, slab_bounding_box, slab_cell_ranges,
-                                                    x_slab_renumbering)
-
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1 or args.force_dist:
-        # stdout belongs to the ONE JSON line.  This image exports NCCL_DEBUG=VERSION, which makes every rank print a
-        # five-line banner on stdout (NCCL_DEBUG_FILE does not move it): ask for warnings only instead, send whatever
-        # else RCCL logs to stderr, and print the JSON after everything else has been flushed (below)
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here as a CHILD process -- this process has
+    not touched the GPU and never does -- the way the driver starts them for N > 1, forward rank 0's one JSON line as
+    this process's only stdout line (anything else the ranks wrote to stdout goes to stderr) and return the child's
+    exit code.  (The reference has no counterpart: one GPU, driven by the MPI master only, src/advect.H:59-89.)"""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC (RCCL across processes)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    json_lines = []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            json_lines.append(ln)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            print(ln, file=sys.stderr)
+    if r.returncode == 0 and len(json_lines) != 1:
+        print("bench.py: expected ONE JSON line from rank 0, got %d" % len(json_lines), file=sys.stderr)
+        return 3
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    return r.returncode
 
-    # ---- synthetic case: pitzDaily mesh renumbered into x-slabs (same mesh for every N)
-    mesh0 = pz.pitzdaily_mesh()
-    c0, _ = mesh0.cell_centres_volumes()
-    mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
-    centres, vols = mesh.cell_centres_volumes()
-    U = pz.uniform_u(mesh) if args.field == "uniform" else pz.analytic_step_u(mesh, centres)
-    cell_lo = slab_cell_ranges(vols, world)
 
-    ctx = Context(local)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_mesh(mesh)
-    ctx.set_velocity(U)
+class GpuMachine:
+    """What `run()` needs from the machine: one MI355X per rank through the C-ABI, collectives over RCCL.
+    No CPU fallback: without a GPU or without the HIP library the constructor exits."""
 
-    n_total = int(args.particles) * (world if args.scaling == "weak" else 1)
-    n_local = n_total // world
-    # every rank seeds its own x-slab: the sampling box is clipped to the slab's points, then points are kept
-    # only if their cell belongs to the rank
-    box = [list(pz.DOMAIN_BOX[0]), list(pz.DOMAIN_BOX[1])]
-    if world > 1:
-        lo_pt, hi_pt = slab_bounding_box(mesh, int(cell_lo[rank]), int(cell_lo[rank + 1]))
-        box[0][0] = max(box[0][0], float(lo_pt[0]) - 1e-9)
-        box[1][0] = min(box[1][0], float(hi_pt[0]) + 1e-9)
-    x, y, z, c = seed_in_fluid(ctx, torch, n_local, box, 1000 + rank, device,
-                               (int(cell_lo[rank]), int(cell_lo[rank + 1])) if world > 1 else None)
-    gid = torch.arange(n_local, dtype=torch.int64, device=device) + rank * n_local
-    # 288 GB of HBM: slack is free.  3x capacity and a send buffer as large as the shard make an overflow
-    # impossible even if a whole neighbouring slab drains into this rank between two rebalances.
-    cap = (int(n_local * 3.0) if world > 1 else n_local) + 4096
-    cloud = ShardedCloud(HipOps(ctx), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
-                         exchange_interval=args.exchange_interval)
-    cloud.force_collectives = args.force_dist
-    if args.force_dist and world == 1:
-        cloud.send_capacity = cloud.capacity
-        cloud.sendbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
-        cloud.recvbuf = torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=torch.float64, device=device)
-    cloud.rebalance_interval = args.rebalance_interval
-    cloud.overlap_steps = args.overlap_steps
-    cloud.timing_on = True
-    if (world > 1 or args.force_dist) and args.balance == "time":
-        cloud.enable_time_balancing()
-    cloud.sort_interval = 0 if args.no_sort else args.sort_interval
-    cloud.set_particles(x, y, z, c, gid)
-    del x, y, z, c, gid
-    if world > 1 or args.force_dist:
-        cloud.rebalance(mesh.n_cells)         # also pays RCCL's one-time all-reduce / all-to-all set-up before timing
-        cloud.exchange()
-    if not args.no_sort:
-        cloud.sort()
-    torch.cuda.synchronize()
+    collectives = "RCCL all-to-all"
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def __init__(self, args, rank, world, local):
+        import torch
+        import torch.distributed as dist
+        from cudaparticlesfoam_amd.api import Context
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        self.dist_on = world > 1 or args.force_dist
+        if self.dist_on:
+            # stdout belongs to the ONE JSON line.  This image exports NCCL_DEBUG=VERSION, which makes every rank print a
+            # five-line banner on stdout (NCCL_DEBUG_FILE does not move it): ask for warnings only instead, send whatever
+            # else RCCL logs to stderr, and print the JSON after everything else has been flushed (main)
+            if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+                os.environ["NCCL_DEBUG"] = "WARN"
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+            if "WORLD_SIZE" not in os.environ:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.device)
+            else:
+                dist.init_process_group("nccl", device_id=self.device)
+        self.ctx = Context(local)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    dt = 1e-4
-    # Device spin-up (see --spinup-ms): the cloud itself is untouched, the W warm-up steps and the K timed steps below
-    # are the first steps it ever takes.
-    spinup = None
-    if args.spinup_ms > 0 and cloud.n > 0:
+    def set_case(self, mesh, U):
+        self.ctx.set_mesh(mesh)
+        self.ctx.set_velocity(U)
+
+    def make_ops(self):
+        from cudaparticlesfoam_amd.parallel import HipOps
+        return HipOps(self.ctx)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def seed_in_fluid(self, n, box, seed, cell_range=None, chunk=20_000_000):
+        """n points uniform in `box`, rejection-resampled until located in a cell (SURVEY.md 8d config 3);
+        with cell_range=(lo, hi) only points whose cell lies in [lo, hi) are kept (a rank seeding its own slab)."""
+        torch, device, ctx = self.torch, self.device, self.ctx
+        g = torch.Generator(device=device); g.manual_seed(seed)
+        lo = torch.tensor(box[0], dtype=torch.float64, device=device)
+        ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
+        xs, ys, zs, cs = [], [], [], []
+        have = 0
+        while have < n:
+            m = min(int((n - have) * 1.35) + 1024, chunk)
+            u = torch.rand((3, m), generator=g, dtype=torch.float64, device=device)
+            x = (lo[0] + u[0] * ext[0]).contiguous(); y = (lo[1] + u[1] * ext[1]).contiguous()
+            z = (lo[2] + u[2] * ext[2]).contiguous()
+            del u
+            c = torch.empty(m, dtype=torch.int32, device=device)
+            ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
+            torch.cuda.synchronize()
+            keep = c >= 0
+            if cell_range is not None:
+                keep &= (c >= cell_range[0]) & (c < cell_range[1])
+            xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
+            have += int(keep.sum())
+        cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
+        return cat(xs), cat(ys), cat(zs), cat(cs)
+
+    def prepare_cloud(self, cloud, args):
+        from cudaparticlesfoam_amd import _lib as L
+        if args.force_dist and self.world == 1:
+            cloud.send_capacity = cloud.capacity
+            cloud.sendbuf = self.torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=self.torch.float64, device=self.device)
+            cloud.recvbuf = self.torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=self.torch.float64, device=self.device)
+
+    def spinup(self, cloud, dt, ms):
+        """Device spin-up (see --spinup-ms): the cloud itself is untouched, the W warm-up steps and the K timed steps
+        are the first steps it ever takes."""
+        torch, ctx = self.torch, self.ctx
+        if ms <= 0 or cloud.n <= 0:
+            return None
         sp = lambda a: a.data_ptr()   # noqa: E731
         sx, sy, sz, sc = (a[:cloud.n].clone() for a in (cloud.x, cloud.y, cloud.z, cloud.cell))
         # (the statistics-on instantiation, like the warm-up steps: a profiler's per-kernel average of the headline
@@ -242,104 +248,68 @@ def main():
         ctx.set_option("stats", 1)
         torch.cuda.synchronize()
         ts, launches = time.perf_counter(), 0
-        while (time.perf_counter() - ts) * 1e3 < args.spinup_ms:
+        while (time.perf_counter() - ts) * 1e3 < ms:
             for _ in range(40):
                 ctx.step_dev(sp(sx), sp(sy), sp(sz), sp(sc), None, None, cloud.n, dt, 0.0, 0, 1, 0)
             launches += 40
             torch.cuda.synchronize()
-        spinup = {"ms": round((time.perf_counter() - ts) * 1e3, 1), "launches": launches,
-                  "on": "a scratch copy of the rank's cloud, discarded; the cloud's own first steps are the warm-up steps"}
-        del sx, sy, sz, sc
-    ctx.set_option("stats", 1)
-    counters0 = ctx.counters()
-    cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
-    torch.cuda.synchronize(); barrier()
-    counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
-    ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
-    n_before = cloud.global_count()
-    # live kernel timing for the roofline: HIP events around every 4th launch of the timed region (a pair around
-    # EVERY launch costs 3.5 % of the throughput it is there to measure: 0.166 vs 0.160 ms/step)
-    ctx.set_option("timing_stride", args.timing_stride)
-    ctx.timing_enable(True)
-    ctx.timing_read()                              # drop the warm-up launches' events
-    handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
-    hhost0, ncomm0 = cloud.handoff_host_ms, len(cloud._comm_events)
-    torch.cuda.synchronize(); barrier()
-    t0 = time.perf_counter()
-    cloud.step(dt, args.steps)
-    cloud.flush()                                  # a hand-off still in flight belongs to the timed region
-    torch.cuda.synchronize(); barrier()
-    el = time.perf_counter() - t0
-    launches, kernel_ms = ctx.timing_read()        # + what the load balancer drained during the timed region
-    launches += cloud.kernel_launches - launches0; kernel_ms += cloud.kernel_ms - ms0
-    psteps = cloud.particle_steps - psteps0
-    ctx.timing_enable(False)
-    handoff_host_ms = cloud.handoff_host_ms - hhost0
-    comm_events = cloud._comm_events[ncomm0:]
-    handoff_comm_ms = 0.0
-    for a_, b_ in comm_events:
-        b_.synchronize(); handoff_comm_ms += a_.elapsed_time(b_)
-    rccl_ranks = dist.get_world_size() if (world > 1 or args.force_dist) else 1
-    per_rank = [cloud.n]
-    if world > 1:
-        tn = torch.tensor([cloud.n], dtype=torch.int64, device=device)
-        rows = [torch.empty_like(tn) for _ in range(world)]
-        dist.all_gather(rows, tn)
-        per_rank = [int(r.item()) for r in rows]
-    t = torch.tensor([el], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-    n_after = cloud.global_count()
+        return {"ms": round((time.perf_counter() - ts) * 1e3, 1), "launches": launches,
+                "on": "a scratch copy of the rank's cloud, discarded; the cloud's own first steps are the warm-up steps"}
 
-    # Outside the timed region, single GPU only, right after it (the cloud is still where the timed steps left it): the
-    # tutorial's diffusion coefficient (pitzDaily/system/cudaParticlesDict: diffusionCoeff 1.5e-5) -- another
-    # instantiation of the same kernel, never `value`.
-    brown = None
-    if world == 1 and not args.force_dist and args.brownian_extra > 0:
-        Db = 1.5e-5
-        cloud.step(dt, 3, D=Db)
-        torch.cuda.synchronize()
-        ctx.timing_enable(True); ctx.timing_read()
-        tb = time.perf_counter()
-        cloud.step(dt, args.brownian_extra, D=Db)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb
-        lb, msb = ctx.timing_read()
-        ctx.timing_enable(False)
-        kb = msb / max(lb, 1)
-        bytes_b = ALGO_BYTES_PER_PARTICLE_STEP + 8          # + the 8-byte particle id the Philox counter needs
-        brown = {"D": Db, "ms_per_step": round(tb / args.brownian_extra * 1e3, 4), "kernel_avg_ms": round(kb, 4),
-                 "kernel": ctx.step_kernel_name(Db, 0), "algorithmic_bytes_per_particle_step": bytes_b,
-                 "achieved_GBs": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
-                 "frac": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kb > 0 else None}
-        if not args.no_sort:
-            cloud.sort()        # diffusion scrambles the order within a few dozen steps: the extras below start sorted again
+    def comm_ms(self, events):
+        tot = 0.0
+        for a_, b_ in events:
+            b_.synchronize(); tot += a_.elapsed_time(b_)
+        return tot
 
-    # Outside the timed region, single GPU only: the same cloud stepped with 8 cycles fused into one launch
-    # (CPF_STEP_FUSE_CYCLES: what the replacement advect.H does between two output points; results identical,
-    # tests/test_gpu_parity.py).  Reported as an extra, never as `value`.
-    fused = None
-    if world == 1 and not args.force_dist and args.fused_extra > 0:
-        p = lambda a: a.data_ptr()   # noqa: E731
-        K = 8
-        ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
-                     cloud.step_index, K, L.STEP_FUSE_CYCLES)
-        torch.cuda.synchronize()
-        tf = time.perf_counter()
-        for r in range(args.fused_extra):
+    def extras(self, cloud, dt, args, box):
+        """Outside the timed region, single GPU only, never `value`: (brownian, fused, steady, anchor)."""
+        from cudaparticlesfoam_amd import _lib as L
+        torch, ctx = self.torch, self.ctx
+        # right after the timed region (the cloud is still where the timed steps left it): the tutorial's diffusion
+        # coefficient (pitzDaily/system/cudaParticlesDict: diffusionCoeff 1.5e-5) -- another instantiation of the same kernel
+        brown = None
+        if args.brownian_extra > 0:
+            Db = 1.5e-5
+            cloud.step(dt, 3, D=Db)
+            torch.cuda.synchronize()
+            ctx.timing_enable(True); ctx.timing_read()
+            tb = time.perf_counter()
+            cloud.step(dt, args.brownian_extra, D=Db)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            lb, msb = ctx.timing_read()
+            ctx.timing_enable(False)
+            kb = msb / max(lb, 1)
+            bytes_b = ALGO_BYTES_PER_PARTICLE_STEP + 8          # + the 8-byte particle id the Philox counter needs
+            brown = {"D": Db, "ms_per_step": round(tb / args.brownian_extra * 1e3, 4), "kernel_avg_ms": round(kb, 4),
+                     "kernel": ctx.step_kernel_name(Db, 0), "algorithmic_bytes_per_particle_step": bytes_b,
+                     "achieved_GBs": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
+                     "frac": round(bytes_b * cloud.n / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kb > 0 else None}
+            if not args.no_sort:
+                cloud.sort()        # diffusion scrambles the order within a few dozen steps: the extras below start sorted again
+
+        # the same cloud stepped with 8 cycles fused into one launch (CPF_STEP_FUSE_CYCLES: what the replacement
+        # advect.H does between two output points; results identical, tests/test_gpu_parity.py)
+        fused = None
+        if args.fused_extra > 0:
+            p = lambda a: a.data_ptr()   # noqa: E731
+            K = 8
             ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
-                         cloud.step_index + K * (r + 1), K, L.STEP_FUSE_CYCLES)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - tf
-        fused = {"cycles_per_launch": K, "launches": args.fused_extra,
-                 "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
-                 "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
+                         cloud.step_index, K, L.STEP_FUSE_CYCLES)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for r in range(args.fused_extra):
+                ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
+                             cloud.step_index + K * (r + 1), K, L.STEP_FUSE_CYCLES)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf
+            fused = {"cycles_per_launch": K, "launches": args.fused_extra,
+                     "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
+                     "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
 
-    # Outside the timed region, single GPU: steady state -- one full sort interval, so the periodic re-sort the short
-    # window may miss is in.
-    steady = None
-    if world == 1 and not args.force_dist:
+        # steady state -- one full sort interval, so the periodic re-sort the short window may miss is in
+        steady = None
         k = args.steady_steps if args.steady_steps >= 0 else (0 if args.no_sort else args.sort_interval)
         if k > 0:
             torch.cuda.synchronize()
@@ -352,11 +322,154 @@ def main():
                       "first_step": cloud.step_index - k,
                       "sorts_inside": (cloud.step_index // max(1, cloud.sort_interval)) -
                                       ((cloud.step_index - k) // max(1, cloud.sort_interval)) if cloud.sort_interval else 0}
+
+        # the N = 1 point of the strong-scaling curve: the cloud `--gpus N > 1` shards (1e8 in total), on this one GPU,
+        # same mesh, field, seeding rule, sort and kernel; its own scratch arrays, freed afterwards
+        anchor = None
+        na = int(args.anchor_particles)
+        if na > 0 and args.anchor_steps > 0:
+            p = lambda a: a.data_ptr()   # noqa: E731
+            ax, ay, az, ac = self.seed_in_fluid(na, box, 4711)
+            ag = torch.arange(na, dtype=torch.int64, device=self.device)
+            if not args.no_sort:
+                o = [torch.empty_like(t_) for t_ in (ax, ay, az, ac, ag)]
+                ctx.sort_by_cell_dev_to(p(ax), p(ay), p(az), p(ac), p(ag), *[p(t_) for t_ in o], na)
+                torch.cuda.synchronize()
+                ax, ay, az, ac, ag = o
+            for s_ in range(3):
+                ctx.step_dev(p(ax), p(ay), p(az), p(ac), p(ag), None, na, dt, 0.0, s_, 1, 0)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for s_ in range(args.anchor_steps):
+                ctx.step_dev(p(ax), p(ay), p(az), p(ac), p(ag), None, na, dt, 0.0, 3 + s_, 1, 0)
+            torch.cuda.synchronize()
+            ta = time.perf_counter() - ta
+            alive = int((ac >= 0).sum())
+            anchor = {"particles": na, "particles_after": alive, "steps": args.anchor_steps,
+                      "ms_per_step": round(ta / args.anchor_steps * 1e3, 4),
+                      "Mparticle_steps_per_s": round(na * args.anchor_steps / ta / 1e6, 1),
+                      "note": "one GPU, no sharding, no hand-off: divide the --gpus N value by this for the strong-scaling ratio"}
+            del ax, ay, az, ac, ag
+        return brown, fused, steady, anchor
+
+    def finish(self):
+        if self.dist_on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        self.ctx.close()
+
+
+def run(args, M):
+    """The measurement.  Returns the JSON record on rank 0, None elsewhere."""
+    from cudaparticlesfoam_amd.cases import pitzdaily as pz
+    from cudaparticlesfoam_amd.parallel import ShardedCloud, slab_bounding_box, slab_cell_ranges, x_slab_renumbering
+    torch, dist, rank, world, device = M.torch, M.dist, M.rank, M.world, M.device
+    dist_on = world > 1 or args.force_dist
+
+    # ---- synthetic case: pitzDaily mesh renumbered into x-slabs (same mesh for every N)
+    mesh0 = pz.pitzdaily_mesh()
+    c0, _ = mesh0.cell_centres_volumes()
+    mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
+    centres, vols = mesh.cell_centres_volumes()
+    U = pz.uniform_u(mesh) if args.field == "uniform" else pz.analytic_step_u(mesh, centres)
+    cell_lo = slab_cell_ranges(vols, world)
+    M.set_case(mesh, U)
+    ctx = M.ctx
+
+    n_total = int(args.particles) * (world if args.scaling == "weak" else 1)
+    n_local = n_total // world
+    # every rank seeds its own x-slab: the sampling box is clipped to the slab's points, then points are kept
+    # only if their cell belongs to the rank
+    box = [list(pz.DOMAIN_BOX[0]), list(pz.DOMAIN_BOX[1])]
+    full_box = [list(box[0]), list(box[1])]
+    if world > 1:
+        lo_pt, hi_pt = slab_bounding_box(mesh, int(cell_lo[rank]), int(cell_lo[rank + 1]))
+        box[0][0] = max(box[0][0], float(lo_pt[0]) - 1e-9)
+        box[1][0] = min(box[1][0], float(hi_pt[0]) + 1e-9)
+    x, y, z, c = M.seed_in_fluid(n_local, box, 1000 + rank,
+                                 (int(cell_lo[rank]), int(cell_lo[rank + 1])) if world > 1 else None)
+    gid = torch.arange(n_local, dtype=torch.int64, device=device) + rank * n_local
+    # 288 GB of HBM: slack is free.  3x capacity and a send buffer as large as the shard make an overflow
+    # impossible even if a whole neighbouring slab drains into this rank between two rebalances.
+    cap = (int(n_local * 3.0) if world > 1 else n_local) + 4096
+    cloud = ShardedCloud(M.make_ops(), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
+                         exchange_interval=args.exchange_interval)
+    cloud.force_collectives = args.force_dist
+    M.prepare_cloud(cloud, args)
+    cloud.rebalance_interval = args.rebalance_interval
+    cloud.overlap_steps = args.overlap_steps
+    cloud.timing_on = True
+    if dist_on and args.balance == "time":
+        cloud.enable_time_balancing()
+    cloud.sort_interval = 0 if args.no_sort else args.sort_interval
+    cloud.set_particles(x, y, z, c, gid)
+    del x, y, z, c, gid
+    if dist_on:
+        cloud.rebalance(mesh.n_cells)         # also pays RCCL's one-time all-reduce / all-to-all set-up before timing
+        cloud.exchange()
+    if not args.no_sort:
+        cloud.sort()
+    M.sync()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    dt = 1e-4
+    spinup = M.spinup(cloud, dt, args.spinup_ms)
+    ctx.set_option("stats", 1)
+    counters0 = ctx.counters()
+    cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
+    M.sync(); barrier()
+    counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
+    ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
+    n_before = cloud.global_count()
+    # live kernel timing for the roofline: HIP events around every 4th launch of the timed region (a pair around
+    # EVERY launch costs 3.5 % of the throughput it is there to measure: 0.166 vs 0.160 ms/step)
+    ctx.set_option("timing_stride", args.timing_stride)
+    ctx.timing_enable(True)
+    ctx.timing_read()                              # drop the warm-up launches' events
+    handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
+    hhost0, ncomm0, ex0 = cloud.handoff_host_ms, len(cloud._comm_events), cloud.exchanges
+    cloud.profile_comm = True                      # keep the (start, end) events of the hand-offs' collectives
+    M.sync(); barrier()
+    t0 = time.perf_counter()
+    cloud.step(dt, args.steps)
+    cloud.flush()                                  # a hand-off still in flight belongs to the timed region
+    M.sync(); barrier()
+    el = time.perf_counter() - t0
+    launches, kernel_ms = ctx.timing_read()        # + what the load balancer drained during the timed region
+    launches += cloud.kernel_launches - launches0; kernel_ms += cloud.kernel_ms - ms0
+    psteps = cloud.particle_steps - psteps0
+    ctx.timing_enable(False)
+    handoff_host_ms = cloud.handoff_host_ms - hhost0
+    comm_events = cloud._comm_events[ncomm0:]
+    handoff_comm_ms = M.comm_ms(comm_events)
+    handoffs = cloud.exchanges - ex0
+    cloud.profile_comm = False
+    rccl_ranks = dist.get_world_size() if dist_on else 1
+    per_rank = [cloud.n]
+    if world > 1:
+        tn = torch.tensor([cloud.n], dtype=torch.int64, device=device)
+        rows = [torch.empty_like(tn) for _ in range(world)]
+        dist.all_gather(rows, tn)
+        per_rank = [int(r.item()) for r in rows]
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    n_after = cloud.global_count()
+
+    brown = fused = steady = anchor = None
+    if world == 1 and not args.force_dist:
+        brown, fused, steady, anchor = M.extras(cloud, dt, args, full_box)
+
+    out = None
     if rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         per_launch = psteps / max(args.steps, 1)         # rank 0's particles per launch (varies when N > 1)
-        achieved = ALGO_BYTES_PER_PARTICLE_STEP * per_launch / avg_kernel_s / 1e9 if launches else 0.0
+        achieved = ALGO_BYTES_PER_PARTICLE_STEP * per_launch / avg_kernel_s / 1e9 if (launches and avg_kernel_s > 0) else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -376,25 +489,26 @@ def main():
                                    % ("uniform (10,0,0)" if args.field == "uniform" else "analytic step-flow",
                                       ("%d fp64 particles on one GPU seeded over the fluid domain (BASELINE configs[2])" % n_total)
                                       if world == 1 else
-                                      ("%d fp64 particles in total sharded over %d GPUs by x-slab, mesh replicated, RCCL "
-                                       "all-to-all hand-off (BASELINE configs[3], %s scaling; --gpus 1 runs the 1e7 single-GPU "
-                                       "config)" % (n_total, world, args.scaling))),
+                                      ("%d fp64 particles in total sharded over %d GPUs by x-slab, mesh replicated, %s "
+                                       "hand-off (BASELINE configs[3], %s scaling; --gpus 1 runs the 1e7 single-GPU "
+                                       "config and reports this cloud on one GPU as config.strong_anchor_1e8)"
+                                       % (n_total, world, M.collectives, args.scaling))),
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
                        "rebalance_interval": args.rebalance_interval if world > 1 else None,
-                       "overlap_steps": args.overlap_steps if (world > 1 or args.force_dist) else None,
+                       "overlap_steps": args.overlap_steps if dist_on else None,
                        "balance": (("measured step time" if args.balance == "time" else "particle count")
-                                   if (world > 1 or args.force_dist) else None),
+                                   if dist_on else None),
                        "particles_per_rank_at_end": per_rank if world > 1 else None,
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
-                                                     if (world > 1 or args.force_dist) else None),
+                                                     if dist_on else None),
                        "rccl_ranks": rccl_ranks,
                        "ms_in_handoff": ({"host_ms_total": round(handoff_host_ms, 3), "collectives_device_ms_total": round(handoff_comm_ms, 3),
-                                          "handoffs": len(comm_events),
+                                          "handoffs": handoffs,
                                           "host_ms_per_step": round(handoff_host_ms / max(1, args.steps), 4)}
-                                         if (world > 1 or args.force_dist) else None),
+                                         if dist_on else None),
                        "ms_per_step_steady": steady, "brownian": brown, "device_spinup": spinup,
-                       "extra_fused_cycles": fused,
+                       "extra_fused_cycles": fused, "strong_anchor_1e8": anchor,
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
                        "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},
@@ -412,10 +526,20 @@ def main():
             except Exception as e:          # the checker being absent must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
                                        "sample": "unavailable: %r" % (e,)}
-    if world > 1 or args.force_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    M.finish()
+    return out
+
+
+def main():
+    args = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args))                 # before any import that could touch the GPU
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
+    out = run(args, GpuMachine(args, rank, world, local))
     if rank == 0:
         # the JSON line is the LAST thing on stdout: anything a library left in C stdio's buffer goes out before it
         try:

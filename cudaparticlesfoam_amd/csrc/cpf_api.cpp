@@ -536,12 +536,19 @@ int cpf_sort_by_cell(cpf_context* ctx) {
     if (ctx->x2 == nullptr) {
         CPF_HIP(ctx, hipSetDevice(ctx->device));
         const size_t c = (size_t)ctx->cap;
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->x2, c * 8));
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->y2, c * 8));
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->z2, c * 8));
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->cell2, c * 4));
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->gid2, c * 8));
-        CPF_HIP(ctx, hipMemsetAsync(ctx->cell2, 0xFF, c * 4, ctx->stream));
+        // all five or none: a failure part-way must not leave x2 set and the later pointers null (the next call would
+        // skip this block and scatter into null pointers)
+        void* b[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const size_t bytes[5] = {c * 8, c * 8, c * 8, c * 4, c * 8};
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMalloc(&b[k], bytes[k]);
+        if (e == hipSuccess) e = hipMemsetAsync(b[3], 0xFF, bytes[3], ctx->stream);
+        if (e != hipSuccess) {
+            for (int k = 0; k < 5; ++k) if (b[k]) (void)hipFree(b[k]);
+            CPF_HIP(ctx, e);
+        }
+        ctx->x2 = (double*)b[0]; ctx->y2 = (double*)b[1]; ctx->z2 = (double*)b[2];
+        ctx->cell2 = (int32_t*)b[3]; ctx->gid2 = (int64_t*)b[4];
     }
     int r = sortImpl(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->n, ctx->x2, ctx->y2, ctx->z2, ctx->cell2, ctx->gid2,
                      ctx->vel);

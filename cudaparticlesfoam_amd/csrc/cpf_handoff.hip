@@ -54,9 +54,12 @@ __global__ __launch_bounds__(kBlock) void count_leavers_kernel(const int32_t* __
     if (threadIdx.x < nRanks) blockCnt[(int64_t)blockIdx.x * nRanks + threadIdx.x] = sCnt[threadIdx.x];
 }
 
-// single block: exclusive scan of blockCnt over blocks per destination; totals, bases, nStay
+// single block: exclusive scan of blockCnt over blocks per destination; totals, bases, nStay.
+// Leavers that do not fit into the send buffer abort the split HERE, on the device: *nStay = -1, holeFill[2] = 1, and
+// the three kernels after this one touch nothing -- the shard stays exactly as it was (the caller keeps stepping it),
+// counts[] say how large the buffer has to be, and the host can repeat the split (parallel.py, _finish_exchange).
 __global__ __launch_bounds__(kBlock) void scan_leavers_kernel(int32_t* __restrict__ blockCnt, int nBlocks, int nRanks,
-                                                              int64_t n, int64_t* __restrict__ counts,
+                                                              int64_t n, int64_t sendCapacity, int64_t* __restrict__ counts,
                                                               int64_t* __restrict__ destBase,
                                                               int64_t* __restrict__ nStay,
                                                               unsigned long long* __restrict__ holeFill) {
@@ -87,8 +90,9 @@ __global__ __launch_bounds__(kBlock) void scan_leavers_kernel(int32_t* __restric
     if (threadIdx.x == 0) {
         long long run = 0;
         for (int r = 0; r < nRanks; ++r) { counts[r] = sTot[r]; destBase[r] = run; run += sTot[r]; }
-        *nStay = n - run;
-        holeFill[0] = 0; holeFill[1] = 0;
+        const bool fits = run <= sendCapacity;
+        *nStay = fits ? n - run : -1;
+        holeFill[0] = 0; holeFill[1] = 0; holeFill[2] = fits ? 0ull : 1ull;
     }
 }
 
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
     int32_t* __restrict__ holes, int32_t* __restrict__ fillers, unsigned long long* __restrict__ holeFill) {
     __shared__ int sWave[kBlock / 64][kMaxRanks];
     __shared__ int sRun[kMaxRanks];
+    if (holeFill[2] != 0ull) return;                          // split aborted (send buffer too small): move nothing
     if (threadIdx.x < kMaxRanks) sRun[threadIdx.x] = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long ltMask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -121,12 +126,10 @@ __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
             int off = sRun[d] + myPrefix;
             for (int w = 0; w < wave; ++w) off += sWave[w][d];
             const int64_t slot = destBase[d] + blockOff[(int64_t)blockIdx.x * nRanks + d] + off;
-            if (slot < sendCapacity) {
-                double* rec = sendbuf + slot * CPF_HANDOFF_DOUBLES;
-                rec[0] = x[i]; rec[1] = y[i]; rec[2] = z[i];
-                rec[3] = (double)c;                              // exact: |c| < 2^31
-                rec[4] = (double)(gid ? gid[i] : i);             // exact below 2^53
-            }
+            double* rec = sendbuf + slot * CPF_HANDOFF_DOUBLES;   // slot < sendCapacity: the scan kernel checked the total
+            rec[0] = x[i]; rec[1] = y[i]; rec[2] = z[i];
+            rec[3] = (double)c;                                  // exact: |c| < 2^31
+            rec[4] = (double)(gid ? gid[i] : i);                 // exact below 2^53
             if (i < nStay) holes[atomicAdd(&holeFill[0], 1ull)] = (int32_t)i;
         } else if (i < n && i >= nStay) {
             fillers[atomicAdd(&holeFill[1], 1ull)] = (int32_t)i;
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(kBlock) void fill_holes_kernel(double* __restrict__
 // only with the counts): inactive lanes cost one 4-byte load.
 __global__ __launch_bounds__(kBlock) void mark_tail_kernel(int32_t* __restrict__ cell, const int64_t* __restrict__ nStayPtr,
                                                            int64_t n) {
-    for (int64_t i = *nStayPtr + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    const int64_t nStay = *nStayPtr;
+    if (nStay < 0) return;                                    // split aborted: nothing is stale
+    for (int64_t i = nStay + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         cell[i] = CPF_CELL_LOST;
 }
 
@@ -368,7 +373,7 @@ static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 size_t handoff_scratch_bytes(int64_t n, int nRanks) {
     const int64_t nBlocks = (n + kTile - 1) / kTile;
-    return al256((size_t)nBlocks * nRanks * 4) + al256((size_t)kMaxRanks * 8) + al256(16) + 2 * al256((size_t)n * 4);
+    return al256((size_t)nBlocks * nRanks * 4) + al256((size_t)kMaxRanks * 8) + al256(24) + 2 * al256((size_t)n * 4);
 }
 
 hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
@@ -380,13 +385,13 @@ hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t
     char* p = (char*)scratch;
     int32_t* blockCnt = (int32_t*)p; p += al256((size_t)std::max(nBlocks, 1) * nRanks * 4);
     int64_t* destBase = (int64_t*)p; p += al256((size_t)kMaxRanks * 8);
-    unsigned long long* holeFill = (unsigned long long*)p; p += al256(16);
+    unsigned long long* holeFill = (unsigned long long*)p; p += al256(24);
     int32_t* holes = (int32_t*)p; p += al256((size_t)n * 4);
     int32_t* fillers = (int32_t*)p;
     if (nBlocks > 0)
         hipLaunchKernelGGL(count_leavers_kernel, dim3(nBlocks), dim3(kBlock), 0, st, cell, n, cellLo, nRanks, myRank,
                            blockCnt);
-    hipLaunchKernelGGL(scan_leavers_kernel, dim3(1), dim3(kBlock), 0, st, blockCnt, nBlocks, nRanks, n, counts,
+    hipLaunchKernelGGL(scan_leavers_kernel, dim3(1), dim3(kBlock), 0, st, blockCnt, nBlocks, nRanks, n, sendCapacity, counts,
                        destBase, nStay, holeFill);
     if (nBlocks > 0) {
         hipLaunchKernelGGL(write_leavers_kernel, dim3(nBlocks), dim3(kBlock), 0, st, x, y, z, cell, gid, n, cellLo,

@@ -515,8 +515,7 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug};
     hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
                        gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
-    ss.parity ^= 1;
-    return hipGetLastError();
+    return stream_launch_done(st, ss);
 }
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare

@@ -76,4 +76,15 @@ struct StreamArgs {
     int debug;             // diagnostics only (results are wrong): 1 = no stores, 2 = no loads after a wave's first tile
 };
 
+// After a streaming launch: the launch zeroed the OTHER counter set for its successor, so the sets swap roles -- but only
+// if the launch really went out.  A failed launch has zeroed nothing: both sets are cleared on the stream instead, so the
+// next launch never starts on counters an older launch left exhausted (every wave would exit at once and the particles
+// would go unstepped without an error).
+inline hipError_t stream_launch_done(hipStream_t st, StreamState& ss) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) { ss.parity ^= 1; return e; }
+    (void)hipMemsetAsync(ss.d_grab, 0, kStreamGrabBytes, st);
+    return e;
+}
+
 }  // namespace cpf

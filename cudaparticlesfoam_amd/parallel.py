@@ -204,7 +204,9 @@ class ShardedCloud:
         self.rebalances = 0
         self.grown = 0               # times the arrays had to be enlarged for arrivals
         self.handoff_host_ms = 0.0   # host wall time spent in the re-cut / split / exchange calls (incl. their one sync)
-        self._comm_events = []       # (start, end) device events around the collectives of every hand-off
+        self.profile_comm = False    # keep timing-enabled (start, end) device events around every hand-off's collectives
+        self._comm_events = []       # ... here (bench.py reads them); off: one plain event per hand-off, nothing kept
+        self.send_grown = 0          # times the send buffer had to be enlarged and the split repeated (see _finish_exchange)
         self.rebalance_interval = 0  # 0 = never; else every that many steps (needs n_cells)
         self.sort_interval = 0       # 0 = never; else re-sort by cell every that many steps (coalescing)
         self.force_collectives = False   # run the hand-off path even with one rank (single-GPU smoke of the N>1 code)
@@ -311,7 +313,13 @@ class ShardedCloud:
 
         One host synchronisation, on the side stream only: the per-destination counts of every rank are
         all-gathered on the device (world x (world+1) int64) and copied to the host once, which gives this
-        rank both its send sizes (its row) and its receive sizes (its column)."""
+        rank both its send sizes (its row) and its receive sizes (its column).
+
+        Send-buffer overflow cannot lose particles or hang the job: a split whose leavers do not fit reports
+        ``nStay < 0`` and moves NOTHING (cpf_pack_leavers_dev).  Every rank reads that in the same all-gathered
+        table, so all of them take the same branch: the overflowing ranks enlarge their send buffers and split again
+        (on the compute stream, i.e. at the current step: their leavers then need no catch-up), everybody repeats
+        the all-gather, and only then does the all-to-all run."""
         p = self._pending
         if p is None:
             return
@@ -319,44 +327,81 @@ class ShardedCloud:
         self._pending = None
         W = self.world
         D = L.HANDOFF_DOUBLES
-        side = contextlib.nullcontext() if self._side is None else torch.cuda.stream(self._side)
+        cuda = self._side is not None
+        compute = torch.cuda.current_stream(self.device) if cuda else None
+        side = torch.cuda.stream(self._side) if cuda else contextlib.nullcontext()
+        repacked = set()                # ranks whose split was repeated at the current step
         with side:
-            if self._side is not None:
+            if cuda:
                 self._side.wait_event(p["event"])
-                ev0 = torch.cuda.Event(enable_timing=True); ev0.record(self._side)
-            meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
-            rows = [torch.empty_like(meta) for _ in range(W)]
-            self.comm.all_gather(rows, meta, group=self.group)
-            host = torch.cat(rows + [self.cell_lo_dev.to(torch.int64)]).cpu().numpy()
-            table = host[: W * (W + 1)].reshape(W, W + 1)
+                ev0 = torch.cuda.Event(enable_timing=self.profile_comm); ev0.record(self._side)
+            while True:
+                meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
+                rows = [torch.empty_like(meta) for _ in range(W)]
+                self.comm.all_gather(rows, meta, group=self.group)
+                host = torch.cat(rows + [self.cell_lo_dev.to(torch.int64)]).cpu().numpy()
+                table = host[: W * (W + 1)].reshape(W, W + 1)
+                over = [r for r in range(W) if table[r, W] < 0]
+                if not over:
+                    break
+                if repacked & set(over):
+                    raise RuntimeError("hand-off: rank(s) %s still overflow after their send buffer was enlarged"
+                                       % sorted(repacked & set(over)))     # same table, same exception on every rank
+                if self.rank in over:
+                    need = int(table[self.rank, :W].sum())
+                    self.send_capacity = need + need // 8 + 1024
+                    self.sendbuf = torch.empty(self.send_capacity * D, dtype=torch.float64, device=self.device)
+                    self.send_grown += 1
+                    self.ops.pack(self)                                  # compute stream: after the steps queued so far
+                    if cuda:
+                        self.sendbuf.record_stream(self._side)
+                        ev = torch.cuda.Event(); ev.record(compute)
+                        self._side.wait_event(ev)
+                repacked |= set(over)
             self.cell_lo = host[W * (W + 1):].astype(np.int32)
             send_counts = [int(v) for v in table[self.rank, :W]]
             recv_counts = [int(v) for v in table[:, self.rank]]
             n_stay = int(table[self.rank, W])
             n_send, n_recv = sum(send_counts), sum(recv_counts)
-            if n_send > self.send_capacity:
-                raise RuntimeError("hand-off buffer overflow: %d leavers > capacity %d" % (n_send, self.send_capacity))
+            assert n_send <= self.send_capacity
             if n_recv * D > self.recvbuf.numel():
                 self.recvbuf = torch.empty(n_recv * D, dtype=torch.float64, device=self.device)
-                if self._side is not None:
-                    self.recvbuf.record_stream(torch.cuda.current_stream(self.device))   # unpack reads it there
+                if cuda:
+                    self.recvbuf.record_stream(compute)                  # unpack reads it there
             self.comm.all_to_all_single(self.recvbuf[: n_recv * D], self.sendbuf[: n_send * D],
                                    [c * D for c in recv_counts], [c * D for c in send_counts], group=self.group)
-            if self._side is not None:
-                done = torch.cuda.Event(enable_timing=True)
+            if cuda:
+                done = torch.cuda.Event(enable_timing=self.profile_comm)
                 done.record(self._side)
-                self._comm_events.append((ev0, done))
-        if self._side is not None:
-            torch.cuda.current_stream(self.device).wait_event(done)   # also orders the next pack after this all-to-all
+                if self.profile_comm:
+                    self._comm_events.append((ev0, done))
+        if cuda:
+            compute.wait_event(done)   # also orders the next pack after this all-to-all
         missed = self.step_index - p["step"]
-        self.particle_steps -= (self.n - n_stay) * missed             # the inactive tail was not real work
+        if self.rank not in repacked:
+            self.particle_steps -= (self.n - n_stay) * missed         # the inactive tail was not real work
         if n_stay + n_recv > self.capacity:
             self._grow(n_stay + n_recv, n_stay)
         self.ops.unpack(self, n_stay, self.recvbuf, n_recv)
         if missed and n_recv:
+            # arrivals sit in source-rank order; those from a rank that split again at the current step are current,
+            # the others replay the cycles they missed -- one launch per run of consecutive sources
             dt, Dc, flags = self._step_args
-            self.ops.step_slice(self, n_stay, n_recv, dt, Dc, p["step"], missed, flags)
-            self.particle_steps += n_recv * missed
+            first = n_stay
+            run_first, run_count = first, 0
+            for src in range(W):
+                k = recv_counts[src]
+                if src in repacked:
+                    if run_count:
+                        self.ops.step_slice(self, run_first, run_count, dt, Dc, p["step"], missed, flags)
+                        self.particle_steps += run_count * missed
+                    run_first, run_count = first + k, 0
+                else:
+                    run_count += k
+                first += k
+            if run_count:
+                self.ops.step_slice(self, run_first, run_count, dt, Dc, p["step"], missed, flags)
+                self.particle_steps += run_count * missed
         self.n = n_stay + n_recv
         self.handed_off += n_send
         self.exchanges += 1

@@ -169,6 +169,8 @@ int cpf_get_particles(cpf_context* ctx, double* xyzw, int32_t* cell, double* vel
 /* cumulative counters since creation (accumulated only while option "stats" is 1): particle-steps done, cells visited,
  * wall reflections, lost */
 int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
+/* Seed of the counter-based Brownian stream (Philox keyed by seed, particle id, step); default 1591593751, the
+ * constant the reference seeds cuRAND with (cuda/particles.cu:544). */
 int cpf_set_seed(cpf_context* ctx, uint32_t seed);
 /* tuning knobs, never semantics (every step variant is bit-identical):
  *   "step_variant"  -1 (default) chosen per launch: 4, but 3 for launches that fuse 3 or more cycles
@@ -194,13 +196,17 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   per 1e7-particle launch)
  *   "timing_stride" cpf_timing_enable brackets every k-th step launch only (default 1)
  *   "sort_interval" cpf_step re-sorts the context-owned cloud by cell every N cycles (default 50, 0 = never);
- *                   invisible to callers: cpf_get_particles always answers in particle-id order */
+ *                   invisible to callers: cpf_get_particles always answers in particle-id order.  The sort writes
+ *                   into a second set of particle arrays that then swap roles with the first: 36 B per particle
+ *                   slot more device memory from the first sort on.  With a diffusion coefficient the order decays
+ *                   ~5x faster: the replacement fragments (compat/src/initCuda.H) and api.CudaParticles set 25 then,
+ *                   bench.py uses 100 (D = 0) */
 int cpf_set_option(cpf_context* ctx, const char* key, double value);
 /* Name of the kernel instantiation cpf_step / cpf_step_dev launches for this diffusion coefficient and these flags with
  * the current mesh and options (and the particle count of the most recent step launch, which picks the record lookup of
  * the streaming kernel), as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false, false>"):
  * lets a benchmark label its roofline with what actually ran. */
-int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes);   /* Brownian stream; default 1591593751 (particles.cu:544) */
+int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes);
 
 /* ---------------------------------------------------------------------------------------------
  * device-array level (framework hosts that own the particle arrays, multi-GPU sharding)
@@ -232,7 +238,10 @@ int cpf_sort_by_cell_dev_to(cpf_context* ctx, const double* x, const double* y, 
  * gid-as-double).  counts[nRanks] (device int64) = records per destination; nStay (device).
  * Lost/frozen particles stay where they are.  The slots [nStay, n) are then marked CPF_CELL_LOST, so a
  * caller that learns nStay late (it sits in device memory) may keep stepping [0, n) while the all-to-all is
- * in flight and let the arrivals catch up afterwards (cpf_step_dev on the appended slice, same step0). */
+ * in flight and let the arrivals catch up afterwards (cpf_step_dev on the appended slice, same step0).
+ * More leavers than sendCapacity records: the split is ABORTED on the device -- *nStay = -1, counts[] still hold the
+ * records per destination (their sum is the capacity needed), and no particle is moved, marked or written: the shard
+ * is exactly as before the call, so the caller can enlarge sendbuf and call again (at any later step). */
 #define CPF_HANDOFF_DOUBLES 5
 int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                          int64_t n, const int32_t* cellLo_dev, int nRanks, int myRank, double* sendbuf,

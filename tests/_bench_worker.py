@@ -1,0 +1,111 @@
+"""Worker for tests/test_bench_contract.py: one rank of bench.run() on CPU over gloo.
+
+bench.py has no CPU path; this stand-in for its `GpuMachine` (numpy + the cell-walk oracle through tests/fake_ops.py,
+collectives over gloo) lets the N > 1 ORCHESTRATION of bench.run() -- seeding per slab, re-cut, overlapped hand-offs,
+max-over-ranks timing, the one JSON line -- run without a GPU.  The numbers it prints are meaningless as performance.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bench                                                                  # noqa: E402
+from fake_ops import FakeOps                                                  # noqa: E402
+from oracle import oracle as O                                                # noqa: E402
+
+
+class FakeCtx:
+    """The few context calls bench.run() makes besides the shard operations."""
+    def __init__(self, ops):
+        self.ops = ops
+
+    def set_option(self, key, value):
+        pass
+
+    def counters(self):
+        return {"particle_steps": 0, "cells_visited": 0, "reflections": 0, "lost": 0}
+
+    def timing_enable(self, on=True):
+        pass
+
+    def timing_read(self):
+        return self.ops.step_time(None, True)
+
+    def step_kernel_name(self, D=0.0, flags=0):
+        return "tests/fake_ops.py (CPU oracle stand-in)"
+
+    def close(self):
+        pass
+
+
+class CpuMachine:
+    collectives = "gloo all-to-all (CPU test double)"
+
+    def __init__(self, rank, world):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.device = torch.device("cpu")
+        self.cw = O.CellWalk()
+        self.ops = None
+        self.ctx = None
+
+    def set_case(self, mesh, U):
+        self.t = self.cw.build(mesh)
+        self.ops = FakeOps(self.cw, self.t, U)
+        self.ctx = FakeCtx(self.ops)
+
+    def make_ops(self):
+        return self.ops
+
+    def sync(self):
+        pass
+
+    def seed_in_fluid(self, n, box, seed, cell_range=None):
+        rng = np.random.default_rng(seed)
+        xs, cs, have = [], [], 0
+        while have < n:
+            m = int((n - have) * 1.5) + 256
+            p = rng.uniform(box[0], box[1], size=(m, 3))
+            c = self.cw.locate_initial(p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy(), self.t)
+            keep = c >= 0
+            if cell_range is not None:
+                keep &= (c >= cell_range[0]) & (c < cell_range[1])
+            xs.append(p[keep]); cs.append(c[keep]); have += int(keep.sum())
+        p = np.concatenate(xs)[:n]; c = np.concatenate(cs)[:n]
+        return (torch.from_numpy(p[:, 0].copy()), torch.from_numpy(p[:, 1].copy()), torch.from_numpy(p[:, 2].copy()),
+                torch.from_numpy(c.astype(np.int32)))
+
+    def prepare_cloud(self, cloud, args):
+        pass
+
+    def spinup(self, cloud, dt, ms):
+        return None
+
+    def comm_ms(self, events):
+        return 0.0
+
+    def extras(self, cloud, dt, args, box):
+        return None, None, None, None
+
+    def finish(self):
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = bench.parse(sys.argv[1:])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == args.gpus
+    out = bench.run(args, CpuMachine(rank, world))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

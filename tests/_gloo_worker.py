@@ -22,6 +22,7 @@ def main():
     capacity = int(sys.argv[6]) if len(sys.argv) > 6 else 0              # 0: room for the whole cloud on every rank
     slow_rank0 = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # > 0: balance by "measured" time, rank 0 that much slower
     u_step = int(sys.argv[7]) if len(sys.argv) > 7 else 0                # > 0: the velocity field changes after that many steps
+    send_fraction = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0    # small: the send buffer overflows and must grow
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -38,7 +39,7 @@ def main():
     mine = np.arange(rank, n_total, world)
     ops = FakeOps(cw, t, U, 2.0e-8 * (slow_rank0 if (slow_rank0 and rank == 0) else 1.0))
     cloud = ShardedCloud(ops, cell_lo, capacity or (n_total + 16), torch.device("cpu"), rank, world,
-                         send_fraction=1.0, exchange_interval=interval)
+                         send_fraction=send_fraction, exchange_interval=interval)
     cloud.set_particles(torch.from_numpy(xyz[mine, 0].copy()), torch.from_numpy(xyz[mine, 1].copy()),
                         torch.from_numpy(xyz[mine, 2].copy()), None, torch.from_numpy(mine.astype(np.int64)))
     cloud.exchange()
@@ -64,7 +65,7 @@ def main():
     owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
-             n_local=cloud.n, grown=cloud.grown, cell_lo=np.asarray(cell_lo))
+             n_local=cloud.n, grown=cloud.grown, send_grown=cloud.send_grown, cell_lo=np.asarray(cell_lo))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -59,6 +59,10 @@ class FakeOps:
             counts[r] = idx.size
             recs.append(np.stack([s.x[:n].numpy()[idx], s.y[:n].numpy()[idx], s.z[:n].numpy()[idx],
                                   cell[idx].astype(np.float64), s.gid[:n].numpy()[idx].astype(np.float64)], 1))
+        s.counts_dev[:] = torch.from_numpy(counts)
+        if int(counts.sum()) > s.send_capacity:                 # like the HIP split: aborted, nothing moved
+            s.nstay_dev[0] = -1
+            return
         flat = np.concatenate(recs).reshape(-1)
         s.sendbuf[: flat.size] = torch.from_numpy(flat)
         for a in (s.x, s.y, s.z, s.cell, s.gid):

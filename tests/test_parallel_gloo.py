@@ -61,6 +61,26 @@ def test_shard_grows_when_arrivals_exceed_its_slack(tmp_path, oracle_libs):
         assert np.array_equal(d["cell"], c[g])
 
 
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_send_buffer_overflow_grows_instead_of_dropping_or_hanging(overlap, tmp_path, oracle_libs):
+    """send_fraction 0.01: the first hand-offs find far more leavers than the send buffer holds (every rank starts with
+    an arbitrary slice of the cloud).  The split aborts without moving anything, EVERY rank sees that in the all-gathered
+    table, the overflowing ranks enlarge their buffers and split again, and the run gives the particles of one process
+    -- with the step loop running on in between (overlap 3) as well as synchronously."""
+    out = str(tmp_path / "ovf")
+    _run_workers(2, out, 2, 0, 0, overlap, 0, 0, 0.01)       # fixed ranges, hand-off every 2 steps
+    x, y, z, c = _single_process_answer(oracle_libs)
+    ds = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    assert sum(int(d["send_grown"]) for d in ds) >= 2 and sum(int(d["n_local"]) for d in ds) == 6000
+    seen = np.zeros(6000, bool)
+    for d in ds:
+        g = d["gid"]; seen[g] = True
+        assert int(d["total0"]) == 6000 and int(d["total1"]) == 6000
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g])
+    assert seen.all()
+
+
 def test_velocity_update_inside_a_handoff_window(tmp_path, oracle_libs):
     """A transient solver sets a new U between two step() calls while a hand-off is still in flight (4 overlapped
     steps): ShardedCloud.set_velocity completes the hand-off first, so the arrivals replay their missed cycles with
