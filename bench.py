@@ -132,6 +132,32 @@ def cpu_baseline(mesh, centres, U, seconds):
                        "particles, %.1f s" % (n, cycles, el))
 
 
+def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None, chunk=20_000_000):
+    """n points uniform in `box`, rejection-resampled until located in a cell (SURVEY.md 8d config 3);
+    with cell_range=(lo, hi) only points whose cell lies in [lo, hi) are kept (a rank seeding its own slab)."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    lo = torch.tensor(box[0], dtype=torch.float64, device=device)
+    ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
+    xs, ys, zs, cs = [], [], [], []
+    have = 0
+    while have < n:
+        m = min(int((n - have) * 1.35) + 1024, chunk)
+        u = torch.rand((3, m), generator=g, dtype=torch.float64, device=device)
+        x = (lo[0] + u[0] * ext[0]).contiguous(); y = (lo[1] + u[1] * ext[1]).contiguous()
+        z = (lo[2] + u[2] * ext[2]).contiguous()
+        del u
+        c = torch.empty(m, dtype=torch.int32, device=device)
+        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
+        torch.cuda.synchronize()
+        keep = c >= 0
+        if cell_range is not None:
+            keep &= (c >= cell_range[0]) & (c < cell_range[1])
+        xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
+        have += int(keep.sum())
+    cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
+    return cat(xs), cat(ys), cat(zs), cat(cs)
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks here as a CHILD process -- this process has
     not touched the GPU and never does -- the way the driver starts them for N > 1, forward rank 0's one JSON line as
@@ -202,31 +228,8 @@ class GpuMachine:
     def sync(self):
         self.torch.cuda.synchronize()
 
-    def seed_in_fluid(self, n, box, seed, cell_range=None, chunk=20_000_000):
-        """n points uniform in `box`, rejection-resampled until located in a cell (SURVEY.md 8d config 3);
-        with cell_range=(lo, hi) only points whose cell lies in [lo, hi) are kept (a rank seeding its own slab)."""
-        torch, device, ctx = self.torch, self.device, self.ctx
-        g = torch.Generator(device=device); g.manual_seed(seed)
-        lo = torch.tensor(box[0], dtype=torch.float64, device=device)
-        ext = torch.tensor(box[1], dtype=torch.float64, device=device) - lo
-        xs, ys, zs, cs = [], [], [], []
-        have = 0
-        while have < n:
-            m = min(int((n - have) * 1.35) + 1024, chunk)
-            u = torch.rand((3, m), generator=g, dtype=torch.float64, device=device)
-            x = (lo[0] + u[0] * ext[0]).contiguous(); y = (lo[1] + u[1] * ext[1]).contiguous()
-            z = (lo[2] + u[2] * ext[2]).contiguous()
-            del u
-            c = torch.empty(m, dtype=torch.int32, device=device)
-            ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), m)
-            torch.cuda.synchronize()
-            keep = c >= 0
-            if cell_range is not None:
-                keep &= (c >= cell_range[0]) & (c < cell_range[1])
-            xs.append(x[keep]); ys.append(y[keep]); zs.append(z[keep]); cs.append(c[keep])
-            have += int(keep.sum())
-        cat = lambda l: torch.cat(l)[:n].contiguous()   # noqa: E731
-        return cat(xs), cat(ys), cat(zs), cat(cs)
+    def seed_in_fluid(self, n, box, seed, cell_range=None):
+        return seed_in_fluid(self.ctx, self.torch, n, box, seed, self.device, cell_range)
 
     def prepare_cloud(self, cloud, args):
         from cudaparticlesfoam_amd import _lib as L

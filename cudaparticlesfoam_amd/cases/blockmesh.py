@@ -189,6 +189,7 @@ def block_mesh(vertices: np.ndarray, blocks: Sequence[Dict], scale: float = 1.0,
         cls = lambda fcen, own, slot: classify(fcen, own, slot, boc[own])  # noqa: E731
     mesh = hexes_to_polymesh(pts, new_id[H], cls, patch_names)
     mesh.block_of_cell = boc  # type: ignore[attr-defined]
+    mesh.hexes = new_id[H]    # type: ignore[attr-defined]   (nC, 8) corner ids in blockMesh order (cases/refine.py)
     return mesh
 
 

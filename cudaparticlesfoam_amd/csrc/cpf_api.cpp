@@ -115,6 +115,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.cellRec = c->d_cellRec;
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6) ? 1 : 0;
+    m.zPairLast = c->host.zPairLast ? 1 : 0;
     return m;
 }
 cpf::GridView gridView(const cpf_context* c) {
@@ -234,6 +235,12 @@ int cpf_create(int device, cpf_context** out) {
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         if (e == hipSuccess && cus > 0) ctx->streamState.numCU = cus;
     }
+    if (e == hipSuccess) {
+        // overflow area of the streaming kernel's per-wave pool of wall hit points: 1.5 KB per wave slot the chip can hold
+        ctx->streamState.hitSpillWaves = 32 * ctx->streamState.numCU;
+        e = hipMalloc((void**)&ctx->streamState.d_hitSpill,
+                      (size_t)ctx->streamState.hitSpillWaves * cpf::kStreamHitSpillDoubles * sizeof(double));
+    }
     if (e != hipSuccess) {
         std::string m = std::string("cpf_create: ") + hipGetErrorString(e);
         if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -251,7 +258,7 @@ int cpf_destroy(cpf_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     freeMesh(ctx); freeCloud(ctx);
-    freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab);
+    freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab); freeDev(ctx->streamState.d_hitSpill);
     freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);

@@ -20,6 +20,7 @@ struct MeshView {
     const double4* cellRec;   // [nCells][8] packed 256-B records (all-hex meshes only, else null)
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s)
+    int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
 };
 
 struct GridView {
@@ -32,8 +33,11 @@ struct GridView {
 // Host-side state of the streaming step kernel (cpf_stream.hip): two sets of per-group chunk counters (a launch
 // uses one and zeroes the other for the launch after it on the same stream) and the tuning knobs.
 constexpr size_t kStreamGrabBytes = 2 * 256 * 16 * sizeof(unsigned);
+constexpr int kStreamHitSpillDoubles = 3 * 64;          // x[64] | y[64] | z[64] per wave
 struct StreamState {
     unsigned* d_grab = nullptr;
+    double* d_hitSpill = nullptr;   // wall hit points that do not fit a wave's LDS pool: kStreamHitSpillDoubles per wave slot (cpf_stream.hip)
+    int hitSpillWaves = 0;          // wave slots d_hitSpill has room for (the launcher never starts more single-wave workgroups)
     int parity = 0;
     int numCU = 256;
     int tilesPerChunk = 4;    // "stream_tiles_per_chunk"

@@ -11,7 +11,7 @@ namespace cpf {
 // Host-built connectivity, laid out exactly as it is uploaded (DESIGN.md "Data layout in HBM").
 struct HostTables {
     int64_t nCells = 0, nSlots = 0;
-    std::vector<int32_t> cellOff;   // [nCells+1]   CSR offsets, slot order = mesh.cells()[c]
+    std::vector<int32_t> cellOff;   // [nCells+1]   CSR offsets, slot order = mesh.cells()[c] (z-layered meshes: z faces last, see zPairLast)
     std::vector<double> planes;     // [nSlots][4]  unit normal INTO the cell, d = n . faceCentre
     std::vector<int32_t> nbr;       // [nSlots]     neighbour cell, or -(face+1) on the boundary
     // uniform bin grid over the mesh bounding box for the initial locate
@@ -20,6 +20,7 @@ struct HostTables {
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
     int32_t maxCellFaces = 0, minCellFaces = 0;
+    bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes
     // from most to least significant (the longest domain axis first)

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;
                     }
-                    next = trace_lds6(S, E, cur, rec, token, outSlot);
+                    next = trace_lds6(S, E, cur, rec, token, outSlot, m.zPairLast != 0);
                 } else {
                     // no slot: more than kCoopSlots distinct cells in the wave (a cloud that is not kept sorted).
                     // Per-lane gathers keep such a wave moving; letting these lanes wait for a free slot instead

@@ -121,6 +121,40 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
+    // ---- z-layered meshes: the two z faces of every cell go LAST.  If every cell has exactly six faces of which exactly
+    // two have a normal along z EXACTLY (nx == 0 and ny == 0: the front/back faces of a 2-D case extruded in z -- both
+    // tutorials' pitzDaily -- and the layers of any mesh extruded along z), those two take slots 4 and 5, everything
+    // else keeps OpenFOAM's order.  A particle whose displacement has dz == 0 exactly (2-D flow without diffusion)
+    // has a denominator of exactly +-0 against such a face and can never leave through it (ConvexQuery.cu:86-95:
+    // dT = +-inf -> -1, or NaN); with the pair in a fixed place a wave of such particles drops both faces with ONE test
+    // instead of fetching both planes and evaluating two denominators (cpf_walk.h, trace_lds6).  The slot order is part
+    // of the walk's definition (ties in dT go to the lower slot), so oracle/cellwalk.c states the same rule.
+    out.zPairLast = out.minCellFaces == 6 && out.maxCellFaces == 6;
+    for (int64_t c = 0; c < nCells && out.zPairLast; ++c) {
+        int nz = 0;
+        for (int s = 0; s < 6; ++s) {
+            const double* pl = &out.planes[4 * ((size_t)out.cellOff[(size_t)c] + s)];
+            nz += (pl[0] == 0.0 && pl[1] == 0.0) ? 1 : 0;
+        }
+        if (nz != 2) out.zPairLast = false;
+    }
+    if (out.zPairLast) {
+        for (int64_t c = 0; c < nCells; ++c) {
+            const size_t s0 = (size_t)out.cellOff[(size_t)c];
+            double pl[6][4]; int32_t nb[6];
+            int k = 0;
+            for (int pass = 0; pass < 2; ++pass)               // stable: first the four others, then the two z faces
+                for (int s = 0; s < 6; ++s) {
+                    const double* q = &out.planes[4 * (s0 + s)];
+                    const bool isZ = q[0] == 0.0 && q[1] == 0.0;
+                    if (isZ != (pass == 1)) continue;
+                    std::memcpy(pl[k], q, sizeof(pl[k])); nb[k] = out.nbr[s0 + s]; ++k;
+                }
+            std::memcpy(&out.planes[4 * s0], pl, sizeof(pl));
+            std::memcpy(&out.nbr[s0], nb, sizeof(nb));
+        }
+    }
+
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)
     for (int k = 0; k < 3; ++k) { out.lo[k] = 1e300; out.hi[k] = -1e300; }
     for (int64_t p = 0; p < nPoints; ++p)

@@ -36,7 +36,7 @@ namespace cpf {
 #define CPF_STREAM_SLOTS 6
 #endif
 #ifndef CPF_STREAM_WAVES
-#define CPF_STREAM_WAVES 6
+#define CPF_STREAM_WAVES 7
 #endif
 constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
 constexpr int kSlotStride = 8;                          // double4 per slot = one 256-byte record, see `slots`
@@ -45,14 +45,35 @@ static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
 #define CPF_STREAM_GATHER_LANES 32
 #endif
 constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a record slot from which a round gathers (0: always)
+// two faces per wave-uniform decision on 3-D meshes (trace_lds6_paired): 4 more registers, i.e. a wave per SIMD less
+#ifndef CPF_STREAM_PAIRED
+#define CPF_STREAM_PAIRED 0
+#endif
+// Reflect inside the round (see the round's `again` loop): 0 never, 1 with the Brownian kick only, 2 always
+#ifndef CPF_STREAM_INROUND
+#define CPF_STREAM_INROUND 0
+#endif
+#ifndef CPF_STREAM_HIT_POOL
+#define CPF_STREAM_HIT_POOL 10
+#endif
 constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
+// The kernel's parameter list as the kernarg segment lays it out (each parameter at its natural alignment, in order):
+// kernarg_cloud_ptrs() / kernarg_pointer<>() read single arguments from there.  Checked against the launch in
+// launch_stream_inst (the arguments are passed in this order, nothing else).
+struct StreamKernArgs {
+    double *x, *y, *z; int32_t* cell; const int64_t* gid; double* vel; int64_t n; double dt, sigma; uint32_t step0; int nCyc;
+    uint32_t seed; MeshView m; unsigned long long* counters; StreamArgs sa;
+};
+static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
+constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
+
 template <bool BROWNIAN, bool STORE_VEL, bool STATS>
-struct StreamOccupancy { static constexpr int waves = (!BROWNIAN && !STORE_VEL && !STATS) ? CPF_STREAM_WAVES : 1; };
+struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? 6 : CPF_STREAM_WAVES); };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, bool LOOKUP_FIXED>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_stream(
-    double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, int32_t* __restrict__ cell,
+    double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,   // read through kernarg_cloud_ptrs()
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
     constexpr int NS = kStreamSlots;
@@ -63,26 +84,49 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     // CU, and with 5 padded slots instead of 6 -- same LDS as now -- the extra misses cost more than the conflicts.)
     __shared__ double4 slots[NS][kSlotStride];
     __shared__ unsigned sCnt[4];
-    __shared__ double sLane[6][64];                  // per-lane end point E and last wall hit point (see step_kernel_coop)
+    // Per-lane end point E, parked between rounds (see step_kernel_coop) -- the slot also carries the three Brownian
+    // deviates from the first round of a cycle to the lane's advect, and the previous tile's position from the tile's end
+    // to the next tile's hook -- and the LAST WALL HIT POINT of the lanes that were reflected in the current cycle.  Only
+    // the ~1 % of particle-steps that meet a wall need a hit point (5-10 % with the tutorial's diffusion on the 1 mm slab),
+    // so a wave has a small POOL instead of 64 x 24 bytes: a lane takes an entry at its first reflection of the cycle (LDS
+    // counter), and entries beyond the pool go to the wave's own 1.5 KB of global memory (sa.hitSpill) -- 1.3 KB of LDS
+    // less per wave, which is what a 7th wave per SIMD needs (160 KB / 28 waves = 5851 B; 8 waves: 5120 B).
+    constexpr bool HIT_POOL = true;
+    constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
+    constexpr int kPool = CPF_STREAM_HIT_POOL;
+    __shared__ double sLane[3][64];
+    __shared__ double sPool[3][kPool];
+    __shared__ unsigned sPoolUsed;
     // landing zone of the next tile: x[64] | y[64] | z[64] | cell[64] (int32) | gid[64] (Brownian only)
     __shared__ double sPre[BROWNIAN ? 288 : 224];
     double(*sE)[64] = sLane;
-    double(*sHit)[64] = sLane + 3;
     const int lane = threadIdx.x;
     const unsigned ul = threadIdx.x;                 // unsigned lane index: scalar base + 32-bit lane offset addressing
     const unsigned preBase = uniform32(lds_addr(sPre));
     const unsigned slotBase = uniform32(lds_addr(slots));
     const int tpc = sa.tilesPerChunk;
-    const int64_t nTiles = (n + 63) >> 6;
-    const unsigned long long big = sa.bigChunks;
+    const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
+    // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
+    // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
+    // (a group's counter keeps counting) saturate instead of wrapping.
+    const unsigned nTiles = (unsigned)((n + 63) >> 6);
+    const unsigned nFull = (unsigned)(n >> 6), nTail = (unsigned)n & 63u;     // full tiles, particles in the last, partial one
+    const unsigned big = sa.bigChunks;
+    const unsigned nChunks = big + (nTiles - big * (unsigned)tpc);
     // first tile of chunk c, and how many of its tiles exist (0: the chunk lies past the end of the cloud)
-    auto chunk_first = [&](unsigned long long c) -> int64_t {
-        return c < big ? (int64_t)c * tpc : (int64_t)big * tpc + (int64_t)(c - big);
+    auto chunk_first = [&](unsigned c) -> unsigned {
+        return c < big ? c * (unsigned)tpc : big * (unsigned)tpc + (c - big);
     };
-    auto chunk_tiles = [&](unsigned long long c, int64_t firstTile) -> int {
-        const int64_t k = nTiles - firstTile;
-        const int64_t want = c < big ? (int64_t)tpc : (int64_t)1;
-        return (int)(k < 0 ? 0 : (k < want ? k : want));
+    auto chunk_tiles = [&](unsigned c, unsigned firstTile) -> int {
+        if (c >= nChunks) return 0;
+        const unsigned k = nTiles - firstTile;
+        const unsigned want = c < big ? (unsigned)tpc : 1u;
+        return (int)(k < want ? k : want);
+    };
+    // chunk j of the group (j = what the group's counter returns) is chunk grp + G*j of the cloud
+    auto chunk_of = [&](unsigned j) -> unsigned {
+        const unsigned long long c = (unsigned long long)(blockIdx.x & (kStreamGroups - 1)) + (unsigned long long)kStreamGroups * j;
+        return c < (unsigned long long)nChunks ? (unsigned)c : nChunks;
     };
     StepStats st = {0, 0, 0, 0};
 #ifdef CPF_STREAM_TIMELINE
@@ -101,10 +145,15 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 
     // Requests tile t: full tiles by LDS-DMA (returns the number of memory operations issued), the cloud's last,
     // partial tile by ordinary masked loads (complete when the function returns: 0).
-    auto prefetch = [&](int64_t t) __attribute__((always_inline)) -> int {
-        const int64_t b = uniform64(t * 64);
-        const int64_t left = n - b;
-        if (left >= 64) {
+    auto prefetch = [&](unsigned t, const CloudPtrs& cp) __attribute__((always_inline)) -> int {
+        double* const x = cp.x; double* const y = cp.y; double* const z = cp.z; int32_t* const cell = cp.cell;
+        t = uniform32(t);
+        const int64_t b = (int64_t)t * 64;
+        // (the lane number through an opaque copy: the per-lane source offsets below are then recomputed per tile -- three
+        // vector instructions -- instead of being hoisted out of the tile loop into registers that live for the whole kernel)
+        unsigned ul = threadIdx.x;
+        asm volatile("" : "+v"(ul));
+        if (t < nFull) {
             const char* s1 = (ul < 32u ? reinterpret_cast<const char*>(x + b) : reinterpret_cast<const char*>(y + b)) + (ul & 31u) * 16u;
             glds16(s1, preBase);                                               // x -> [0, 512), y -> [512, 1024)
             if (ul < 48u) {
@@ -118,7 +167,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
             }
             return 2;
         }
-        const unsigned lim = (unsigned)(left - 1);
+        const unsigned lim = nTail - 1u;
         const unsigned l = ul < lim ? ul : lim;
         const double vx = (x + b)[l], vy = (y + b)[l], vz = (z + b)[l];
         const int vc = (cell + b)[l];
@@ -128,54 +177,58 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
         return 0;
     };
 
-    // chunk j of the group (j = what the group's counter returns) is chunk grp + G*j of the cloud
     unsigned got0 = 0;
     if (lane == 0) got0 = grab_sync(myGrab);
-    const unsigned long long chunk0 = (unsigned long long)grp + (unsigned long long)kStreamGroups * uniform32(got0);
+    const unsigned chunk0 = chunk_of(uniform32(got0));
     if (chunk_tiles(chunk0, chunk_first(chunk0)) > 0) {
         // tags of the record cache: lane k holds the cell id whose record sits in slot k (-1: none)
         int tagv = -1;
         unsigned fifo = 0;
 
-        int64_t tile = chunk_first(chunk0);
+        unsigned tile = chunk_first(chunk0);
         int tilesLeft = chunk_tiles(chunk0, tile);
-        (void)prefetch(tile);
+        (void)prefetch(tile, kernarg_cloud_ptrs());
         wait_vmcnt<0>();
 
-        // results of the previous tile, stored one tile late
+        // results of the previous tile, stored one tile late.  Its positions wait in the lanes' parked-E slots (sE): a
+        // slot is free from the end of a tile's last cycle to the next tile's advect, and every round begins by reading
+        // it anyway (Epre) -- six registers that are not live across the walk.
         bool havePrev = false;
-        int64_t rtile = 0;
-        double rx = 0, ry = 0, rz = 0, rvx = 0, rvy = 0, rvz = 0;
+        unsigned rtile = 0;
+        double rvx = 0, rvy = 0, rvz = 0;
         int rc = 0;
-        bool rhad = false;
         unsigned rlim = 63;
 
         for (;;) {
-            tile = uniform64(tile);
+            tile = uniform32(tile);
             // ---- take the tile out of the landing zone
-            const int64_t tileLeft = n - tile * 64;
-            const unsigned plim = (unsigned)(tileLeft < 64 ? tileLeft : (int64_t)64) - 1u;   // last lane with a particle slot
+            const unsigned plim = tile < nFull ? 63u : nTail - 1u;      // last lane with a particle slot
             double px = sPre[ul], py = sPre[64 + ul], pz = sPre[128 + ul];
             int pc = reinterpret_cast<const int*>(sPre + 192)[ul];
             uint64_t pid = 0;
-            if (BROWNIAN) pid = gid ? (uint64_t) reinterpret_cast<const int64_t*>(sPre + 224)[ul] : (uint64_t)(tile * 64 + ul);
-            if (ul > plim) pc = CPF_CELL_FROZEN;
+            if (BROWNIAN) pid = gid ? (uint64_t) reinterpret_cast<const int64_t*>(sPre + 224)[ul] : (uint64_t)tile * 64 + ul;
+            // no particle in this lane (beyond the cloud's end, frozen, or lost in an earlier step: w = 0 from now on,
+            // cuda/particles.cu:333-338): CPF_CELL_FROZEN, and the lane stores back what it loaded.  Which lanes carry a
+            // particle is read off `cur` wherever it is needed (cur >= 0) instead of being kept in wave masks: scalar
+            // registers are what this kernel is shortest of.
+            if (ul > plim || pc < 0) pc = CPF_CELL_FROZEN;
 
             int cur = pc;
-            const bool hadParticle = cur >= 0;
-            bool valid = hadParticle;
-            D3 P = {px, py, pz}, v = {0, 0, 0};
+            // the particle's position IS the walk's running start point S_: between two cycles (and for a lane without an
+            // active particle, always) S_ holds the position; a cycle's walk advances it from crossing to crossing and the
+            // move at the cycle's end overwrites it (one register triple, not two)
+            D3 S_ = {px, py, pz}, v = {0, 0, 0};
             const uint64_t id = pid;
 
             // where the wave goes next
-            int64_t ntile = -1;
-            int ntilesLeft = 0;
+            unsigned ntile = 0;
+            int ntilesLeft = 0;                      // 0: this was the wave's last tile
 
             // Once per tile, right after round 1's missing records have been REQUESTED: the next chunk if this is the
             // chunk's last tile, the previous tile's stores, the next tile's loads.  Returns how many of these
             // operations are certainly younger than the record requests: s_waitcnt vmcnt(that many) then lets
             // exactly the records complete.
-            auto hook = [&]() __attribute__((always_inline)) -> int {
+            auto hook = [&](const D3& prev) __attribute__((always_inline)) -> int {
                 int younger = 0;
                 __builtin_amdgcn_sched_barrier(0);
                 if (tilesLeft > 1) {
@@ -184,47 +237,57 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                 } else {
                     unsigned got = 0;
                     if (lane == 0) got = grab_sync(myGrab);
-                    const unsigned j = uniform32(got);
-                    const unsigned long long nxt = (unsigned long long)grp + (unsigned long long)kStreamGroups * j;
-                    const int64_t ft = chunk_first(nxt);
-                    const int nt = chunk_tiles(nxt, ft);
-                    if (nt > 0) { ntile = ft; ntilesLeft = nt; }
+                    const unsigned nxt = chunk_of(uniform32(got));
+                    ntile = chunk_first(nxt);
+                    ntilesLeft = chunk_tiles(nxt, ntile);
                 }
+                const CloudPtrs cp = kernarg_cloud_ptrs();
+                double* const x = cp.x; double* const y = cp.y; double* const z = cp.z; int32_t* const cell = cp.cell;
                 if (havePrev && !(sa.debug & 1)) {
-                    const int64_t b = uniform64(rtile * 64);
-                    if (STORE_VEL && rhad) {
+                    const int64_t b = (int64_t)uniform32(rtile) * 64;
+                    if (STORE_VEL && rc != CPF_CELL_FROZEN) {
                         double* vv = vel + 3 * b;
                         async_store(vv, ul * 24u, rvx); async_store(vv + 1, ul * 24u, rvy); async_store(vv + 2, ul * 24u, rvz);
                     }
                     if (ul <= rlim) {
-                        async_store(x + b, ul * 8u, rx); async_store(y + b, ul * 8u, ry); async_store(z + b, ul * 8u, rz);
+                        async_store(x + b, ul * 8u, prev.x); async_store(y + b, ul * 8u, prev.y); async_store(z + b, ul * 8u, prev.z);
                         async_store(cell + b, ul * 4u, rc);
                     }
                     younger += 4;
                 }
-                if (ntile >= 0 && !(sa.debug & 2)) younger += prefetch(ntile);
+                if (ntilesLeft > 0 && !(sa.debug & 2)) younger += prefetch(ntile, cp);
                 __builtin_amdgcn_sched_barrier(0);
                 return younger;
             };
 
-            // ---- per-cycle walk state (step_kernel_coop's state machine)
-            bool busy = false, needAdvect = false, reflected = false, lostNow = false;
+            // ---- per-cycle walk state (step_kernel_coop's state machine).  Only `busy` is a wave mask; the others are
+            // read off the lane's own registers: a lane has yet to advect while its token is still INT32_MIN (no face
+            // crossed or hit in this cycle), it has been reflected iff j != 0, and it is lost in this cycle iff
+            // j >= kMaxReflect (still on a wall after 5 bounces; a wall without reflection sets j = kMaxReflect too).
+            bool busy = false;
             int token = INT32_MIN, h = 0, j = 0;
-            D3 S_ = P;
-
-            auto cycle_begin = [&](int c) __attribute__((always_inline)) {
-                if (valid && cur < 0) { cur = CPF_CELL_FROZEN; valid = false; }      // lost in the previous cycle: w = 0
-                busy = valid; needAdvect = busy; reflected = false; lostNow = false;
-                token = INT32_MIN; h = 0; j = 0;
-                S_ = P;
-                if (STATS && busy) ++st.steps;
-                if (BROWNIAN && busy) {                                              // see step_kernel_coop
-                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
-                    sHit[0][lane] = xi.x; sHit[1][lane] = xi.y; sHit[2][lane] = xi.z;
+            int hitAt = -1;                          // HIT_POOL: where this lane's hit point is parked (< kPool: pool entry)
+            // parks the wall hit point of a lane that is being reflected (it is read back once, by the move at cycle end)
+            auto park_hit = [&](const D3& Hp) __attribute__((always_inline)) {
+                if (HIT_POOL) {
+                    if (hitAt < 0) hitAt = (int)atomicAdd(&sPoolUsed, 1u);          // first reflection of the cycle
+                    if (hitAt < kPool) { sPool[0][hitAt] = Hp.x; sPool[1][hitAt] = Hp.y; sPool[2][hitAt] = Hp.z; }
+                    else {
+                        double* sp = static_cast<double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles;
+                        async_store(sp, ul * 8u, Hp.x); async_store(sp + 64, ul * 8u, Hp.y); async_store(sp + 128, ul * 8u, Hp.z);
+                    }
                 }
             };
 
-            auto round = [&](auto withHook) __attribute__((always_inline)) {
+            auto cycle_begin = [&](int c) __attribute__((always_inline)) {
+                if (cur < 0) cur = CPF_CELL_FROZEN;                                  // lost in the previous cycle: w = 0
+                busy = cur >= 0;
+                token = INT32_MIN; h = 0; j = 0;
+                if (HIT_POOL && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
+                if (STATS && busy) ++st.steps;
+            };
+
+            auto round = [&](bool hookDue, bool cycleStart, int c) __attribute__((always_inline)) {
 #ifdef CPF_STREAM_TIMELINE
                 ++tlRounds;
 #endif
@@ -312,7 +375,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 #undef CPF_JOB
                 }
                 int younger = 0;
-                if (decltype(withHook)::value) younger = hook();
+                if (hookDue) younger = hook(Epre);                            // (the tile's first round: Epre is the PREVIOUS tile's result)
+                if (BROWNIAN && cycleStart && busy) {
+                    // Philox + Box-Muller for the cycle, HERE: behind the hook (the parked result it stores has left the
+                    // E slot) and behind the record requests (the deviates overlap their round trip), with almost nothing
+                    // of the walk live.  They wait in the lane's E slot -- not needed before the advect, which consumes them.
+                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+                    sE[0][lane] = xi.x; sE[1][lane] = xi.y; sE[2][lane] = xi.z;
+                }
 #ifdef CPF_STREAM_TIMELINE
                 const uint64_t tlw0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -337,6 +407,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane = {0, 0, 0, 0};
+                    const bool needAdvect = token == INT32_MIN;
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
                     if (myslot >= 0) {
@@ -344,23 +415,54 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                         if (needAdvect) {
                             const double4 u = rec[6];
                             v = {u.x, u.y, u.z};
-                            const D3 Pn = axpy(dt, v, P);                              // particles.cu:355-362
-                            D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
-                            if (BROWNIAN) {                                            // the deviates drawn in cycle_begin
-                                const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                            const D3 Pn = axpy(dt, v, S_);                             // particles.cu:355-362
+                            D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};   // not yet walked in this cycle: S_ is the position
+                            if (BROWNIAN) {                                            // the deviates drawn in the cycle's first round
+                                const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
                                 disp = axpy(sigma, xi, disp);
                             }
-                            E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                            E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                             sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                            needAdvect = false;
                         }
-                        // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h; measured
-                        // 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for zero denominators)
-                        next = (LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot)
-                                                            : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
-                        // the wall's plane is read HERE, where the record's address space is known: one expression
-                        // choosing between the LDS slot and the global record becomes a flat load (vmcnt + lgkmcnt 0)
-                        if (REFLECT && next < 0) wallPlane = rec[outSlot];
+                        // ---- the visit, and -- in the same round -- the visits after a wall.  A wall hit never changes the
+                        // cell and its record is in the slot already, so a lane that hits a wall mirrors its end point and
+                        // walks on at once (the j < 5 loop of ConvexQuery.cu:353-409, which re-walks in the same `cur`)
+                        // instead of sending the whole wave through another round -- lookup, ballots, hook logic -- for
+                        // it.  ONE instance of the face tests inside a per-lane loop: from its second trip on only the
+                        // reflecting lanes are active and most faces drop out wave-uniformly.  Same arithmetic in the same
+                        // order as a round per reflection: bit-identical.
+                        bool again;
+                        do {
+                            again = false;
+                            // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
+                            // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
+                            // zero denominators)
+                            next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
+                                                                : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot, zLast);
+                            if (STATS) ++st.hops;
+                            if (REFLECT && next < 0) {
+                                // mirror end point and velocity about the wall (ConvexQuery.cu:286-309).  The wall's plane
+                                // is read HERE, where the record's address space is known (one expression choosing between
+                                // the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0), and E comes
+                                // from its parking slot -- it is there, from this round's advect or an earlier round -- so
+                                // that it need not stay in registers across the face tests.
+                                const double4 wallPlane = rec[outSlot];
+                                asm volatile("" ::: "memory");
+                                E = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                                park_hit(S_);
+                                if (STATS) ++st.refl;
+                                const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
+                                const double sd = dot3(wallPlane, E) - wallPlane.w;
+                                E = axpy(-2.0 * sd, nn, E);
+                                sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                                v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
+                                token = next;
+                                h = 0;
+                                if (++j == kMaxReflect) { busy = false; next = cur; }   // still on a wall after 5 bounces: lost
+                                else if (kInRound) again = true;
+                                else next = kSitOut;                                    // walks on in the next round
+                            }
+                        } while (again);
                     } else {
                         // no slot: more distinct new cells in the wave than the round can place (a cloud that is not
                         // kept sorted).  Per-lane gathers keep such a wave moving.
@@ -370,17 +472,17 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                             if (needAdvect) {
                                 const double4 u = rec[6];
                                 v = {u.x, u.y, u.z};
-                                const D3 Pn = axpy(dt, v, P);
-                                D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
+                                const D3 Pn = axpy(dt, v, S_);
+                                D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};   // not yet walked in this cycle: S_ is the position
                                 if (BROWNIAN) {
-                                    const D3 xi = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
+                                    const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
                                     disp = axpy(sigma, xi, disp);
                                 }
-                                E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                                E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                                 sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                                needAdvect = false;
                             }
                             next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                            if (STATS) ++st.hops;
                             // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
                             // at the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
                             if (REFLECT && next < 0) {
@@ -389,16 +491,15 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                             }
                         }
                     }
-                    if (STATS && next != kSitOut) ++st.hops;
                     if (next == cur) {
                         busy = false;                                              // segment ends in this cell
-                    } else if (next < 0) {                                         // boundary face, or sitting this round out
+                    } else if (next < 0) {                                         // sitting this round out, or a boundary face met on the gather path
                         if (next == kSitOut) {
-                        } else if (!REFLECT) { busy = false; lostNow = true; }
+                        } else if (!REFLECT) { busy = false; j = kMaxReflect; token = next; }     // lost (token: the advect is done)
                         else {
-                            // mirror end point and velocity about the wall (ConvexQuery.cu:286-309)
-                            sHit[0][lane] = S_.x; sHit[1][lane] = S_.y; sHit[2][lane] = S_.z;
-                            reflected = true; if (STATS) ++st.refl;
+                            // mirror end point and velocity about the wall (ConvexQuery.cu:286-309); walks on next round
+                            park_hit(S_);
+                            if (STATS) ++st.refl;
                             const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
                             const double sd = dot3(wallPlane, E) - wallPlane.w;
                             E = axpy(-2.0 * sd, nn, E);
@@ -406,7 +507,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                             v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
                             token = next;
                             h = 0;
-                            if (++j == kMaxReflect) { busy = false; lostNow = true; }  // still on a wall after 5 bounces
+                            if (++j == kMaxReflect) busy = false;                      // still on a wall after 5 bounces: lost
                         }
                     } else {
                         token = cur;
@@ -418,28 +519,35 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 
             auto cycle_end = [&]() __attribute__((always_inline)) {
                 // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit; else P + disp == E
-                if (valid) {
+                if (cur >= 0) {                              // every lane that began the cycle with a particle
                     const D3 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
-                    if (reflected) {
-                        const D3 hit = {sHit[0][lane], sHit[1][lane], sHit[2][lane]};
-                        P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
-                    } else P = E;
-                    if (lostNow) { cur = CPF_CELL_LOST; if (STATS) ++st.lost; }
+                    if (REFLECT && j != 0) {                 // reflected at least once
+                        D3 hit;
+                        if (HIT_POOL) {
+                            if (hitAt < kPool) hit = {sPool[0][hitAt], sPool[1][hitAt], sPool[2][hitAt]};
+                            else load3_sync(static_cast<const double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles,
+                                            ul * 8u, hit.x, hit.y, hit.z);
+                        }
+                        S_ = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
+                    } else S_ = E;
+                    if (j >= kMaxReflect) { cur = CPF_CELL_LOST; if (STATS) ++st.lost; }
                 }
             };
 
             if (nCyc > 0) {
-                cycle_begin(0);
-                round(std::true_type{});                    // always runs (it carries the hook), even with no busy lane
-                while (ballot64(busy) != 0ull) round(std::false_type{});
-                cycle_end();
-                for (int c = 1; c < nCyc; ++c) {
+                // ONE instance of the round in the kernel's code: the tile's first round carries the hook behind a
+                // wave-uniform flag (three inlined copies -- hook round, other rounds of the first cycle, rounds of the later
+                // cycles of a fused launch -- were 3 x 1400 instructions and a dozen register shuffles at every loop edge).
+                // A cycle's first round always runs, even with no busy lane (cycle 0's carries the hook).
+                for (int c = 0; c < nCyc; ++c) {
                     cycle_begin(c);
-                    while (ballot64(busy) != 0ull) round(std::false_type{});
+                    bool hookDue = c == 0, cycleStart = true;
+                    do { round(hookDue, cycleStart, c); hookDue = false; cycleStart = false; } while (ballot64(busy) != 0ull);
                     cycle_end();
                 }
             } else {
-                (void)hook();                                // zero cycles: loads + stores only (bandwidth calibration)
+                const D3 prev = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                (void)hook(prev);                            // zero cycles: loads + stores only (bandwidth calibration)
             }
 
             // everything this tile's hook issued has landed (the next tile in LDS) or been accepted (the stores)
@@ -455,19 +563,21 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
             // x, y, z and the cell: a frozen or lost particle gets the bytes it was loaded with (and CPF_CELL_FROZEN),
             // which keeps the NUMBER of stores per tile fixed -- the counted wait above needs it
             rtile = tile; havePrev = true;
-            rx = P.x; ry = P.y; rz = P.z;
+            sE[0][lane] = S_.x; sE[1][lane] = S_.y; sE[2][lane] = S_.z;
             if (STORE_VEL) { rvx = v.x; rvy = v.y; rvz = v.z; }
-            rc = hadParticle ? cur : CPF_CELL_FROZEN;
-            rhad = hadParticle;
+            rc = cur;
             rlim = plim;
-            if (ntile < 0) break;
+            if (ntilesLeft <= 0) break;
             tile = ntile; tilesLeft = ntilesLeft;
         }
         // ---- the last tile's results
         {
-            const int64_t b = rtile * 64;
+            const int64_t b = (int64_t)rtile * 64;
+            const CloudPtrs cp = kernarg_cloud_ptrs();
+            double* const x = cp.x; double* const y = cp.y; double* const z = cp.z; int32_t* const cell = cp.cell;
+            const double rx = sE[0][lane], ry = sE[1][lane], rz = sE[2][lane];
             if (ul <= rlim) { (x + b)[ul] = rx; (y + b)[ul] = ry; (z + b)[ul] = rz; (cell + b)[ul] = rc; }
-            if (STORE_VEL && rhad) {
+            if (STORE_VEL && rc != CPF_CELL_FROZEN) {
                 double* vv = vel + 3 * b;
                 vv[3 * ul] = rvx; vv[3 * ul + 1] = rvy; vv[3 * ul + 2] = rvz;
             }
@@ -498,6 +608,7 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
         wavesPerCU = nb < 1 ? 1 : (nb > 32 ? 32 : nb);
     }
     const int64_t nTiles = (n + 63) >> 6;
+    if (nTiles >= ((int64_t)1 << 31)) return hipErrorInvalidValue;      // the kernel numbers tiles and chunks in 32 bits
     const int64_t slotsOnChip = (int64_t)(ss.wavesPerCU > 0 ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
     // small clouds: shorter chunks, so that every wave slot still gets several
     int tpc = ss.tilesPerChunk;
@@ -512,7 +623,9 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     if (R < 1) R = 1;
     unsigned* cur = ss.d_grab + (size_t)(ss.parity & 1) * kStreamGroups * kStreamCounterStride;
     unsigned* nxt = ss.d_grab + (size_t)((ss.parity & 1) ^ 1) * kStreamGroups * kStreamCounterStride;
-    StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug};
+    if (R * kStreamGroups > ss.hitSpillWaves) R = ss.hitSpillWaves / kStreamGroups;      // (never: the area is sized for the chip)
+    if (R < 1 || ss.d_hitSpill == nullptr) return hipErrorInvalidValue;
+    StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug, ss.d_hitSpill};
     hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
                        gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
     return stream_launch_done(st, ss);

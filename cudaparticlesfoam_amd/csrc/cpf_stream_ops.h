@@ -46,6 +46,34 @@ __device__ __forceinline__ unsigned grab_sync(unsigned* base) {
     asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(0u), "v"(1u), "s"(base) : "memory");
     return r;
 }
+// three doubles at base + byteOff, + 512, + 1024 bytes, straight from L2, complete when the statement ends -- and everything
+// this wave stored before it has been written back first (the values were stored by this very lane a few rounds ago)
+__device__ __forceinline__ void load3_sync(const double* base, unsigned byteOff, double& a, double& b, double& c) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 4\n\tglobal_load_dwordx2 %0, %3, %4 sc0 sc1\n\tglobal_load_dwordx2 %1, %3, %4 offset:512 sc0 sc1\n\t"
+                 "global_load_dwordx2 %2, %3, %4 offset:1024 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(byteOff), "s"(base) : "memory");
+}
+// Kernel arguments that are needed once per tile (or less) are read from the kernarg segment WHERE they are needed
+// instead of sitting in scalar registers for the whole kernel: the streaming kernel's occupancy is bounded by its
+// scalar registers (800 per SIMD: <= 96 per wave for 7 waves, <= 80 for 8; MI355X_MICROARCH.md "Residency"), and four
+// array pointers are 8 of them.  A scalar load that hits the constant cache costs a wave ~100 cycles once per tile.
+// (lgkmcnt(0) also retires the wave's pending LDS reads; the callers need those next anyway.)
+struct CloudPtrs { double* x; double* y; double* z; int32_t* cell; };
+__device__ __forceinline__ CloudPtrs kernarg_cloud_ptrs() {          // the kernel's first four parameters: bytes 0..31
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    u32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
+    auto ptr = [](unsigned lo, unsigned hi) { return (uintptr_t)(((unsigned long long)hi << 32) | lo); };
+    return {reinterpret_cast<double*>(ptr(r[0], r[1])), reinterpret_cast<double*>(ptr(r[2], r[3])),
+            reinterpret_cast<double*>(ptr(r[4], r[5])), reinterpret_cast<int32_t*>(ptr(r[6], r[7]))};
+}
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void* kernarg_pointer() {                  // one 8-byte pointer argument at a fixed offset
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(BYTE_OFFSET) : "memory");
+    return reinterpret_cast<void*>((uintptr_t)(((unsigned long long)r[1] << 32) | r[0]));
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
@@ -74,6 +102,7 @@ struct StreamArgs {
                            // of the launch is dealt in small pieces, so that all waves finish within a tile's time of
                            // each other (measured with 4-tile chunks throughout: the last wave 20 us after the median)
     int debug;             // diagnostics only (results are wrong): 1 = no stores, 2 = no loads after a wave's first tile
+    double* hitSpill;      // kStreamHitSpillDoubles per workgroup: wall hit points beyond the wave's LDS pool
 };
 
 // After a streaming launch: the launch zeroed the OTHER counter set for its successor, so the sets swap roles -- but only

@@ -145,8 +145,13 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
 // chain per pair.  Measured at steady clocks: 1-2 % on the 3-D meshes (no face is skipped there before its offset is
 // needed), nothing either way on pitzDaily.
 #define CPF_PIN_W(a, b) asm volatile("" : "+v"(a.w), "+v"(b.w));
+// zLast (wave-uniform; MeshView::zPairLast): slots 4 and 5 are the cell's two faces with an exactly z-parallel normal.
+// When no active lane moves in z (Pd.z == +-0 exactly: 2-D flow on a z-extruded mesh, no diffusion) both denominators
+// are exactly +-0 for every lane -- nx == ny == 0 leaves den = nz * 0 -- so neither face can be accepted
+// (ConvexQuery.cu:86-95) and ONE test replaces two plane fetches, two denominators and two votes.  Exact, not
+// approximate: it is the zero-denominator skip of face_test, decided for the pair up front.
 template <bool ZERO_SKIP = true>
-__device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+__device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot, bool zLast = false) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
@@ -166,7 +171,7 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
         face_test<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
         face_test<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
-    {
+    if (!(zLast && ballot64(Pd.z != 0.0) == 0ull)) {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
         CPF_PIN_W(p4, p5)
@@ -205,7 +210,7 @@ __device__ __forceinline__ void face_pair_test(const double4& pa, const double4&
         if (mB != 0ull) face_accept(denB, fdB, b.y, token, s + 1, dTmin, next, best);
     }
 }
-__device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+__device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot, bool zLast = false) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
@@ -213,7 +218,9 @@ __device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, co
     const int2* nb = reinterpret_cast<const int2*>(rec + 7);
     { const double4 p0 = rec[0], p1 = rec[1]; face_pair_test(p0, p1, nb[0], P0, Pd, token, 0, dTmin, next, best); }
     { const double4 p2 = rec[2], p3 = rec[3]; face_pair_test(p2, p3, nb[1], P0, Pd, token, 2, dTmin, next, best); }
-    { const double4 p4 = rec[4], p5 = rec[5]; face_pair_test(p4, p5, nb[2], P0, Pd, token, 4, dTmin, next, best); }
+    if (!(zLast && ballot64(Pd.z != 0.0) == 0ull)) {          // see trace_lds6
+        const double4 p4 = rec[4], p5 = rec[5]; face_pair_test(p4, p5, nb[2], P0, Pd, token, 4, dTmin, next, best);
+    }
     if (best >= 0) {
         S = axpy(dTmin, Pd, P0);
         outSlot = best;
@@ -256,22 +263,28 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-// Three N(0,1) deviates for (particle gid, step) from ONE Philox block (definition 2 of the transform; parity with the
-// reference's cuRAND stream is statistical by contract, SURVEY.md 8c, so the arithmetic is free): Box-Muller on
-// 23-bit uniforms u = ((w >> 9) + 0.5) * 2^-23 in (0, 1), evaluated with the fp32 hardware transcendentals
-// (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32, whose argument is in revolutions: no 2*pi, no range reduction) --
-// words 0,1 give two deviates (one log, one sqrt), words 2,3 the third.  The fp64 version this replaces (two log, two
-// sqrt, sincospi + cospi in double) was a third of the Brownian kernel's time and cost it its occupancy; the
-// kick itself, disp += sigma * xi, stays an fp64 fma.  oracle/cellwalk.c states the same transform with libm.
+// Three N(0,1) deviates for (particle gid, step) from ONE Philox block (parity with the reference's cuRAND stream is
+// statistical by contract, SURVEY.md 8c, so the arithmetic is free): Box-Muller evaluated with the fp32 hardware
+// transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32, whose argument is in revolutions: no 2*pi, no range
+// reduction) -- words 0,1 give two deviates (one log, one sqrt), words 2,3 the third.  The radius uniform uses ALL 32
+// bits of its word, u = (w + 0.5) * 2^-32: log2 u = log2(mantissa) + (exponent - 32) of x = float(w) + 0.5, so the tail
+// reaches sqrt(2 * 33 * ln 2) = 6.76 sigma (round 2's 23-bit uniforms stopped at 5.77) and the result keeps its relative
+// precision near u = 1; the angle uniform is 23-bit, ((w >> 9) + 0.5) * 2^-23.  The fp64 version this replaces (two
+// log, two sqrt, sincospi + cospi in double) was a third of the Brownian kernel's time and cost it its occupancy; the
+// kick itself, disp += sigma * xi, stays an fp64 fma.  oracle/cellwalk.c (cw_normal3_words) states the same transform
+// with libm; what still differs from curand_normal_double is listed there.
+__device__ __forceinline__ float log2_radius_uniform(uint32_t w) {
+    const float x = (float)w + 0.5f;
+    return __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(x)) + (float)(__builtin_amdgcn_frexp_expf(x) - 32);
+}
 __device__ __forceinline__ D3 normal3(uint64_t gid, uint32_t step, uint32_t seed) {
     uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0u};
     philox4x32_10(c, seed, 0x43504631u);
     const float s = 1.0f / 8388608.0f;                                    // 2^-23
-    const float u0 = ((float)(c[0] >> 9) + 0.5f) * s, u1 = ((float)(c[1] >> 9) + 0.5f) * s;
-    const float u2 = ((float)(c[2] >> 9) + 0.5f) * s, u3 = ((float)(c[3] >> 9) + 0.5f) * s;
+    const float u1 = ((float)(c[1] >> 9) + 0.5f) * s, u3 = ((float)(c[3] >> 9) + 0.5f) * s;
     const float k = -1.3862943611198906f;                                 // -2 ln 2: -2 ln u = k * log2 u
-    const float r0 = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u0));
-    const float r1 = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u2));
+    const float r0 = __builtin_amdgcn_sqrtf(k * log2_radius_uniform(c[0]));
+    const float r1 = __builtin_amdgcn_sqrtf(k * log2_radius_uniform(c[2]));
     return {(double)(r0 * __builtin_amdgcn_cosf(u1)), (double)(r0 * __builtin_amdgcn_sinf(u1)),
             (double)(r1 * __builtin_amdgcn_cosf(u3))};
 }

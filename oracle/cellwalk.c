@@ -43,7 +43,11 @@ static inline v3 crossp(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x 
 
 /* ------------------------------------------------------------------------------------------
  * polyMesh -> CSR cell/face-slot tables.  Slot order = mesh.cells()[c] order
- * (primitiveMesh::calcCells: owned faces ascending, then neighbour faces ascending).
+ * (primitiveMesh::calcCells: owned faces ascending, then neighbour faces ascending) -- except on z-layered meshes
+ * (EVERY cell has exactly six faces, exactly two of them with nx == 0 and ny == 0 exactly): there the two z faces of
+ * each cell come last, in their original relative order, after the other four in theirs.  The order matters only for
+ * exact ties in dT (the lower slot wins, trace_in_cell); the product's mesh layer (csrc/cpf_mesh.cpp) states the same
+ * rule so that its kernels can drop both z faces with one test when no lane moves in z.
  *   planes[4*s..] = (nx, ny, nz, d): unit normal pointing INTO the cell, d = n . Cf
  *   nbr[s]        = neighbour cell, or -(face+1) for a boundary face
  * Face centre/area vector: triangle fan about the vertex average (OpenFOAM's
@@ -96,6 +100,26 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
         }
     }
     free(cnt);
+    /* z-layered meshes: z faces last (see above) */
+    int layered = 1;
+    for (int c = 0; c < nCells && layered; ++c) {
+        if (cellOff[c + 1] - cellOff[c] != 6) { layered = 0; break; }
+        int nz = 0;
+        for (int s = cellOff[c]; s < cellOff[c + 1]; ++s) nz += (planes[4 * s] == 0.0 && planes[4 * s + 1] == 0.0);
+        if (nz != 2) layered = 0;
+    }
+    for (int c = 0; c < nCells && layered; ++c) {
+        double pl[24]; int nb[6], k = 0;
+        const int s0 = cellOff[c];
+        for (int wantZ = 0; wantZ < 2; ++wantZ)
+            for (int s = s0; s < s0 + 6; ++s) {
+                const int isZ = planes[4 * s] == 0.0 && planes[4 * s + 1] == 0.0;
+                if (isZ != wantZ) continue;
+                memcpy(pl + 4 * k, planes + 4 * s, 4 * sizeof(double)); nb[k] = nbr[s]; ++k;
+            }
+        memcpy(planes + 4 * s0, pl, sizeof(pl));
+        memcpy(nbr + s0, nb, sizeof(nb));
+    }
     return cellOff[nCells];
 }
 
@@ -143,21 +167,48 @@ void cw_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     }
     memcpy(out, c, sizeof(c));
 }
-/* three N(0,1) deviates for (particle gid, step): one Philox block, Box-Muller in single precision on 23-bit
- * uniforms u = ((w >> 9) + 0.5) * 2^-23 in (0,1); words 0,1 -> two deviates, words 2,3 -> the third.  Same
- * transform as the kernels' normal3 (csrc/cpf_walk.h), which evaluates log2 / sqrt / sin / cos with the fp32
- * hardware instructions: the two agree to a few 1e-6 (asserted), the statistics are identical. */
+/* Box-Muller on the four words of one Philox block, in single precision (the kernels' normal3, csrc/cpf_walk.h, which
+ * evaluates log2 / sqrt / sin / cos with the fp32 hardware instructions: the two agree to a few 1e-6, asserted; the
+ * statistics are identical).  Words 0,1 -> two deviates, words 2,3 -> the third.
+ *   radius (words 0, 2): ALL 32 bits, u = (w + 0.5) * 2^-32 in (0,1), so that the tail reaches sqrt(2*33*ln 2) = 6.76
+ *     sigma (23-bit uniforms stopped at 5.77: at 1e7 particles x 3 deviates x 1000 cycles a true Gaussian draws ~250
+ *     values beyond that).  log2 u = log2(mantissa) + (exponent - 32) with x = (float)w + 0.5f = mantissa * 2^exponent,
+ *     mantissa in [0.5,1): the integer part is exact, the fractional part keeps its full relative precision near u = 1.
+ *   angle (words 1, 3): 23-bit uniforms ((w >> 9) + 0.5) * 2^-23 revolutions.
+ * What remains different from the reference's curand_normal_double (cuda/particles.cu:551-575; parity statistical by
+ * contract): the generator (Philox vs XORWOW), single- instead of double-precision transcendentals
+ * (deviates carry ~1e-7 relative error) and the hard cap at 6.76 sigma (cuRAND's double Box-Muller: ~8.6 sigma). */
+void cw_normal3_words(const uint32_t w[4], double out[3]) {
+    const float s = 1.0f / 8388608.0f, twopi = 6.283185307179586f, k = -1.3862943611198906f;
+    int e0, e2;
+    const float m0 = frexpf((float)w[0] + 0.5f, &e0), m2 = frexpf((float)w[2] + 0.5f, &e2);
+    const float l0 = log2f(m0) + (float)(e0 - 32), l2 = log2f(m2) + (float)(e2 - 32);
+    const float u1 = ((float)(w[1] >> 9) + 0.5f) * s, u3 = ((float)(w[3] >> 9) + 0.5f) * s;
+    const float r0 = sqrtf(k * l0), r1 = sqrtf(k * l2);
+    out[0] = (double)(r0 * cosf(twopi * u1));
+    out[1] = (double)(r0 * sinf(twopi * u1));
+    out[2] = (double)(r1 * cosf(twopi * u3));
+}
+/* three N(0,1) deviates for (particle gid, step) */
 void cw_normal3(uint64_t gid, uint32_t step, uint32_t seed, double out[3]) {
     uint32_t key[2] = {seed, 0x43504631u /* "CPF1" */};
     uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0}, w[4];
     cw_philox4x32_10(ctr, key, w);
-    const float s = 1.0f / 8388608.0f, twopi = 6.283185307179586f, k = -1.3862943611198906f;
-    const float u0 = ((float)(w[0] >> 9) + 0.5f) * s, u1 = ((float)(w[1] >> 9) + 0.5f) * s;
-    const float u2 = ((float)(w[2] >> 9) + 0.5f) * s, u3 = ((float)(w[3] >> 9) + 0.5f) * s;
-    const float r0 = sqrtf(k * log2f(u0)), r1 = sqrtf(k * log2f(u2));
-    out[0] = (double)(r0 * cosf(twopi * u1));
-    out[1] = (double)(r0 * sinf(twopi * u1));
-    out[2] = (double)(r1 * cosf(twopi * u3));
+    cw_normal3_words(w, out);
+}
+/* test helper: the (gid, step) in [0, n) x [step0, step0 + nSteps) whose FIRST radius word is smallest, i.e. whose
+ * first two deviates lie farthest out */
+void cw_scan_min_radius_word(uint32_t seed, uint32_t step0, int nSteps, int64_t n, int64_t* bestGid, uint32_t* bestStep,
+                             uint32_t* bestWord) {
+    uint32_t key[2] = {seed, 0x43504631u}, best = 0xFFFFFFFFu, bs = step0;
+    int64_t bg = 0;
+    for (int t = 0; t < nSteps; ++t)
+        for (int64_t g = 0; g < n; ++g) {
+            uint32_t ctr[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), step0 + (uint32_t)t, 0}, w[4];
+            cw_philox4x32_10(ctr, key, w);
+            if (w[0] < best) { best = w[0]; bg = g; bs = step0 + (uint32_t)t; }
+        }
+    *bestGid = bg; *bestStep = bs; *bestWord = best;
 }
 
 typedef struct { long long hops, reflections, lost; } cw_stats;

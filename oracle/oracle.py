@@ -225,6 +225,9 @@ class CellWalk:
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
         L.cw_normal3.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _dp]
+        L.cw_normal3_words.argtypes = [_up, _dp]
+        L.cw_scan_min_radius_word.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.cw_advect_vertex.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, C.c_int, _dp, _dp, C.c_int]
         self.hw_threads = L.cw_max_threads()
         self.max_threads = usable_threads(self.hw_threads)
@@ -269,3 +272,15 @@ class CellWalk:
         out = np.zeros(3)
         self.lib.cw_normal3(int(gid), int(step), int(seed), out)
         return out
+
+    def normal3_words(self, words):
+        """the deviate transform alone, on four given 32-bit words"""
+        out = np.zeros(3)
+        self.lib.cw_normal3_words(_c(np.asarray(words), np.uint32), out)
+        return out
+
+    def scan_min_radius_word(self, seed, step0, n_steps, n):
+        """(gid, step, word): where in [0, n) x [step0, step0 + n_steps) the first radius word is smallest"""
+        g, st, w = C.c_int64(0), C.c_uint32(0), C.c_uint32(0)
+        self.lib.cw_scan_min_radius_word(int(seed), int(step0), int(n_steps), int(n), C.byref(g), C.byref(st), C.byref(w))
+        return int(g.value), int(st.value), int(w.value)

@@ -82,3 +82,38 @@ def test_count_conserved_with_diffusion_on_pitzdaily(pitz, gpu_ctx_factory):
         assert fd.max() <= 1e-9
     assert len(torch.unique(g)) == n                           # ids travelled with the particles through two sorts
     ctx.use_own_stream()
+
+
+def test_tail_of_the_deviates_reaches_beyond_the_23_bit_cap(oracle_libs, gpu_ctx_factory):
+    """The radius uniform of the Box-Muller transform uses all 32 bits of its Philox word (cpf_walk.h normal3):
+    among 4e6 particles x 64 steps the CPU statement names the (particle, step) whose radius word is smallest; on the GPU
+    that particle's first two deviates must have that radius -- beyond sqrt(2 * 24 * ln 2) = 5.77 sigma, where 23-bit
+    uniforms stopped -- and agree with the CPU statement (libm vs the fp32 hardware transcendentals)."""
+    import torch
+    from cudaparticlesfoam_amd.cases import box_mesh
+    cw = oracle_libs.CellWalk()
+    n, seed = 4_000_000, 20261003
+    gid, step, word = cw.scan_min_radius_word(seed, 0, 64, n)  # 2.6e8 Philox blocks: the smallest word is ~16
+    want = cw.normal3(gid, step, seed)
+    r_want = float(np.hypot(want[0], want[1]))
+    assert word < 2 ** 7 and r_want > 5.9                      # 23-bit uniforms ((w >> 9) + 0.5) gave 5.77 for EVERY word < 512
+    mesh = box_mesh(2, 2, 2, lower=(-1, -1, -1), upper=(1, 1, 1))
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(np.zeros((mesh.n_cells, 3)))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_seed(seed)
+    dev = torch.device("cuda", 0)
+    x = torch.full((n,), 0.5, dtype=torch.float64, device=dev); y = x.clone(); z = x.clone()
+    c = torch.empty(n, dtype=torch.int32, device=dev)
+    p = lambda t: t.data_ptr()   # noqa: E731
+    ctx.locate_initial_dev(p(x), p(y), p(z), p(c), n)
+    ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, DT, D, step, 1, 0)      # gid = index; Philox counter (gid, step)
+    torch.cuda.synchronize()
+    sigma = np.sqrt(2 * D * DT)
+    d = np.array([float(x[gid]) - 0.5, float(y[gid]) - 0.5, float(z[gid]) - 0.5]) / sigma
+    assert np.abs(d - want).max() < 2e-5, (d, want)
+    assert np.hypot(d[0], d[1]) > 5.9
+    # and nobody in the whole cloud lies beyond the transform's cap, sqrt(2 * 33 * ln 2) = 6.764 sigma per radius
+    r = torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2) / sigma
+    assert float(r.max()) < 6.7638 and float(r.max()) >= np.hypot(d[0], d[1]) - 1e-9
+    ctx.use_own_stream()

@@ -24,6 +24,33 @@ def test_normal3_moments(oracle_libs):
     assert np.array_equal(cw.normal3(5, 3, 42), cw.normal3(5, 3, 42))         # stateless / reproducible
 
 
+def test_normal_transform_known_answers_and_reach(oracle_libs):
+    """The deviate transform on given Philox words (cw_normal3_words = the kernels' normal3 with libm): the radius
+    uniform uses all 32 bits, u = (w + 0.5) * 2^-32, so the smallest word gives sqrt(2 * 33 * ln 2) = 6.7637 sigma
+    (23-bit uniforms stopped at 5.77) and the largest gives 0, never NaN; pinned values for four word sets."""
+    cw = oracle_libs.CellWalk()
+    top = cw.normal3_words([0, 0, 0, 0])
+    assert abs(np.hypot(top[0], top[1]) - np.sqrt(2 * 33 * np.log(2))) < 1e-5 and abs(top[2]) > 6.6
+    assert np.all(np.isfinite(cw.normal3_words([0xFFFFFFFF] * 4))) and np.abs(cw.normal3_words([0xFFFFFFFF] * 4)).max() < 1e-3
+    # the radius is a decreasing function of its word across float rounding and exponent boundaries
+    words = [0, 1, 2, 255, 256, (1 << 23) - 1, 1 << 23, (1 << 24) + 1, (1 << 31) - 1, 1 << 31, 0xFFFFFF00, 0xFFFFFFFF]
+    radii = [float(np.hypot(*cw.normal3_words([w, 12345 << 9, 0, 0])[:2])) for w in words]
+    assert all(a >= b for a, b in zip(radii, radii[1:])) and radii[0] > 6.76 and radii[-1] < 1e-3
+    for w, want_r in ((1, 6.59928), (1 << 16, 4.70964), (1 << 31, 1.17741), (3 << 30, 0.75853)):
+        got = cw.normal3_words([w, 0, w, 0])
+        u = (w + 0.5) / 2.0 ** 32
+        assert abs(np.hypot(got[0], got[1]) - np.sqrt(-2 * np.log(u))) < 2e-6 * max(1.0, np.sqrt(-2 * np.log(u)))
+        assert abs(np.hypot(got[0], got[1]) - want_r) < 1e-4
+    kat = {(0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8): None}          # Philox KAT output 1 as transform input
+    for wds in kat:
+        a = cw.normal3_words(list(wds))
+        u0, u1 = (wds[0] + 0.5) / 2.0 ** 32, ((wds[1] >> 9) + 0.5) / 2.0 ** 23
+        u2, u3 = (wds[2] + 0.5) / 2.0 ** 32, ((wds[3] >> 9) + 0.5) / 2.0 ** 23
+        ref = np.array([np.sqrt(-2 * np.log(u0)) * np.cos(2 * np.pi * u1), np.sqrt(-2 * np.log(u0)) * np.sin(2 * np.pi * u1),
+                        np.sqrt(-2 * np.log(u2)) * np.cos(2 * np.pi * u3)])
+        assert np.abs(a - ref).max() < 5e-6
+
+
 def test_brownian_cellwalk_variance(oracle_libs):
     from cudaparticlesfoam_amd.cases import box_mesh
     cw = oracle_libs.CellWalk()
