@@ -94,6 +94,7 @@ SIGNATURES = {
     "cpf_set_tets": (_int, [_ctx, _vp, _i64, _vp, _i64, _int]),
     "cpf_set_vertex_velocity": (_int, [_ctx, _vp, _i64]),
     "cpf_stage_advect_vertex": (_int, [_ctx, _vp, _vp, _vp, _vp, _dbl, _i64]),
+    "cpf_stage_advect_const": (_int, [_ctx, _vp, _vp, _vp, _vp, _dbl, _i64]),
     "cpf_stage_brownian": (_int, [_ctx, _vp, _vp, _dbl, _i64, _dbl, _u32]),
     "cpf_stage_locate": (_int, [_ctx, _vp, _vp, _vp, _i64]),
     "cpf_stage_reflect": (_int, [_ctx, _vp, _vp, _vp, _vp, _i64]),

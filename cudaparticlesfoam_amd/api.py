@@ -435,8 +435,10 @@ class StagedCloud:
             self.ctx._ck(self.ctx.lib.cpf_stage_advect(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
         elif mode == "VertexVelocity":                                    # :428-437 -> particleAdvectKernel :244-313
             self.ctx._ck(self.ctx.lib.cpf_stage_advect_vertex(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
+        elif mode == "ConstantVelocity":                                  # :439-445 -> particleAdvectConstVel :376-399
+            self.ctx._ck(self.ctx.lib.cpf_stage_advect_const(self.ctx.h, b["P"], b["ids"], b["vels"], b["disps"], dt, self.n))
         else:
-            raise ValueError("cudaAdvect: mode must be TetVelocity or VertexVelocity")
+            raise ValueError("cudaAdvect: mode must be TetVelocity, VertexVelocity or ConstantVelocity (cuda/particles.cu:417-445)")
 
     def cudaBrownianMotion(self, dt: float, D: float, step: int):         # cuda/particles.cu:577-599
         b = self._bufs

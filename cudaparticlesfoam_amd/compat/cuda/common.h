@@ -111,9 +111,12 @@ inline void cudaAdvect(Particle* d_particles, int* d_tetIDs, vec4d* d_vels, vec4
     } else if (mode == "VertexVelocity") {
         // needs the decomposition and the vertex velocities in the library: cpf_set_tets + cpf_set_vertex_velocity
         check(c, cpf_stage_advect_vertex(c, &d_particles->x, d_tetIDs, &d_vels->x, &d_disp->x, dt, numParticles));
+    } else if (mode == "ConstantVelocity") {
+        check(c, cpf_stage_advect_const(c, &d_particles->x, d_tetIDs, &d_vels->x, &d_disp->x, dt, numParticles));
     } else {
-        throw Error(CPF_ERR_ARG, "cudaAdvect: mode must be \"TetVelocity\" or \"VertexVelocity\" (cuda/particles.cu:417-447; "
-                                 "\"ConstantVelocity\" is not built)");
+        // (the reference silently does nothing for any other string, cuda/particles.cu:417-445: a typo there is a particle
+        // cloud that never moves; here it is an error)
+        throw Error(CPF_ERR_ARG, "cudaAdvect: mode must be \"TetVelocity\", \"VertexVelocity\" or \"ConstantVelocity\" (cuda/particles.cu:417-445)");
     }
     check(c, cpf_synchronize(c));
 }
@@ -165,6 +168,19 @@ inline void writeParticles2VTU(unsigned int ti, Particle* d_particles, vec4d* d_
     const int r = cpf_write_vtu_arrays(name, numParticles, P.data(), ids.data(), V.data(), &ke);
     if (r != CPF_OK && r != CPF_ERR_STATE) throw Error(r, std::string("writeParticles2VTU: cannot write ") + name);
     std::printf("#adv: System Kinetic Energy=%lf\n", ke);
+}
+
+// Trajectory collection and its two writers (cuda/common.h:87-92, cuda/utils.cpp:7-94): in the reference's fragments they sit
+// behind `saveStreamlinetoFile`, which src/initCuda.H:68 hard-codes to false, i.e. they are dead code there.  They are
+// declared here so that a host that kept src/advect.H:163-175 verbatim still compiles; calling one says what is missing.
+inline void addToTrajectories(Particle* /*d_particles*/, int /*numParticles*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
+    throw Error(CPF_ERR_STATE, "addToTrajectories: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
+}
+inline void saveTrajectories(const std::string& /*fileName*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
+    throw Error(CPF_ERR_STATE, "saveTrajectories: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
+}
+inline void writeStreamline2VTK(const std::string& /*fileName*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
+    throw Error(CPF_ERR_STATE, "writeStreamline2VTK: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
 }
 
 inline std::string prettyNumber(std::size_t s) {

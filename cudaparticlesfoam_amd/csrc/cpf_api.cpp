@@ -57,6 +57,7 @@ struct cpf_context {
     uint32_t lastSortStep = 0;
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = -1;                       // cpf_set_option("step_variant"), see include/cpf.h: -1 = choose per launch
+    bool mixedRecords = true;                   // cpf_set_option("mixed_records"): build cell records for hex-dominant meshes too (before cpf_set_mesh)
     cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
     int64_t lastStepN = -1;                     // particle count of the most recent step launch (cpf_step_kernel_name)
     int lastStepCycles = 1;                     // ... and its cycles per launch
@@ -116,6 +117,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
+    m.mixed = (c->d_cellRec && !m.allHex) ? 1 : 0;
     return m;
 }
 cpf::GridView gridView(const cpf_context* c) {
@@ -189,6 +191,15 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     if (ctx->host.minCellFaces == 6 && ctx->host.maxCellFaces == 6) {
         CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
         CPF_HIP(ctx, cpf::launch_build_cell_records(ctx->stream, ctx->d_planes, ctx->d_nbr, ctx->d_U, ctx->d_cellRec, nCells));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->meshBytes += (size_t)nCells * 256;
+    } else if (ctx->host.nBigCells * 4 <= nCells && ctx->mixedRecords) {
+        // not all-hex, but at most a quarter of the cells have more than six faces (a hex-dominant mesh with refinement
+        // interfaces, prism layers, ...): records for the streaming kernel, padded / header-only where a cell has not
+        // exactly six faces (cpf_walk.h "cell records").  Meshes of mostly polyhedral cells keep the generic CSR walk.
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
+        CPF_HIP(ctx, cpf::launch_build_cell_records_mixed(ctx->stream, ctx->d_cellOff, ctx->d_planes, ctx->d_nbr, ctx->d_U,
+                                                          ctx->d_cellRec, nCells));
         CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->meshBytes += (size_t)nCells * 256;
     }
@@ -611,7 +622,16 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     const std::string k(key);
     if (k == "step_variant") {
         CPF_REQUIRE(ctx, value >= -1 && value <= 5 && value == (int)value, CPF_ERR_ARG, "step_variant must be -1..5");
+#ifndef CPF_EXPERIMENTS
+        CPF_REQUIRE(ctx, value != 1 && value != 2 && value != 5, CPF_ERR_ARG,
+                    "step_variant 1, 2 and 5 are experiments (measured slower on every mesh) and not in this build: make EXPERIMENTS=1");
+#endif
         ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    if (k == "mixed_records") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "mixed_records must be 0 or 1");
+        ctx->mixedRecords = value != 0;
         return CPF_OK;
     }
     if (k == "stream_tiles_per_chunk") {
@@ -698,8 +718,8 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
     else if (v == 4 || v == 5) {
         // (the record lookup is picked per launch from the particle count: the most recent launch's, else the owned cloud's)
-        const bool lf = cpf::stream_lookup_fixed(ctx->lastStepN >= 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState);
-        snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats], b[lf]);
+        const int lf = cpf::stream_lookup_mode(ctx->lastStepN >= 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState);
+        snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s, %d>", b[brown], b[reflect], b[sv], b[ctx->stats], lf);
     }
     else if (v == 3) snprintf(tmp, sizeof tmp, "cpf::step_kernel_coop<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);
     else snprintf(tmp, sizeof tmp, "cpf::step_kernel<%d, %s, %s, %s>", v, b[brown], b[reflect], b[sv]);
@@ -849,6 +869,13 @@ int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, do
     CPF_STAGE_PRE("cpf_stage_advect", true);
     CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect: null array");
     CPF_HIP(ctx, cpf::launch_stage_advect(ctx->stream, particles, ids, vels, disps, dt, n, meshView(ctx)));
+    return CPF_OK;
+}
+int cpf_stage_advect_const(cpf_context* ctx, double* particles, const int32_t* ids, const double* vels, double* disps, double dt,
+                           int64_t n) {
+    CPF_STAGE_PRE("cpf_stage_advect_const", false);
+    CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect_const: null array");
+    CPF_HIP(ctx, cpf::launch_stage_advect_const(ctx->stream, particles, ids, vels, disps, dt, n));
     return CPF_OK;
 }
 int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, const int32_t* tets, int64_t nTets,

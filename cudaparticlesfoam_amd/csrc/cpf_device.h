@@ -17,10 +17,11 @@ struct MeshView {
     const double4* planes;    // [nSlots]   (nx, ny, nz, d), unit normal into the cell
     const int32_t* nbr;       // [nSlots]
     const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
-    const double4* cellRec;   // [nCells][8] packed 256-B records (all-hex meshes only, else null)
+    const double4* cellRec;   // [nCells][8] packed 256-B records (null: generic walk only); layout: cpf_walk.h "cell records"
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s)
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
+    int32_t mixed;            // records exist although not every cell has 6 faces: padded (< 6) and header-only (> 6) records
 };
 
 struct GridView {
@@ -50,7 +51,7 @@ struct StreamState {
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
-bool stream_lookup_fixed(int64_t n, const MeshView& m, const StreamState& ss);
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 2 fixed compare + mixed records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 3;       // fused launches of this many cycles or more run the wave-cooperative kernel
@@ -75,12 +76,16 @@ hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, 
 hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out);
 hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,
                                      double4* rec, int64_t nCells);
+hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
+                                           const double4* U, double4* rec, int64_t nCells);
 hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells);
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
 
 // stage-by-stage kernels on the reference's AoS layouts
 hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                int64_t n, const MeshView& m);
+hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* ids, const double* vels, double* disps, double dt,
+                                     int64_t n);
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                       int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
                                       const double* vertVel);

@@ -20,6 +20,7 @@ struct HostTables {
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
     int32_t maxCellFaces = 0, minCellFaces = 0;
+    int64_t nBigCells = 0;          // cells with more than 6 faces
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes

@@ -337,7 +337,12 @@ static void launch_step_v(bool brown, bool reflect, bool storeVel, dim3 grid, hi
 
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells) {
     if (coopMaxCells <= 0 || coopMaxCells > kCoopMaxCells) coopMaxCells = kCoopMaxCells;
-    if (!m.allHex) return kVariantGeneric;                    // fixed-slot variants need 6 faces per cell
+    if (!m.allHex) {
+        // not all-hex: the streaming kernel where the mesh layer built mixed records for it (few cells with more than six
+        // faces: they take the CSR walk inside the kernel), else the generic CSR walk; the other variants need 6 faces per cell
+        const bool wantsStream = variant == kVariantAuto || variant == kVariantStream || variant == kVariantCoop;
+        return (m.mixed && m.cellRec && haveStream && wantsStream) ? kVariantStream : kVariantGeneric;
+    }
     // Several cycles fused into one launch (CPF_STEP_FUSE_CYCLES: what advect.H does between two output points): the
     // particle stream is loaded and stored once per launch, so hiding it behind the walk buys nothing, and the
     // wave-cooperative kernel's 8 waves per SIMD (the streaming kernel: 6) win -- measured per cycle, pitzDaily:
@@ -346,7 +351,12 @@ int effective_step_variant(int variant, const MeshView& m, bool haveStream, int 
         variant = (haveStream && !(cyclesPerLaunch >= kFusedCoopCycles && m.nCells <= coopMaxCells)) ? kVariantStream : kVariantCoop;
     if ((variant == kVariantStream || variant == kVariantAhead) && !haveStream) variant = kVariantCoop;
     // the wave-cooperative kernel addresses records with a 32-bit byte offset (256 B x 2^24 cells)
-    if (variant == kVariantCoop && m.nCells > coopMaxCells) variant = haveStream ? kVariantStream : kVariantFixedScalar;
+    if (variant == kVariantCoop && m.nCells > coopMaxCells) variant = haveStream ? kVariantStream : kVariantGeneric;
+#ifndef CPF_EXPERIMENTS
+    // (variants 1, 2 and 5 are not in this build: cpf_set_option refuses them; belt and braces)
+    if (variant == kVariantFixed || variant == kVariantFixedScalar) variant = kVariantCoop;
+    if (variant == kVariantAhead) variant = haveStream ? kVariantStream : kVariantCoop;
+#endif
     return variant;
 }
 
@@ -360,16 +370,23 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
     variant = effective_step_variant(variant, m, ss != nullptr, nCyc, ss ? ss->coopMaxCells : 0);
     switch (variant) {
+#ifdef CPF_EXPERIMENTS
         case kVariantAhead:
             // lanes that run ahead into the next tile: one plain cycle per launch only; everything else streams
             if (!brown && !storeVel && nCyc == 1) return launch_step_ahead(st, x, y, z, cell, n, dt, reflect, m, counters, *ss, vel);
             [[fallthrough]];
+#endif
         case kVariantStream:
             return launch_step_stream(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m,
                                       counters, *ss);
+#ifdef CPF_EXPERIMENTS
         case kVariantFixed:
             launch_step_v<kVariantFixed>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
             break;
+        case kVariantFixedScalar:
+            launch_step_v<kVariantFixedScalar>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
+            break;
+#endif
         case kVariantCoop:
             if (brown) {
                 if (reflect) launch_step_coop_sv<true, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
@@ -378,9 +395,6 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
                 if (reflect) launch_step_coop_sv<false, true>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
                 else launch_step_coop_sv<false, false>(storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
             }
-            break;
-        case kVariantFixedScalar:
-            launch_step_v<kVariantFixedScalar>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
             break;
         default:
             launch_step_v<kVariantGeneric>(brown, reflect, storeVel, grid, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters);
@@ -553,6 +567,23 @@ static inline dim3 grid_of(int64_t n) { return dim3((unsigned)((n + kBlock - 1) 
 hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                int64_t n, const MeshView& m) {
     if (n > 0) hipLaunchKernelGGL(stage_advect_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels, (double4*)disps, dt, n, m);
+    return hipGetLastError();
+}
+// "ConstantVelocity" advect (cuda/particles.cu:376-399): the particle's own stored velocity, first-order Euler
+__global__ __launch_bounds__(kBlock) void stage_advect_const_kernel(double4* __restrict__ P, const int32_t* __restrict__ ids,
+                                                                    const double4* __restrict__ vels, double4* __restrict__ disps,
+                                                                    double dt, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double4 p = P[i];
+    if (!p.w) return;
+    if (ids[i] < 0) { p.w = 0.0; P[i] = p; return; }             // particles.cu:390-394
+    const double4 v = vels[i];
+    disps[i] = make_double4(v.x * dt, v.y * dt, v.z * dt, -1.0);  // particles.cu:398
+}
+hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* ids, const double* vels, double* disps, double dt,
+                                     int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(stage_advect_const_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (const double4*)vels, (double4*)disps, dt, n);
     return hipGetLastError();
 }
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
@@ -778,6 +809,25 @@ __global__ void build_cell_records_kernel(const double4* __restrict__ planes, co
     for (int s = 0; s < 6; ++s) nb[s] = nbr[6 * c + s];
     nb[6] = 0; nb[7] = 0;
 }
+// records of a mesh that is not all-hex (layout: cpf_walk.h "cell records")
+__global__ void build_cell_records_mixed_kernel(const int32_t* __restrict__ cellOff, const double4* __restrict__ planes,
+                                                const int32_t* __restrict__ nbr, const double4* __restrict__ U,
+                                                double4* __restrict__ rec, int64_t nCells) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nCells) return;
+    const int s0 = cellOff[c], nf = cellOff[c + 1] - s0;
+    double4* r = rec + 8 * c;
+    int32_t* nb = reinterpret_cast<int32_t*>(r + 7);
+    const double4 nullPlane = make_double4(0.0, 0.0, 0.0, -1.0);
+    for (int s = 0; s < 6; ++s) {
+        const bool real = nf <= 6 && s < nf;
+        r[s] = real ? planes[s0 + s] : nullPlane;
+        nb[s] = real ? nbr[s0 + s] : kNullNbr;
+    }
+    r[6] = U[c];
+    nb[6] = 0; nb[7] = 0;
+    if (nf > 6) { nb[0] = kBigCellMark; nb[1] = s0; nb[2] = nf; }
+}
 __global__ void update_record_velocity_kernel(const double4* __restrict__ U, double4* __restrict__ rec, int64_t nCells) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (c < nCells) rec[8 * c + 6] = U[c];
@@ -814,6 +864,11 @@ hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_
 hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,
                                      double4* rec, int64_t nCells) {
     if (nCells > 0) hipLaunchKernelGGL(build_cell_records_kernel, grid_for(nCells), dim3(kBlock), 0, st, planes, nbr, U, rec, nCells);
+    return hipGetLastError();
+}
+hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
+                                           const double4* U, double4* rec, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(build_cell_records_mixed_kernel, grid_for(nCells), dim3(kBlock), 0, st, cellOff, planes, nbr, U, rec, nCells);
     return hipGetLastError();
 }
 hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells) {

@@ -85,6 +85,7 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         int32_t k = out.cellOff[(size_t)c + 1];
         if (k < 4) return "cell " + std::to_string(c) + " has fewer than 4 faces";
         out.maxCellFaces = std::max(out.maxCellFaces, k);
+        if (k > 6) ++out.nBigCells;
         out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
         out.cellOff[(size_t)c + 1] += out.cellOff[(size_t)c];
     }
@@ -127,7 +128,12 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
     // else keeps OpenFOAM's order.  A particle whose displacement has dz == 0 exactly (2-D flow without diffusion)
     // has a denominator of exactly +-0 against such a face and can never leave through it (ConvexQuery.cu:86-95:
     // dT = +-inf -> -1, or NaN); with the pair in a fixed place a wave of such particles drops both faces with ONE test
-    // instead of fetching both planes and evaluating two denominators (cpf_walk.h, trace_lds6).  The slot order is part
+    // instead of fetching both planes and evaluating two denominators (cpf_walk.h, trace_lds6).
+    // (Measured and dropped in round 3: the same idea for ALL three axes of an axis-aligned mesh -- slots ordered x, y, z
+    // pairs and a two-operation form of the face test for faces exactly along an axis, den = n_a * Pd_a, fd = d - n_a * P_a,
+    // bit-identical because the dropped terms are exact zeros.  5-7 % SLOWER on every mesh, pitzDaily included, where
+    // only the code around the unchanged tests differed: the kernel is bound by how its instructions are scheduled, and
+    // three more wave-uniform branches and a second form of every pair cost more than 24 operations per round save.)  The slot order is part
     // of the walk's definition (ties in dT go to the lower slot), so oracle/cellwalk.c states the same rule.
     out.zPairLast = out.minCellFaces == 6 && out.maxCellFaces == 6;
     for (int64_t c = 0; c < nCells && out.zPairLast; ++c) {

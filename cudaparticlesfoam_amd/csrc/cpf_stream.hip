@@ -54,7 +54,7 @@ constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a
 #define CPF_STREAM_INROUND 0
 #endif
 #ifndef CPF_STREAM_HIT_POOL
-#define CPF_STREAM_HIT_POOL 10
+#define CPF_STREAM_HIT_POOL 40
 #endif
 constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
@@ -68,11 +68,11 @@ struct StreamKernArgs {
 static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
-template <bool BROWNIAN, bool STORE_VEL, bool STATS>
-struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? 6 : CPF_STREAM_WAVES); };
+template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
+struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP == 2 ? 5 : 6) : CPF_STREAM_WAVES); };
 
-template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, bool LOOKUP_FIXED>
-__global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::waves)) void step_kernel_stream(
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
+__global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
     double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,   // read through kernarg_cloud_ptrs()
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
@@ -86,14 +86,18 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     __shared__ unsigned sCnt[4];
     // Per-lane end point E, parked between rounds (see step_kernel_coop) -- the slot also carries the three Brownian
     // deviates from the first round of a cycle to the lane's advect, and the previous tile's position from the tile's end
-    // to the next tile's hook -- and the LAST WALL HIT POINT of the lanes that were reflected in the current cycle.  Only
-    // the ~1 % of particle-steps that meet a wall need a hit point (5-10 % with the tutorial's diffusion on the 1 mm slab),
-    // so a wave has a small POOL instead of 64 x 24 bytes: a lane takes an entry at its first reflection of the cycle (LDS
-    // counter), and entries beyond the pool go to the wave's own 1.5 KB of global memory (sa.hitSpill) -- 1.3 KB of LDS
-    // less per wave, which is what a 7th wave per SIMD needs (160 KB / 28 waves = 5851 B; 8 waves: 5120 B).
-    constexpr bool HIT_POOL = true;
+    // to the next tile's hook.  The LAST WALL HIT POINT of a reflected lane (read once, by the move at the cycle's end)
+    // used to have 64 x 24 bytes of LDS as well; those 1.5 KB are what stood between this kernel and a 7th wave per SIMD
+    // (160 KB / 28 waves = 5851 B).  Two ways out, chosen per instantiation by what it has room for:
+    //   * HIT_IN_REGS (no Brownian kick, all-hex mesh): the hit point stays in six VGPRs -- the scalar-register diet and
+    //     the single round instance left exactly that room under the 72 registers 7 waves allow;
+    //   * otherwise a small per-wave POOL in LDS: a lane takes an entry at its first reflection of the cycle (LDS counter)
+    //     and entries beyond the pool go to the wave's own 1.5 KB of global memory (sa.hitSpill).  (A pool of 10 for
+    //     every instantiation, tried first, cost bench.py's window 3 %: there the cloud drifts into the outlet wall
+    //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
+    constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    constexpr int kPool = CPF_STREAM_HIT_POOL;
+    constexpr int kPool = HIT_IN_REGS ? 1 : CPF_STREAM_HIT_POOL;
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -105,6 +109,11 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     const unsigned preBase = uniform32(lds_addr(sPre));
     const unsigned slotBase = uniform32(lds_addr(slots));
     const int tpc = sa.tilesPerChunk;
+    // LOOKUP: how a wave finds its cells in its record cache, and which records can turn up --
+    //   0 loop over the distinct cells of the wave, 1 fixed tag compare, 2 fixed tag compare on a mesh that is not all-hex
+    //   (MeshView::mixed: header records of cells with more than six faces may turn up)
+    constexpr bool LOOKUP_FIXED = LOOKUP != 0;
+    constexpr bool mixed = LOOKUP == 2;
     const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
@@ -114,6 +123,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
     const unsigned big = sa.bigChunks;
     const unsigned nChunks = big + (nTiles - big * (unsigned)tpc);
     // first tile of chunk c, and how many of its tiles exist (0: the chunk lies past the end of the cloud)
+    // (Measured and dropped in round 3: dealing the chunks from the END of the cloud towards its start, so that the launch
+    // finishes on the inlet's tiles instead of the outlet wall's -- 0.1245 ms either way.)
     auto chunk_first = [&](unsigned c) -> unsigned {
         return c < big ? c * (unsigned)tpc : big * (unsigned)tpc + (c - big);
     };
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
         if (c >= nChunks) return 0;
         const unsigned k = nTiles - firstTile;
         const unsigned want = c < big ? (unsigned)tpc : 1u;
-        return (int)(k < want ? k : want);
+        return (int)(k < want ? k : want);                     // (k < want never happens: chunks tile the cloud exactly)
     };
     // chunk j of the group (j = what the group's counter returns) is chunk grp + G*j of the cloud
     auto chunk_of = [&](unsigned j) -> unsigned {
@@ -266,16 +277,16 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
             // j >= kMaxReflect (still on a wall after 5 bounces; a wall without reflection sets j = kMaxReflect too).
             bool busy = false;
             int token = INT32_MIN, h = 0, j = 0;
-            int hitAt = -1;                          // HIT_POOL: where this lane's hit point is parked (< kPool: pool entry)
+            int hitAt = -1;                          // pool: where this lane's hit point is parked (< kPool: pool entry)
             // parks the wall hit point of a lane that is being reflected (it is read back once, by the move at cycle end)
+            D3 hitReg = {0, 0, 0};                   // HIT_IN_REGS: the last wall hit point
             auto park_hit = [&](const D3& Hp) __attribute__((always_inline)) {
-                if (HIT_POOL) {
-                    if (hitAt < 0) hitAt = (int)atomicAdd(&sPoolUsed, 1u);          // first reflection of the cycle
-                    if (hitAt < kPool) { sPool[0][hitAt] = Hp.x; sPool[1][hitAt] = Hp.y; sPool[2][hitAt] = Hp.z; }
-                    else {
-                        double* sp = static_cast<double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles;
-                        async_store(sp, ul * 8u, Hp.x); async_store(sp + 64, ul * 8u, Hp.y); async_store(sp + 128, ul * 8u, Hp.z);
-                    }
+                if (HIT_IN_REGS) { hitReg = Hp; return; }
+                if (hitAt < 0) hitAt = (int)atomicAdd(&sPoolUsed, 1u);          // first reflection of the cycle
+                if (hitAt < kPool) { sPool[0][hitAt] = Hp.x; sPool[1][hitAt] = Hp.y; sPool[2][hitAt] = Hp.z; }
+                else {
+                    double* sp = static_cast<double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles;
+                    async_store(sp, ul * 8u, Hp.x); async_store(sp + 64, ul * 8u, Hp.y); async_store(sp + 128, ul * 8u, Hp.z);
                 }
             };
 
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                 if (cur < 0) cur = CPF_CELL_FROZEN;                                  // lost in the previous cycle: w = 0
                 busy = cur >= 0;
                 token = INT32_MIN; h = 0; j = 0;
-                if (HIT_POOL && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
+                if (!HIT_IN_REGS && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
                 if (STATS && busy) ++st.steps;
             };
 
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 #ifdef CPF_STREAM_TIMELINE
                 ++tlRounds;
 #endif
-                // ---- record cache lookup, two ways (LOOKUP_FIXED, chosen per launch by stream_lookup_fixed()).  Few particles per cell
+                // ---- record cache lookup, two ways (LOOKUP_FIXED, chosen per launch by stream_lookup_mode()).  Few particles per cell
                 // (3-D meshes: 5-10 distinct cells per round): every lane compares its cell with the NS tags (tag k
                 // broadcast from lane k of tagv), a fixed, branch-free sequence of 3 vector instructions per tag.  Many
                 // particles per cell (pitzDaily: 1-3 distinct cells per round): one scalar iteration per DISTINCT cell
@@ -431,12 +442,23 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                         // it.  ONE instance of the face tests inside a per-lane loop: from its second trip on only the
                         // reflecting lanes are active and most faces drop out wave-uniformly.  Same arithmetic in the same
                         // order as a round per reflection: bit-identical.
+                        // (a mesh that is not all-hex: is this the header record of a cell with more than six faces?)
+                        bool bigCell = false;
+                        int bigS0 = 0, bigNf = 0;
+                        if (LOOKUP_FIXED && mixed) {
+                            const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
+                            bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
+                        }
                         bool again;
                         do {
                             again = false;
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
+                            if (LOOKUP_FIXED && mixed && bigCell) {
+                                // more than six faces: the cell's CSR slots, from global memory (same test, same order)
+                                next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
+                            } else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot, zLast);
                             if (STATS) ++st.hops;
@@ -446,7 +468,11 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                                 // the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0), and E comes
                                 // from its parking slot -- it is there, from this round's advect or an earlier round -- so
                                 // that it need not stay in registers across the face tests.
-                                const double4 wallPlane = rec[outSlot];
+                                double4 wallPlane;
+                                if (LOOKUP_FIXED && mixed && bigCell) {
+                                    wallPlane = m.planes[bigS0 + outSlot];
+                                    asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));   // arrives HERE
+                                } else wallPlane = rec[outSlot];
                                 asm volatile("" ::: "memory");
                                 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
                                 park_hit(S_);
@@ -481,6 +507,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                                 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                                 sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                             }
+                            int gS0 = 0;
+                            bool gBig = false;
+                            if (LOOKUP_FIXED && mixed) {
+                                const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
+                                gBig = hdr.x == kBigCellMark; gS0 = hdr.y;
+                                if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
+                            }
+                            if (!gBig)
                             next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                             if (STATS) ++st.hops;
                             // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
@@ -523,11 +557,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
                     const D3 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
                     if (REFLECT && j != 0) {                 // reflected at least once
                         D3 hit;
-                        if (HIT_POOL) {
-                            if (hitAt < kPool) hit = {sPool[0][hitAt], sPool[1][hitAt], sPool[2][hitAt]};
-                            else load3_sync(static_cast<const double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles,
-                                            ul * 8u, hit.x, hit.y, hit.z);
-                        }
+                        if (HIT_IN_REGS) hit = hitReg;
+                        else if (hitAt < kPool) hit = {sPool[0][hitAt], sPool[1][hitAt], sPool[2][hitAt]};
+                        else load3_sync(static_cast<const double*>(kernarg_pointer<kKernArgHitSpill>()) + (size_t)blockIdx.x * kStreamHitSpillDoubles,
+                                        ul * 8u, hit.x, hit.y, hit.z);
                         S_ = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
                     } else S_ = E;
                     if (j >= kMaxReflect) { cur = CPF_CELL_LOST; if (STATS) ++st.lost; }
@@ -596,7 +629,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS>::w
 // ------------------------------------------------------------------------------------------------
 // launcher: persistent grid sized by the occupancy of the instantiation
 // ------------------------------------------------------------------------------------------------
-template <bool B, bool R_, bool SV, bool ST, bool LF>
+template <bool B, bool R_, bool SV, bool ST, int LF>
 static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                                      double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
                                      uint32_t seed, const MeshView& m, unsigned long long* counters, StreamState& ss) {
@@ -632,19 +665,21 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 }
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
-bool stream_lookup_fixed(int64_t n, const MeshView& m, const StreamState& ss) {
-    return ss.lookup >= 0 ? ss.lookup != 0 : n < 128 * (int64_t)m.nCells;
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
+    if (m.mixed) return 2;                     // not all-hex: the instantiations that know header records (cells with > 6 faces)
+    return (ss.lookup >= 0 ? ss.lookup != 0 : n < 128 * (int64_t)m.nCells) ? 1 : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
                               bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
                               StreamState& ss) {
-    const bool lf = stream_lookup_fixed(n, m, ss);
+    const int lf = stream_lookup_mode(n, m, ss);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
-        if (lf) return launch_stream_inst<B, R, SV, ST, true>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
-        return launch_stream_inst<B, R, SV, ST, false>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);         \
+        if (lf == 2) return launch_stream_inst<B, R, SV, ST, 2>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
+        if (lf == 1) return launch_stream_inst<B, R, SV, ST, 1>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
+        return launch_stream_inst<B, R, SV, ST, 0>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);         \
     } while (0)
 #define CPF_STREAM_SV(B, R)                                                                     \
     do {                                                                                        \

@@ -228,6 +228,38 @@ __device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, co
     return next;
 }
 
+// Cell records (MeshView::cellRec, 256 bytes per cell = 8 double4): [0..5] the planes of face slots 0..5, [6] U,
+// [7] six neighbour ids (int32) + two spare words.  On meshes that are not all-hex (MeshView::mixed):
+//   * a cell with FEWER than 6 faces (prism, tet, pyramid) is padded with null faces -- plane (0, 0, 0, -1), neighbour
+//     kNullNbr: den == 0 and fd == -1 for every particle, so the face can never be accepted (ConvexQuery.cu:86-95) and
+//     the six-slot tests give what the walk over its real faces gives, in the same slot order;
+//   * a cell with MORE than 6 faces (next to a 2:1 refinement: 7 ... 24) has a HEADER record: neighbour word 0 =
+//     kBigCellMark, word 1 = its first CSR slot, word 2 = its face count, null planes, U as usual.  A lane in such a
+//     cell walks the CSR tables (planes / nbr in global memory) with trace_csr -- same arithmetic, same slot order.
+// The reference cannot run such meshes at all (src/initCuda.H:64: tetsPerCell = 12).
+constexpr int kNullNbr = INT32_MIN + 5;
+constexpr int kBigCellMark = INT32_MIN + 6;
+
+// trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0
+__device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const double4* __restrict__ planes,
+                                         const int32_t* __restrict__ nbr, int s0, int nf, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 1.1;
+    for (int s = 0; s < nf; ++s) {
+        const double4 pl = planes[s0 + s];
+        const int nb = nbr[s0 + s];
+        const double fd = plane_dist(pl, P0);
+        double dT = fd / dot3(pl, Pd);
+        if (__builtin_isinf(dT)) dT = -1.0;
+        if (nb == token) continue;
+        if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
+    }
+    if (best >= 0) { S = axpy(dTmin, Pd, P0); outSlot = best; }
+    return next;
+}
+
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
 enum { kVariantAuto = -1, kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4, kVariantAhead = 5 };
 

@@ -176,15 +176,20 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "step_variant"  -1 (default) chosen per launch: 4, but 3 for launches that fuse 3 or more cycles
  *                     (CPF_STEP_FUSE_CYCLES: the particle stream is loaded and stored once per launch there, and kernel
  *                     3's higher occupancy wins: 5-15 % per cycle)
- *                   0 generic CSR walk (any polyhedral mesh; forced when a cell is not a hex)
- *                   1 all-hex fixed-slot walk, per-lane gathers
- *                   2 + wave-uniform plane fetches through the scalar cache
+ *                   0 generic CSR walk (any polyhedral mesh; runs by itself when more than a quarter of the cells have
+ *                     more than six faces, or with option "mixed_records" 0)
  *                   3 wave-cooperative LDS cell cache on packed 256-byte cell records, one block per 128 particles
+ *                     (all-hex meshes)
  *                   4 streaming kernel: persistent waves, next tile prefetched into LDS while the current
- *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip)
- *                   5 experimental: variant 4 whose finished lanes start on the next tile at once (cpf_ahead.hip).
- *                     Fewer rounds per tile but dearer rounds: measured SLOWER than 4 on every mesh;
- *                     only the plain reflect / no-reflect step without Brownian or stored velocity, else 4 runs
+ *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip);
+ *                     all-hex meshes, and meshes with a minority of other cells ("mixed_records")
+ *                   1, 2, 5 experiments, measured SLOWER than 3 / 4 on every mesh: per-lane gathers,
+ *                     + scalar plane fetches, run-ahead lanes (cpf_ahead.hip).  Only in libraries built with
+ *                     `make EXPERIMENTS=1`; the default build answers CPF_ERR_ARG
+ *   "mixed_records" (1; set BEFORE cpf_set_mesh) on a mesh that is not all-hex, build cell records anyway if at most a
+ *                   quarter of the cells have more than six faces: cells with fewer than six faces get padded records,
+ *                   cells with more a header record and are walked through the CSR tables inside kernel 4.  0 = such
+ *                   meshes run the generic walk (kernel 0)
  *   "stream_tiles_per_chunk" (4), "stream_tail_fraction" (0.1), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare): how a wave finds its cells in its record cache;
@@ -204,7 +209,7 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
 int cpf_set_option(cpf_context* ctx, const char* key, double value);
 /* Name of the kernel instantiation cpf_step / cpf_step_dev launches for this diffusion coefficient and these flags with
  * the current mesh and options (and the particle count of the most recent step launch, which picks the record lookup of
- * the streaming kernel), as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false, false>"):
+ * the streaming kernel), as a profiler prints it (e.g. "cpf::step_kernel_stream<false, true, false, false, 0>"):
  * lets a benchmark label its roofline with what actually ran. */
 int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, size_t bufBytes);
 
@@ -294,6 +299,11 @@ int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, cons
 int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVerts);
 int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps,
                             double dt, int64_t n);
+/* cudaAdvect, "ConstantVelocity" mode (cuda/particles.cu:439-445 -> particleAdvectConstVel, :376-399): every particle
+ * keeps the velocity ALREADY in vels -- disps = (vel.x*dt, vel.y*dt, vel.z*dt, -1); a particle whose id is negative is
+ * switched off (w = 0) like in the other modes.  No caller in the reference's src/ uses this mode. */
+int cpf_stage_advect_const(cpf_context* ctx, double* particles, const int32_t* ids, const double* vels, double* disps,
+                           double dt, int64_t n);
 /* cudaBrownianMotion (cuda/particles.cu:577-599); step selects the counter-based stream */
 int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,
                        uint32_t step);

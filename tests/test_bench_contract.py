@@ -111,7 +111,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
     assert d["steps"] == 6 and d["warmup"] == 2 and d["config"]["particles_total"] == 200_000
     assert d["config"]["particles_after"] == 200_000                      # every boundary reflects: nobody is lost
     # what really ran: 2e5 particles on 12 225 cells = 16 per cell, so the fixed-compare record lookup (last parameter)
-    assert d["roofline"]["kernel"] == "cpf::step_kernel_stream<false, true, false, false, true>"
+    assert d["roofline"]["kernel"] == "cpf::step_kernel_stream<false, true, false, false, 1>"
     assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None      # other launch size than the PMC run
     if extra:
         h = d["config"]["ms_in_handoff"]
@@ -119,7 +119,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert h["collectives_device_ms_total"] > 0 and d["config"]["handoff_fraction_per_step"] is not None
     else:
         b, st = d["config"]["brownian"], d["config"]["ms_per_step_steady"]
-        assert b["D"] == 1.5e-5 and b["kernel"] == "cpf::step_kernel_stream<true, true, false, false, true>" and 0 < b["frac"] < 1
+        assert b["D"] == 1.5e-5 and b["kernel"] == "cpf::step_kernel_stream<true, true, false, false, 1>" and 0 < b["frac"] < 1
         assert st["steps"] == 100 and st["sorts_inside"] == 1 and st["ms_per_step"] > 0
         f = d["config"]["extra_fused_cycles"]
         assert f["cycles_per_launch"] == 8 and f["launches"] == 10 and f["Mparticle_steps_per_s"] > 0

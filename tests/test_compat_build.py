@@ -36,3 +36,44 @@ def test_mock_solver_fails_loudly_without_gpu(tmp_path, pitz):
     r = subprocess.run([os.path.join(COMPAT, "bin", "mockUncoupledFoam"), str(tmp_path / "case")], cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_reference_io_block_compiles_against_the_shims(tmp_path):
+    """A host that kept the reference's per-cycle I/O block verbatim (src/advect.H:163-175: addToTrajectories,
+    writeParticles2VTU, saveTrajectories, writeStreamline2VTK behind saveStreamlinetoFile) and all three cudaAdvect mode
+    strings (cuda/particles.cu:417-445) compiles against compat/cuda/common.h with plain g++; the three trajectory
+    functions -- dead in the reference, src/initCuda.H:68 -- throw advect::Error when called."""
+    src = tmp_path / "io_block.cpp"
+    src.write_text(r'''
+#include "cuda/common.h"
+#include <cstring>
+using namespace advect;
+int main() {
+    Particle* d_particles = nullptr; vec4d* d_particle_vels = nullptr; vec4d* d_disp = nullptr;
+    int* d_particles_tetIDs = nullptr; int* d_particles_ConvextetIDs = nullptr;
+    int numParticles = 0, step = 0, saveInterval = 10;
+    bool saveStreamlinetoFile = false;
+    std::string objTrajectoryFileName, vtkStreamlineFileName;
+    std::vector<std::vector<vec3f>> trajectories;
+    if (saveStreamlinetoFile)
+        if ((step % (saveInterval * 1)) == 0)
+            addToTrajectories(d_particles, numParticles, trajectories);
+    if (saveStreamlinetoFile) {
+        if (objTrajectoryFileName.size() > 0) saveTrajectories(objTrajectoryFileName, trajectories);
+        if (vtkStreamlineFileName.size() > 0) writeStreamline2VTK(vtkStreamlineFileName, trajectories);
+    }
+    void (*advectFn)(Particle*, int*, vec4d*, vec4d*, double, int, vec4i*, vec3d*, vec3d*, std::string) = &cudaAdvect;
+    (void)advectFn; (void)d_particle_vels; (void)d_disp; (void)d_particles_tetIDs; (void)d_particles_ConvextetIDs;
+    int thrown = 0;
+    try { addToTrajectories(d_particles, 0, trajectories); } catch (const Error& e) { thrown += std::strstr(e.what(), "src/initCuda.H:68") != nullptr; }
+    try { saveTrajectories("t.obj", trajectories); } catch (const Error&) { ++thrown; }
+    try { writeStreamline2VTK("t.vtk", trajectories); } catch (const Error&) { ++thrown; }
+    return thrown == 3 ? 0 : 1;
+}
+''')
+    exe = tmp_path / "io_block"
+    lib = os.path.join(ROOT, "cudaparticlesfoam_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), str(src),
+                        "-L" + lib, "-lcudaParticleAdvection", "-Wl,-rpath," + lib, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(exe)]).returncode == 0

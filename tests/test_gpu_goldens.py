@@ -173,7 +173,7 @@ def test_vertex_velocity_vs_reference_golden(gpu_ctx_factory, oracle_libs):
             # shared by two tets grows along the trajectory -- still orders of magnitude inside the bar)
             assert _rel(sc.particles, g["P_%d" % k], diag).max() <= REL_TOL
         with pytest.raises(ValueError):
-            sc.cudaAdvect(0.1, "ConstantVelocity")
+            sc.cudaAdvect(0.1, "NoSuchVelocityMode")               # (the reference silently does nothing for a typo, cuda/particles.cu:417-445)
     finally:
         sc.close()
 
@@ -190,3 +190,34 @@ def test_oracle_built_here_stage_face_seed_goldens(oracle_libs):
     og.test_face_table_golden(oracle_libs)
     og.test_seeding_golden(oracle_libs)
     og.test_vertex_velocity_golden(oracle_libs)
+
+
+def test_constant_velocity_advect_mode(gpu_ctx_factory):
+    """cudaAdvect(..., "ConstantVelocity") (cuda/particles.cu:439-445 -> particleAdvectConstVel :376-399): every particle
+    keeps the velocity already stored for it, disp = (vel * dt, -1); negative id -> w = 0 and nothing else; w == 0 ->
+    untouched.  One rounding per component, so the comparison with numpy is exact."""
+    from cudaparticlesfoam_amd.api import StagedCloud
+    from cudaparticlesfoam_amd.cases import box_mesh
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(box_mesh(2, 2, 2))
+    n = 5000
+    rng = np.random.default_rng(4)
+    P = np.concatenate([rng.uniform(0, 2, size=(n, 3)), np.ones((n, 1))], 1)
+    P[::7, 3] = 0.0                                            # already switched off
+    ids = rng.integers(0, 8, size=n).astype(np.int32)
+    ids[::5] = -3                                              # left the domain
+    vels = np.concatenate([rng.normal(size=(n, 3)), -np.ones((n, 1))], 1)
+    sc = StagedCloud(ctx, n)
+    sc.set(P, ids); sc._put("vels", vels); sc._put("disps", np.full((n, 4), 7.0))
+    dt = 0.0123
+    sc.cudaAdvect(dt, "ConstantVelocity")
+    ctx.synchronize()
+    Pn, d = sc.particles, sc.disps
+    live = (P[:, 3] != 0) & (ids >= 0)
+    assert np.array_equal(d[live, :3], vels[live, :3] * dt) and np.all(d[live, 3] == -1.0)
+    assert np.all(d[~live] == 7.0)                              # not touched
+    assert np.array_equal(Pn[:, :3], P[:, :3]) and np.array_equal(sc.vels, vels)
+    assert np.array_equal(Pn[:, 3], np.where((P[:, 3] != 0) & (ids < 0), 0.0, P[:, 3]))
+    with pytest.raises(ValueError):
+        sc.cudaAdvect(dt, "NoSuchMode")
+    sc.close()

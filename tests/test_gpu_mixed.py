@@ -1,0 +1,162 @@
+"""GPU: meshes that are NOT all-hex keep the streaming kernel (BASELINE configs[4] "polyMesh").
+
+The reference cannot run them at all (``src/initCuda.H:64``: ``tetsPerCell = 12``); the bar is this repo's own: the HIP
+path is bit-identical to the CPU statement ``oracle/cellwalk.c`` on them -- cells, positions, visit and reflection
+counters -- whichever kernel runs: the streaming kernel with mixed cell records (padded records for cells with fewer than
+six faces, header records + CSR walk for cells with more), or the generic CSR walk.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _prism_box(nx, ny, nz):
+    """every hex of a box cut into two triangular prisms (5 faces each): padded records"""
+    from cudaparticlesfoam_amd.cases import box_mesh, build_polymesh_from_cells
+    m = box_mesh(nx, ny, nz)
+    cells = []
+    for h in m.hexes:
+        for a, b, c in ((0, 1, 2), (0, 2, 3)):
+            lo = (h[a], h[b], h[c]); hi = (h[a + 4], h[b + 4], h[c + 4])
+            cells.append([(lo[0], lo[2], lo[1]), hi, (lo[0], lo[1], hi[1], hi[0]), (lo[1], lo[2], hi[2], hi[1]),
+                          (lo[2], lo[0], hi[0], hi[2])])
+    return build_polymesh_from_cells(m.points, [[tuple(int(v) for v in f) for f in c] for c in cells])
+
+
+def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, want_kernel):
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
+    stats = cw.step(x, y, z, c, dt, cycles, t, U, nthreads=cw.max_threads)
+    for opts in options:
+        ctx = gpu_ctx_factory()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+        ctx.locate_initial()
+        _, cell0 = ctx.get_particles()
+        assert np.array_equal(cell0, ref0), opts
+        ctx.sort_by_cell()
+        before = ctx.counters()
+        ctx.step(dt, 0.0, cycles)
+        name = ctx.step_kernel_name(0.0, 0)
+        xyzw, cell = ctx.get_particles()
+        after = ctx.counters()
+        assert want_kernel(opts) in name, (opts, name)
+        assert np.array_equal(cell, c), (opts, int((cell != c).sum()))
+        assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z), opts
+        assert after["cells_visited"] - before["cells_visited"] == int(stats[0]), opts
+        assert after["reflections"] - before["reflections"] == int(stats[1]), opts
+    return c
+
+
+def _kernel_for(opts):
+    if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
+        return "cpf::step_kernel<0,"
+    return ", 2>"                                   # step_kernel_stream<..., 2>: fixed compare + mixed records
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_refined_box_cells_with_9_to_21_faces(seed, oracle_libs, gpu_ctx_factory):
+    """A graded 3-D box with a 2:1-refined block in the middle: the unrefined cells around it have 9, 12, 15, 18 or 21
+    faces.  Random cell-constant field, steps that cross several cells and bounce off walls, 40 000 particles all over
+    the box (many start in and cross the many-faced cells)."""
+    from cudaparticlesfoam_amd.cases import refined_box
+    mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
+    off, _ = mesh.cell_faces()
+    nf = np.diff(off)
+    assert nf.max() >= 18 and (nf == 9).sum() > 20 and (nf == 6).sum() > 300
+    rng = np.random.default_rng(seed)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 2.0 + np.array([1.0, 0.3, -0.2])
+    xyz = rng.uniform([0, 0, 0], [8, 6, 5], size=(40000, 3))
+    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.15, 30,
+                  [dict(), dict(mixed_records=0), dict(step_variant=0), dict(stream_lookup=0)], _kernel_for)
+    assert (c >= 0).all() and (nf[c] > 6).sum() > 500          # every boundary reflects; many END in a many-faced cell
+
+
+def test_prism_cells_use_padded_records(oracle_libs, gpu_ctx_factory):
+    """Cells with FIVE faces (every hex of a box cut into two prisms): padded six-slot records, no CSR walk at all."""
+    mesh = _prism_box(7, 6, 5)
+    off, _ = mesh.cell_faces()
+    assert set(np.diff(off)) == {5}
+    rng = np.random.default_rng(11)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 1.5
+    xyz = rng.uniform([0, 0, 0], [7, 6, 5], size=(30000, 3))
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for)
+
+
+def test_refined_pitzdaily_1e6(oracle_libs, gpu_ctx_factory, pitz):
+    """pitzDaily with its first 60 mm behind the step refined 2 x 2 x 1 (26 247 cells, 87 of them with 7 faces), the
+    analytic step flow sampled at the new cell centres, 1e6 particles x 20 cycles of the tutorial's dt: bit-identical to
+    the CPU statement with the streaming kernel (mixed records) and with the generic walk."""
+    from cudaparticlesfoam_amd.cases import refined_pitzdaily
+    pz = pitz["pz"]
+    mesh, parent = refined_pitzdaily()
+    off, _ = mesh.cell_faces()
+    nf = np.diff(off)
+    assert mesh.n_cells == 26247 and (nf == 7).sum() == 87 and nf.max() == 7
+    centres, _ = mesh.cell_centres_volumes()
+    U = pz.analytic_step_u(mesh, centres)
+    xyz = pz.uniform_points(99, 1_400_000, *pz.DOMAIN_BOX)
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    c0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    xyz = xyz[c0 >= 0][:1_000_000]
+    assert xyz.shape[0] == 1_000_000
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1e-4, 20, [dict(), dict(step_variant=0)], _kernel_for)
+
+
+def test_mostly_polyhedral_mesh_keeps_the_generic_walk(oracle_libs, gpu_ctx_factory):
+    """Every cell with TEN faces (pairs of hexes of a box glued along x: convex, coplanar face pairs on four sides): more
+    than a quarter of the cells have more than six faces, so no records are built and the generic CSR walk runs."""
+    from cudaparticlesfoam_amd.cases import box_mesh, build_polymesh_from_cells
+    from cudaparticlesfoam_amd.cases.blockmesh import HEX_FACES
+    m0 = box_mesh(8, 3, 3)
+    cells = []
+    for c in range(0, m0.n_cells, 2):                          # cells are numbered i fastest: (c, c + 1) are x neighbours
+        a, b = m0.hexes[c], m0.hexes[c + 1]
+        loops = [tuple(int(v) for v in a[f]) for k, f in enumerate(HEX_FACES) if k != 1]       # all but a's x+ face
+        loops += [tuple(int(v) for v in b[f]) for k, f in enumerate(HEX_FACES) if k != 0]      # all but b's x- face
+        cells.append(loops)
+    mesh = build_polymesh_from_cells(m0.points, cells)
+    assert set(np.diff(mesh.cell_faces()[0])) == {10} and mesh.n_cells == 36
+    rng = np.random.default_rng(3)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 0.8
+    xyz = rng.uniform([0, 0, 0], [8, 3, 3], size=(20000, 3))
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict()], lambda o: "cpf::step_kernel<0,")
+
+
+def test_every_lane_of_a_tile_reflects_hit_pool_overflows(oracle_libs, gpu_ctx_factory):
+    """The streaming kernel parks wall hit points in a per-wave pool of 10 entries; further ones go to global memory.
+    A cloud driven into a corner of a box -- every particle hits a wall every cycle, most of them two or three walls --
+    overflows the pool in every tile, every cycle: still bit-identical to the CPU statement, single-cycle and fused
+    launches (where the pool is reset per cycle), both record lookups."""
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.cases import box_mesh
+    mesh = box_mesh(6, 5, 4)
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    U = np.tile([9.0, 7.0, 5.0], (mesh.n_cells, 1))               # dt * |U| = several cells: to the far corner and back
+    rng = np.random.default_rng(17)
+    xyz = rng.uniform([0.05, 0.05, 0.05], [5.95, 4.95, 3.95], size=(50000, 3))
+    c0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), c0.copy()
+    stats = cw.step(x, y, z, c, 0.9, 12, t, U, nthreads=cw.max_threads)
+    assert stats[1] > 12 * 50000                                 # more than one reflection per particle-step on average
+    for lookup in (0, 1):
+        for fused in (0, 1):
+            ctx = gpu_ctx_factory()
+            ctx.set_option("step_variant", 4); ctx.set_option("stream_lookup", lookup)
+            ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+            ctx.locate_initial(); ctx.sort_by_cell()
+            before = ctx.counters()
+            ctx.step(0.9, 0.0, 12, L.STEP_FUSE_CYCLES if fused else 0)
+            xyzw, cell = ctx.get_particles()
+            after = ctx.counters()
+            assert "step_kernel_stream" in ctx.step_kernel_name(0.0, 0)
+            assert np.array_equal(cell, c), (lookup, fused)
+            assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+            assert after["reflections"] - before["reflections"] == int(stats[1])
+            assert after["lost"] - before["lost"] == int(stats[2])

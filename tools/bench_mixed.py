@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): the step kernel on a mesh that is NOT all-hex -- pitzDaily with the first 60 mm behind the
+step refined 2 x 2 x 1 (26 247 cells, 87 of them with 7 faces at the rim of the patch) -- against (a) the same mesh on
+the generic CSR walk (what every such mesh ran on before round 3) and (b) the all-hex mesh of the same kind: pitzDaily
+refined 2 x 2 x 1 EVERYWHERE (48 900 cells).  1e7 particles, uniform U = (10,0,0), dt 1e-4, sorted cloud.
+python tools/bench_mixed.py [particles]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    import torch
+    import bench
+    from _spinup import device_spinup
+    from cudaparticlesfoam_amd.api import Context
+    from cudaparticlesfoam_amd.cases import pitzdaily as pz, refine_hexes, refined_pitzdaily
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+    dev = torch.device("cuda", 0)
+    m0 = pz.pitzdaily_mesh()
+    patch, _ = refined_pitzdaily()
+    every, _ = refine_hexes(m0.points, m0.hexes, np.ones(m0.n_cells, bool), split_z=False)
+    cases = [("pitzDaily, patch refined 2x2x1: mixed records (streaming kernel)", patch, {}),
+             ("same mesh, generic CSR walk", patch, {"mixed_records": 0}),
+             ("pitzDaily refined 2x2x1 everywhere: all-hex", every, {}),
+             ("pitzDaily as it is: all-hex", m0, {})]
+    base = None
+    for label, mesh, opts in cases:
+        ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(np.tile([10.0, 0.0, 0.0], (mesh.n_cells, 1)))
+        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+        g = torch.arange(n, dtype=torch.int64, device=dev)
+        p = lambda t: t.data_ptr()   # noqa: E731
+        ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
+        ctx.set_option("stats", 1)
+        c0 = ctx.counters()
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 0, 5, 0)
+        torch.cuda.synchronize()
+        c1 = ctx.counters()
+        ctx.set_option("stats", 0)
+        device_spinup(ctx, torch, x, y, z, c, n, 1e-4)
+        ctx.timing_enable(True); ctx.timing_read()
+        ctx.step_dev(p(x), p(y), p(z), p(c), None, None, n, 1e-4, 0.0, 5, 20, 0)
+        launches, ms = ctx.timing_read(); ctx.timing_enable(False)
+        k = ms / launches
+        nf = np.diff(mesh.cell_faces()[0])
+        row = dict(case=label, cells=mesh.n_cells, cells_with_more_than_6_faces=int((nf > 6).sum()), particles=n,
+                   kernel=ctx.step_kernel_name(0.0, 0), kernel_ms=round(k, 4), Gparticle_steps_per_s=round(n / k / 1e6, 2),
+                   roofline_GBs=round(56 * n / k / 1e6, 1),
+                   visits_per_particle_step=round((c1["cells_visited"] - c0["cells_visited"]) /
+                                                  max(1, c1["particle_steps"] - c0["particle_steps"]), 3))
+        print(json.dumps(row), flush=True)
+        ctx.close()
+        del x, y, z, c, g
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ OUT="gpurun_out/$LABEL"
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-BENCH="bench.py --no-cpu-baseline --steady-steps 0 --brownian-extra 0 --fused-extra 0"   # the bench command, timed region only (100 timed steps after 10 warm-up): the extras of the default run would mix other launches of the same kernel into the averages
+BENCH="bench.py --no-cpu-baseline --steady-steps 0 --brownian-extra 0 --fused-extra 0 --anchor-particles 0"   # the bench command, timed region only (100 timed steps after 10 warm-up): the extras of the default run would mix other launches of the same kernel into the averages
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH > "$OUT/bench_under_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $BENCH > "$OUT/pmc_write.log" 2>&1
