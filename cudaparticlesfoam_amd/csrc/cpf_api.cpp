@@ -454,6 +454,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     const int cycPerLaunch = fuse ? nCycles : 1;
     for (int c = 0; c < nLaunch; ++c) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool stamped = false;
         const bool timed = ctx->timing && (ctx->timingLaunch++ % (uint64_t)ctx->timingStride) == 0;
         if (timed) {
             auto take = [&](hipEvent_t& ev) -> hipError_t {
@@ -461,14 +462,22 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
                 return hipEventCreate(&ev);
             };
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
-            CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
+            // the streaming launcher stamps the events with the dispatch's own begin / end (cpf_device.h, StreamState);
+            // any other kernel is bracketed by two event records
+            stamped = cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
+            if (stamped) { ctx->streamState.evStart = e0; ctx->streamState.evStop = e1; }
+            else CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         ctx->lastStepN = n; ctx->lastStepCycles = cycPerLaunch;
         CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                       reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
                                       &ctx->streamState));
         if (timed) {
-            CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            if (!stamped) CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            else if (ctx->streamState.evStart != nullptr) {  // (cannot happen: the streaming launcher always takes them)
+                ctx->streamState.evStart = ctx->streamState.evStop = nullptr;
+                CPF_HIP(ctx, hipEventRecord(e0, ctx->stream)); CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            }
             ctx->events.emplace_back(e0, e1);
         }
     }

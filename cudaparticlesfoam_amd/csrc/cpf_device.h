@@ -37,6 +37,11 @@ constexpr size_t kStreamGrabBytes = 2 * 256 * 16 * sizeof(unsigned);
 constexpr int kStreamHitSpillDoubles = 3 * 64;          // x[64] | y[64] | z[64] per wave
 struct StreamState {
     unsigned* d_grab = nullptr;
+    // timing of ONE launch (cpf_timing_enable): set by the caller before launch_step, taken (and cleared) by the streaming
+    // launcher, which hands them to hipExtLaunchKernelGGL -- start and stop are then the dispatch's own begin / end time
+    // stamps, what rocprofv3's kernel trace reports, instead of events recorded around the launch (which also time the gap
+    // an event record puts between two otherwise back-to-back kernels: 5 % on a 0.12 ms kernel)
+    hipEvent_t evStart = nullptr, evStop = nullptr;
     double* d_hitSpill = nullptr;   // wall hit points that do not fit a wave's LDS pool: kStreamHitSpillDoubles per wave slot (cpf_stream.hip)
     int hitSpillWaves = 0;          // wave slots d_hitSpill has room for (the launcher never starts more single-wave workgroups)
     int parity = 0;

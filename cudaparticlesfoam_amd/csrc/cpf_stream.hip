@@ -28,6 +28,8 @@
 // slower on every mesh -- DESIGN.md 5.4.)
 #include "cpf_stream_ops.h"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace cpf {
@@ -659,6 +661,11 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     if (R * kStreamGroups > ss.hitSpillWaves) R = ss.hitSpillWaves / kStreamGroups;      // (never: the area is sized for the chip)
     if (R < 1 || ss.d_hitSpill == nullptr) return hipErrorInvalidValue;
     StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug, ss.d_hitSpill};
+    if (ss.evStart != nullptr && ss.evStop != nullptr) {
+        hipExtLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, ss.evStart,
+                              ss.evStop, 0, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
+        ss.evStart = ss.evStop = nullptr;                    // taken
+    } else
     hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
                        gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
     return stream_launch_done(st, ss);
