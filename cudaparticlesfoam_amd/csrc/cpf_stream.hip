@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 const bool gatherRound = __popcll(missLanes) >= kStreamGatherLanes;
                 if (busy) {
                     int next, outSlot = 0;
-                    double4 wallPlane = {0, 0, 0, 0};
+                    double4 wallPlane;                             // (assigned on every path that reads it: wherever a boundary face is met)
                     const bool needAdvect = token == INT32_MIN;
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
@@ -465,30 +465,31 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                                                 : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot, zLast);
                             if (STATS) ++st.hops;
                             if (REFLECT && next < 0) {
-                                // mirror end point and velocity about the wall (ConvexQuery.cu:286-309).  The wall's plane
-                                // is read HERE, where the record's address space is known (one expression choosing between
-                                // the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0), and E comes
-                                // from its parking slot -- it is there, from this round's advect or an earlier round -- so
-                                // that it need not stay in registers across the face tests.
-                                double4 wallPlane;
-                                if (LOOKUP_FIXED && mixed && bigCell) {
+                                // The wall's plane is read HERE, where the record's address space is known (one expression
+                                // choosing between the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0).
+                                if (mixed && bigCell) {
                                     wallPlane = m.planes[bigS0 + outSlot];
                                     asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));   // arrives HERE
                                 } else wallPlane = rec[outSlot];
+                                // E comes from its parking slot again -- it is there, from this round's advect or an earlier
+                                // round -- so that it need not stay in registers across the face tests
                                 asm volatile("" ::: "memory");
                                 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
-                                park_hit(S_);
-                                if (STATS) ++st.refl;
-                                const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
-                                const double sd = dot3(wallPlane, E) - wallPlane.w;
-                                E = axpy(-2.0 * sd, nn, E);
-                                sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                                v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
-                                token = next;
-                                h = 0;
-                                if (++j == kMaxReflect) { busy = false; next = cur; }   // still on a wall after 5 bounces: lost
-                                else if (kInRound) again = true;
-                                else next = kSitOut;                                    // walks on in the next round
+                                if (kInRound) {
+                                    // reflect INSIDE the round (CPF_STREAM_INROUND; measured slower): mirror here and
+                                    // walk on at once instead of in the next round
+                                    park_hit(S_);
+                                    if (STATS) ++st.refl;
+                                    const D3 nn = {wallPlane.x, wallPlane.y, wallPlane.z};
+                                    const double sd = dot3(wallPlane, E) - wallPlane.w;
+                                    E = axpy(-2.0 * sd, nn, E);
+                                    sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                                    v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
+                                    token = next;
+                                    h = 0;
+                                    if (++j == kMaxReflect) { busy = false; next = cur; }   // still on a wall after 5 bounces: lost
+                                    else again = true;
+                                }
                             }
                         } while (again);
                     } else {
@@ -527,11 +528,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             }
                         }
                     }
-                    if (next == cur) {
-                        busy = false;                                              // segment ends in this cell
-                    } else if (next < 0) {                                         // sitting this round out, or a boundary face met on the gather path
-                        if (next == kSitOut) {
-                        } else if (!REFLECT) { busy = false; j = kMaxReflect; token = next; }     // lost (token: the advect is done)
+                    // ---- what the visit led to.  The common outcomes -- the segment ends here, or it crosses into a neighbour --
+                    // are applied with selects, not branches: nested branches made the compiler shuttle cell, token and the two
+                    // counters between registers at every join (a dozen v_mov per round).  Only the wall is a branch (rare).
+                    const bool ends = next == cur;                                 // segment ends in this cell
+                    const bool wall = next < 0 && next != kSitOut;                 // a boundary face (kSitOut: no visit this round)
+                    const bool cross = next >= 0 && !ends;
+                    if (wall) {
+                        if (!REFLECT) j = kMaxReflect;                             // lost
                         else {
                             // mirror end point and velocity about the wall (ConvexQuery.cu:286-309); walks on next round
                             park_hit(S_);
@@ -541,15 +545,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             E = axpy(-2.0 * sd, nn, E);
                             sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                             v = axpy(-2.0 * dot3(wallPlane, v), nn, v);
-                            token = next;
                             h = 0;
-                            if (++j == kMaxReflect) busy = false;                      // still on a wall after 5 bounces: lost
+                            ++j;                                                   // j == 5: still on a wall after 5 bounces, lost
                         }
-                    } else {
-                        token = cur;
-                        cur = next;
-                        if (++h == kMaxHops) busy = false;                             // hop cap: keep the last cell
                     }
+                    token = cross ? cur : (wall ? next : token);                   // (a wall's code as token: the advect is done)
+                    cur = cross ? next : cur;
+                    h += cross ? 1 : 0;
+                    busy = !(ends || (cross && h == kMaxHops) || (wall && j >= kMaxReflect));   // hop cap: keep the last cell
                 }
             };
 
