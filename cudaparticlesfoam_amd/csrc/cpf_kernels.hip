@@ -345,8 +345,9 @@ int effective_step_variant(int variant, const MeshView& m, bool haveStream, int 
     }
     // Several cycles fused into one launch (CPF_STEP_FUSE_CYCLES: what advect.H does between two output points): the
     // particle stream is loaded and stored once per launch, so hiding it behind the walk buys nothing, and the
-    // wave-cooperative kernel's 8 waves per SIMD (the streaming kernel: 6) win -- measured per cycle, pitzDaily:
-    // 2 cycles per launch equal, 3: 5 %, 8: 10 %, 32: 13 %; 3-D bench mesh, 20 cycles: 15 %; TJunction: 1-5 %
+    // wave-cooperative kernel's 8 waves per SIMD (the streaming kernel: 7) win -- by less since round 3, measured per
+    // cycle on pitzDaily: 3 cycles per launch the streaming kernel is 4 % FASTER (0.0982 vs 0.1026 ms; with the Brownian
+    // kick 0.181 vs 0.190), 8 cycles 2 % slower (0.0930 vs 0.0911; kick: equal).  Round 2: 5 % slower at 3, 10 % at 8.
     if (variant == kVariantAuto)
         variant = (haveStream && !(cyclesPerLaunch >= kFusedCoopCycles && m.nCells <= coopMaxCells)) ? kVariantStream : kVariantCoop;
     if ((variant == kVariantStream || variant == kVariantAhead) && !haveStream) variant = kVariantCoop;

@@ -71,7 +71,7 @@ static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell)
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
-struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP == 2 ? 5 : 6) : CPF_STREAM_WAVES); };
+struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP == 2 ? 5 : 6) : (LOOKUP == 2 ? 6 : CPF_STREAM_WAVES)); };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
@@ -99,7 +99,11 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    constexpr int kPool = HIT_IN_REGS ? 1 : CPF_STREAM_HIT_POOL;
+    constexpr int kPool = HIT_IN_REGS ? 1 : (LOOKUP == 2 ? 16 : CPF_STREAM_HIT_POOL);
+    // mixed meshes: the faces of ONE cell with more than six faces, copied in by the whole wave (see the round)
+    constexpr int kBigFaces = 16;
+    __shared__ double4 sBigPl[LOOKUP == 2 ? kBigFaces : 1];
+    __shared__ int sBigNb[LOOKUP == 2 ? kBigFaces : 1];
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -417,26 +421,63 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 // wave pay a second trace (measured on the 3-D bench mesh: two of every three rounds did).  When many
                 // lanes are without a slot (a cloud that is not kept sorted) the gather walk keeps the wave moving.
                 const bool gatherRound = __popcll(missLanes) >= kStreamGatherLanes;
+                // advect (particles.cu:355-362) with the record's velocity: end point E, parked in the lane's E slot
+                auto advect = [&](const double4* rec) __attribute__((always_inline)) -> D3 {
+                    const double4 u = rec[6];
+                    v = {u.x, u.y, u.z};
+                    const D3 Pn = axpy(dt, v, S_);
+                    D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};           // not yet walked in this cycle: S_ is the position
+                    if (BROWNIAN) {                                               // the deviates drawn in the cycle's first round
+                        const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                        disp = axpy(sigma, xi, disp);
+                    }
+                    const D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
+                    sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
+                    return E;
+                };
+                // ---- (meshes that are not all-hex) lanes whose slot holds the HEADER record of a cell with more than six
+                // faces: one such cell at a time, the whole wave copies its CSR planes and neighbour ids into LDS -- one
+                // L2 round trip for the cell instead of one per face and lane -- and the cell's lanes walk them there, in
+                // CSR order, with the arithmetic of trace_in_cell.  Cells with more than kBigFaces faces (several refined
+                // neighbours) take the per-lane CSR walk further down.
+                bool bigLane = false, bigDone = false;
+                int bigS0 = 0, bigNf = 0, bigNext = 0, bigOut = 0;
+                if (mixed) {
+                    if (busy && myslot >= 0) {
+                        const int4 hdr = *reinterpret_cast<const int4*>(&slots[0][0] + myslot * kSlotStride + 7);
+                        bigLane = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
+                    }
+                    unsigned long long bigMask = ballot64(bigLane && bigNf <= kBigFaces);
+                    while (bigMask != 0ull) {
+                        const int leader = __ffsll((long long)bigMask) - 1;
+                        const int cb = __builtin_amdgcn_readlane(cur, leader);
+                        const unsigned s0 = (unsigned)__builtin_amdgcn_readlane(bigS0, leader), nf = (unsigned)__builtin_amdgcn_readlane(bigNf, leader);
+                        if (ul < 2u * nf) reinterpret_cast<double2*>(sBigPl)[ul] = reinterpret_cast<const double2*>(m.planes + s0)[ul];
+                        if (ul < nf) sBigNb[ul] = m.nbr[s0 + ul];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const bool mine = bigLane && cur == cb;
+                        if (mine) {
+                            D3 Eb = Epre;
+                            if (token == INT32_MIN) Eb = advect(&slots[0][0] + myslot * kSlotStride);
+                            bigNext = trace_lds_n(S_, Eb, cur, sBigPl, sBigNb, (int)nf, token, bigOut, m.cellOff, m.planes, m.nbr, (int)s0);
+                            bigDone = true;
+                            if (STATS) ++st.hops;
+                        }
+                        bigMask &= ~ballot64(mine);
+                        __builtin_amdgcn_wave_barrier();                               // the staging area is rewritten for the next cell
+                    }
+                }
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane;                             // (assigned on every path that reads it: wherever a boundary face is met)
-                    const bool needAdvect = token == INT32_MIN;
+                    const bool needAdvect = token == INT32_MIN && !(mixed && bigDone);
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
                     if (myslot >= 0) {
                         const double4* rec = &slots[0][0] + myslot * kSlotStride;
-                        if (needAdvect) {
-                            const double4 u = rec[6];
-                            v = {u.x, u.y, u.z};
-                            const D3 Pn = axpy(dt, v, S_);                             // particles.cu:355-362
-                            D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};   // not yet walked in this cycle: S_ is the position
-                            if (BROWNIAN) {                                            // the deviates drawn in the cycle's first round
-                                const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
-                                disp = axpy(sigma, xi, disp);
-                            }
-                            E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
-                            sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                        }
+                        if (needAdvect) E = advect(rec);
                         // ---- the visit, and -- in the same round -- the visits after a wall.  A wall hit never changes the
                         // cell and its record is in the slot already, so a lane that hits a wall mirrors its end point and
                         // walks on at once (the j < 5 loop of ConvexQuery.cu:353-409, which re-walks in the same `cur`)
@@ -444,26 +485,24 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // it.  ONE instance of the face tests inside a per-lane loop: from its second trip on only the
                         // reflecting lanes are active and most faces drop out wave-uniformly.  Same arithmetic in the same
                         // order as a round per reflection: bit-identical.
-                        // (a mesh that is not all-hex: is this the header record of a cell with more than six faces?)
-                        bool bigCell = false;
-                        int bigS0 = 0, bigNf = 0;
-                        if (LOOKUP_FIXED && mixed) {
-                            const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
-                            bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
-                        }
+                        const bool bigCell = mixed && bigLane;     // the header record of a cell with more than six faces
                         bool again;
                         do {
                             again = false;
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
-                            if (LOOKUP_FIXED && mixed && bigCell) {
-                                // more than six faces: the cell's CSR slots, from global memory (same test, same order)
-                                next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
-                            } else
+                            if (mixed && bigDone) {
+                                next = bigNext; outSlot = bigOut;              // walked above, from the staged copy of the cell's faces
+                            } else if (mixed && bigCell) {
+                                // more than kBigFaces faces: the cell's CSR slots, per lane from global memory (same test, same order)
+                                next = trace_csr(S_, E, cur, m.cellOff, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
+                                if (STATS) ++st.hops;
+                            } else {
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot, zLast);
                             if (STATS) ++st.hops;
+                            }
                             if (REFLECT && next < 0) {
                                 // The wall's plane is read HERE, where the record's address space is known (one expression
                                 // choosing between the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0).
@@ -498,24 +537,13 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         next = kSitOut;
                         if (gatherRound) {
                             const double4* rec = m.cellRec + 8 * (int64_t)cur;
-                            if (needAdvect) {
-                                const double4 u = rec[6];
-                                v = {u.x, u.y, u.z};
-                                const D3 Pn = axpy(dt, v, S_);
-                                D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};   // not yet walked in this cycle: S_ is the position
-                                if (BROWNIAN) {
-                                    const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
-                                    disp = axpy(sigma, xi, disp);
-                                }
-                                E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
-                                sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
-                            }
+                            if (needAdvect) E = advect(rec);
                             int gS0 = 0;
                             bool gBig = false;
                             if (LOOKUP_FIXED && mixed) {
                                 const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
                                 gBig = hdr.x == kBigCellMark; gS0 = hdr.y;
-                                if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
+                                if (gBig) { next = trace_csr(S_, E, cur, m.cellOff, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
                             }
                             if (!gBig)
                             next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);

@@ -33,6 +33,48 @@ constexpr double kTol = 1e-13;     // query/ConvexQuery.cu:42
 constexpr int kMaxHops = 50;       // query/ConvexQuery.cu:169
 constexpr int kMaxReflect = 5;     // query/ConvexQuery.cu:353
 
+// Cells with MORE THAN SIX faces (next to a 2:1 refinement) have COPLANAR faces -- the pieces of a split face share one
+// plane -- so the plane-exit test cannot tell which of them the segment leaves through: dT ties exactly, or within
+// rounding, and "the first face with the smallest dT" is usually the wrong neighbour.  No reference semantics exist for
+// such cells (src/initCuda.H:64: hexes only).  Two rules (stated independently in oracle/cellwalk.c):
+//   1. OUTWARD CROSSINGS ONLY (den < 0).  A particle that came in through one piece of a split face sits on the plane of
+//      its sibling pieces too, a rounding error outside it (fd = +4e-16), moving inward: the reference's acceptance test
+//      takes that for an exit at dT ~ 2e-13 > tol (in a hex only the entry face can look like this, and the token skips
+//      it).  A convex cell is left against the face's inward normal, so den < 0 loses no real exit.
+//   2. among the faces that pass the acceptance test with dT within kTie of the minimum, take the one whose NEIGHBOUR
+//      CELL holds the exit point X best -- the smallest maximum, over the neighbour's faces, of X's signed plane distance;
+//      a boundary face scores +inf; equal scores: the lower slot.  Always on the cell's CSR slots in global memory (a rare
+//      path: leaving a many-faced cell).
+constexpr double kTie = 1e-9;
+__device__ __forceinline__ void resolve_coplanar(const int32_t* __restrict__ cellOff, const double4* __restrict__ planes,
+                                                 const int32_t* __restrict__ nbr, int s0, int nf, const D3& P0, const D3& Pd,
+                                                 const D3& X, int token, double dTmin, int& next, int& best) {
+    double bestScore = 1e301;
+    int pick = best;
+    for (int s = 0; s < nf; ++s) {
+        const double4 pl = planes[s0 + s];
+        const int nb = nbr[s0 + s];
+        const double fd = plane_dist(pl, P0), den = dot3(pl, Pd);
+        double dT = fd / den;
+        if (__builtin_isinf(dT)) dT = -1.0;
+        if (nb == token) continue;
+        if (!(den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0)) continue;
+        if (dT - dTmin > kTie) continue;
+        double score = 1e300;                               // boundary face
+        if (nb >= 0) {
+            score = -1e300;
+            const int q0 = cellOff[nb], q1 = cellOff[nb + 1];
+            for (int q = q0; q < q1; ++q) {
+                const double d = plane_dist(planes[q], X);
+                if (d > score) score = d;
+            }
+        }
+        if (score < bestScore) { bestScore = score; pick = s; }
+    }
+    next = nbr[s0 + pick];
+    best = pick;
+}
+
 // One cell of the walk: traceIntet (query/ConvexQuery.cu:32-131) on a polyhedral cell.
 // Exit through the face slot with the smallest admissible dT in (tol, 1]; the slot we came in
 // through (nbr == token) is skipped.  Returns the next cell (== cur: segment ends here; < 0:
@@ -41,22 +83,29 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
                                              int& outSlot) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
-    int next = cur;
+    int next = cur, best = -1;
     double dTmin = 1.1;
     const int s0 = m.cellOff[cur], s1 = m.cellOff[cur + 1];
+    const bool big = s1 - s0 > 6;
     for (int s = s0; s < s1; ++s) {
         const double4 pl = m.planes[s];
         const double fd = plane_dist(pl, P0);           // (Cf - P0).n  (<= 0 inside)
-        double dT = fd / dot3(pl, Pd);
+        const double den = dot3(pl, Pd);
+        double dT = fd / den;
         if (__builtin_isinf(dT)) dT = -1.0;             // segment parallel to the face
         const int nb = m.nbr[s];
         if (nb == token) continue;
+        if (big && !(den < 0.0)) continue;              // many-faced cells: outward crossings only (see above)
         if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) {
             dTmin = dT;
             next = nb;
             S = axpy(dT, Pd, P0);
-            outSlot = s;
+            best = s - s0;
         }
+    }
+    if (best >= 0) {
+        if (s1 - s0 > 6) resolve_coplanar(m.cellOff, m.planes, m.nbr, s0, s1 - s0, P0, Pd, S, token, dTmin, next, best);
+        outSlot = s0 + best;
     }
     return next;
 }
@@ -241,8 +290,9 @@ constexpr int kNullNbr = INT32_MIN + 5;
 constexpr int kBigCellMark = INT32_MIN + 6;
 
 // trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0
-__device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const double4* __restrict__ planes,
-                                         const int32_t* __restrict__ nbr, int s0, int nf, int token, int& outSlot) {
+__device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const int32_t* __restrict__ cellOff,
+                                         const double4* __restrict__ planes, const int32_t* __restrict__ nbr, int s0, int nf,
+                                         int token, int& outSlot) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
@@ -250,13 +300,43 @@ __device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const doub
     for (int s = 0; s < nf; ++s) {
         const double4 pl = planes[s0 + s];
         const int nb = nbr[s0 + s];
-        const double fd = plane_dist(pl, P0);
-        double dT = fd / dot3(pl, Pd);
+        const double fd = plane_dist(pl, P0), den = dot3(pl, Pd);
+        double dT = fd / den;
         if (__builtin_isinf(dT)) dT = -1.0;
         if (nb == token) continue;
-        if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
+        if (den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
     }
-    if (best >= 0) { S = axpy(dTmin, Pd, P0); outSlot = best; }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        resolve_coplanar(cellOff, planes, nbr, s0, nf, P0, Pd, S, token, dTmin, next, best);
+        outSlot = best;
+    }
+    return next;
+}
+
+// the same walk over nf faces staged in LDS (planes as double4, neighbour ids as int32): every lane of one cell reads the
+// same addresses (broadcast reads)
+__device__ __forceinline__ int trace_lds_n(D3& S, const D3& E, int cur, const double4* planes, const int* nbr, int nf, int token,
+                                           int& outSlot, const int32_t* __restrict__ cellOff, const double4* __restrict__ gPlanes,
+                                           const int32_t* __restrict__ gNbr, int s0) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 1.1;
+    for (int s = 0; s < nf; ++s) {
+        const double4 pl = planes[s];
+        const int nb = nbr[s];
+        const double fd = plane_dist(pl, P0), den = dot3(pl, Pd);
+        double dT = fd / den;
+        if (__builtin_isinf(dT)) dT = -1.0;
+        if (nb == token) continue;
+        if (den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
+    }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        resolve_coplanar(cellOff, gPlanes, gNbr, s0, nf, P0, Pd, S, token, dTmin, next, best);
+        outSlot = best;
+    }
     return next;
 }
 

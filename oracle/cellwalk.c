@@ -123,26 +123,76 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
     return cellOff[nCells];
 }
 
+#define CW_TIE 1e-9        /* two exit parameters dT closer than this count as a tie (cells with more than six faces) */
+
 /* One cell of the walk (traceIntet on a polyhedral cell).  `token` identifies the face we came
- * in through: the previous cell id after a hop, the boundary code after a reflection. */
+ * in through: the previous cell id after a hop, the boundary code after a reflection.
+ *
+ * Cells with MORE THAN SIX faces (next to a 2:1 refinement) have COPLANAR faces -- the four (two) pieces of a split face
+ * share one plane -- so the plane-exit test cannot tell which of them the segment leaves through: dT ties exactly (or
+ * within rounding, where the pieces' planes were computed from different vertices) and "the first face with the smallest
+ * dT" is usually the wrong neighbour.  No reference semantics exist for such cells (src/initCuda.H:64: hexes only;
+ * OpenFOAM's own tracking walks the cell's tet decomposition, where the pieces belong to different tets).  Two rules,
+ * stated here and in the kernels (csrc/cpf_walk.h) alike, for cells with more than six faces only:
+ *   1. outward crossings only (n.Pd < 0 for the inward-signed plane): a particle that came in through one piece of a
+ *      split face lies on the plane of the sibling pieces too, a rounding error outside (fd = +4e-16) and moving inward,
+ *      which the reference's acceptance test takes for an exit at dT ~ 2e-13 > tol; in a hex only the entry face can look
+ *      like that and the token skips it.  A convex cell is only ever left with n.Pd < 0.
+ *   2. among the faces that pass the acceptance test with dT within CW_TIE of the minimum, take the one whose NEIGHBOUR
+ *      CELL holds the exit point best -- the smallest maximum, over the neighbour's faces, of the exit point's signed
+ *      plane distance; a boundary face scores +inf (it only wins where no internal face competes); equal scores: the
+ *      lower slot.
+ * Cells with up to six faces keep the reference's rule (first smallest dT). */
 static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const double* planes, const int* nbr,
                          int token, int* outSlot) {
     const v3 P0 = *Ps;
     const v3 Pd = sub(Pe, P0);
-    int next = cur;
+    int next = cur, best = -1;
     double dTmin = 1.1;
+    const int big = cellOff[cur + 1] - cellOff[cur] > 6;
     for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
         v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
         double fd = plane_dist(n, planes[4 * s + 3], P0);  /* (Cf - P0).n, <= 0 inside */
-        double dT = fd / dotf(n, Pd);
+        double den = dotf(n, Pd);
+        double dT = fd / den;
         if (isinf(dT)) dT = -1.0;
         if (nbr[s] == token) continue;
+        if (big && !(den < 0.0)) continue;                 /* rule 1 */
         if (fd < CW_TOL && dT > CW_TOL && dT <= 1.0 && dT < dTmin) {
             dTmin = dT;
             next = nbr[s];
             *Ps = axpy(dT, Pd, P0);
             *outSlot = s;
+            best = s;
         }
+    }
+    if (best >= 0 && cellOff[cur + 1] - cellOff[cur] > 6) {
+        const v3 X = *Ps;                                   /* the exit point */
+        double bestScore = 1e301;
+        int pick = best;
+        for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
+            v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
+            double fd = plane_dist(n, planes[4 * s + 3], P0);
+            double den = dotf(n, Pd);
+            double dT = fd / den;
+            if (isinf(dT)) dT = -1.0;
+            if (nbr[s] == token) continue;
+            if (!(den < 0.0)) continue;
+            if (!(fd < CW_TOL && dT > CW_TOL && dT <= 1.0)) continue;
+            if (dT - dTmin > CW_TIE) continue;
+            double score = 1e300;                           /* boundary face */
+            const int nb = nbr[s];
+            if (nb >= 0) {
+                score = -1e300;
+                for (int q = cellOff[nb]; q < cellOff[nb + 1]; ++q) {
+                    const double d = plane_dist(V(planes[4 * q], planes[4 * q + 1], planes[4 * q + 2]), planes[4 * q + 3], X);
+                    if (d > score) score = d;
+                }
+            }
+            if (score < bestScore) { bestScore = score; pick = s; }
+        }
+        next = nbr[pick];
+        *outSlot = pick;
     }
     return next;
 }

@@ -8,6 +8,8 @@ six faces, header records + CSR walk for cells with more), or the generic CSR wa
 import numpy as np
 import pytest
 
+from test_oracle_mixed import worst_outside
+
 pytestmark = pytest.mark.gpu
 
 
@@ -30,6 +32,8 @@ def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, w
     ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
     x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
     stats = cw.step(x, y, z, c, dt, cycles, t, U, nthreads=cw.max_threads)
+    alive = c >= 0                                  # the walk's own invariant: everybody inside the cell they claim
+    assert worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive]).max() <= 1e-9
     for opts in options:
         ctx = gpu_ctx_factory()
         for k, v in opts.items():
@@ -160,3 +164,33 @@ def test_every_lane_of_a_tile_reflects_hit_pool_overflows(oracle_libs, gpu_ctx_f
             assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
             assert after["reflections"] - before["reflections"] == int(stats[1])
             assert after["lost"] - before["lost"] == int(stats[2])
+
+
+def test_diffusion_on_a_mixed_mesh_loses_nobody(oracle_libs, gpu_ctx_factory):
+    """The Brownian kick on the refined box (the LOOKUP = 2 instantiation with the kick, hit points in the per-wave pool):
+    parity with the CPU statement is statistical there, so the check is the domain's own -- every boundary reflects, so
+    after 60 kicked cycles nobody is lost and every particle lies inside the cell it claims (all plane distances <= 0),
+    many-faced cells included."""
+    from cudaparticlesfoam_amd.cases import refined_box
+    mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    rng = np.random.default_rng(23)
+    n = 200_000
+    xyz = rng.uniform([0, 0, 0], [8, 6, 5], size=(n, 3))
+    U = rng.normal(size=(mesh.n_cells, 3)) * 0.5
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+    assert ctx.locate_initial() == 0
+    ctx.sort_by_cell()
+    before = ctx.counters()
+    ctx.step(0.05, 0.4, 60)                                        # sigma = sqrt(2 D dt) = 0.2 cell widths per cycle
+    assert ", 2>" in ctx.step_kernel_name(0.4, 0)
+    xyzw, cell = ctx.get_particles()
+    after = ctx.counters()
+    assert (cell >= 0).all() and after["lost"] == before["lost"] and after["reflections"] > before["reflections"]
+    nf = np.diff(t.cell_off)
+    assert (nf[cell] > 6).sum() > 1000                             # plenty of them ended in a many-faced cell
+    w = worst_outside(t, xyzw[:, :3], cell)
+    assert w.max() <= 1e-9, (int((w > 1e-9).sum()), float(w.max()))
+    assert float(np.abs(xyzw[:, :3] - xyz).max()) > 0.5            # they did move

@@ -188,7 +188,7 @@ def test_fused_cycles_and_sort_do_not_change_results(setup, gpu_ctx_factory):
 
 
 def test_kernel_choice_per_launch(setup):
-    """Default step_variant -1: single-cycle launches run the streaming kernel, launches that fuse three or more cycles
+    """Default step_variant -1: single-cycle launches run the streaming kernel, launches that fuse eight or more cycles
     the wave-cooperative one (faster there); an explicit variant is obeyed.  Results are the same either way."""
     from cudaparticlesfoam_amd import _lib as L
     pz, ctx = setup["pz"], setup["ctx"]
@@ -228,7 +228,7 @@ def test_coop_kernel_cell_limit_guard(setup):
         for variant in (3, -1):
             ctx.set_option("step_variant", variant)
             ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
-            ctx.step(1e-4, 0.0, 6, L.STEP_FUSE_CYCLES)
+            ctx.step(1e-4, 0.0, 9, L.STEP_FUSE_CYCLES)
             names.append(ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES))
             got.append(ctx.get_particles())
         assert all(("step_kernel_coop" in nm) == (limit == 0) for nm in names), names

@@ -29,14 +29,30 @@ def main():
              ("same mesh, generic CSR walk", patch, {"mixed_records": 0}),
              ("pitzDaily refined 2x2x1 everywhere: all-hex", every, {}),
              ("pitzDaily as it is: all-hex", m0, {})]
-    base = None
-    for label, mesh, opts in cases:
+    if os.environ.get("CPF_MIXED_3D", "1") != "0":
+        # a 3-D mesh: graded 40 x 40 x 40 box with its central 20 x 20 x 20 block refined 2 x 2 x 2 (120 000 cells, the
+        # ~2 400 unrefined cells around the block have 9 ... 21 faces), swirling field, particles over the whole box
+        from cudaparticlesfoam_amd.cases import box_mesh, refined_box
+        lo3, hi3 = (0.0, 0.0, 0.0), (0.3, 0.05, 0.05)
+        b3, _ = refined_box(40, 40, 40, lo3, hi3, ((0.075, 0.0125, 0.0125), (0.225, 0.0375, 0.0375)), grading=(2.0, 1.0, 0.5))
+        h3 = box_mesh(49, 49, 50, lower=lo3, upper=hi3, grading=(2.0, 1.0, 0.5))          # all-hex, about the same cell count
+        cases += [("3-D box, central block refined 2x2x2: mixed records", b3, {}, (lo3, hi3)),
+                  ("same mesh, generic CSR walk", b3, {"mixed_records": 0}, (lo3, hi3)),
+                  ("3-D box of the same cell count: all-hex", h3, {}, (lo3, hi3))]
+    for case in cases:
+        label, mesh, opts = case[:3]
+        box3 = case[3] if len(case) > 3 else None
         ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.set_mesh(mesh)
-        ctx.set_velocity(np.tile([10.0, 0.0, 0.0], (mesh.n_cells, 1)))
-        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+        if box3 is None:
+            ctx.set_velocity(np.tile([10.0, 0.0, 0.0], (mesh.n_cells, 1)))
+            x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+        else:
+            cc, _ = mesh.cell_centres_volumes()
+            ctx.set_velocity(np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1))
+            x, y, z, c = bench.seed_in_fluid(ctx, torch, n, box3, 1000, dev)
         g = torch.arange(n, dtype=torch.int64, device=dev)
         p = lambda t: t.data_ptr()   # noqa: E731
         ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
