@@ -106,6 +106,15 @@ class Context:
         self._ck(self.lib.cpf_get_mesh_tables(self.h, _ptr(off), _ptr(planes), _ptr(nbr)))
         return off, planes, nbr
 
+    def mesh_groups(self):
+        """Face groups of the mesh (coplanar faces of a cell that lead to different cells share one slot): (group_off
+        [n_groups + 1], group_nbr); slot neighbour id INT32_MIN + 16 + g marks group g."""
+        ng, nm = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.cpf_get_mesh_groups(self.h, C.byref(ng), C.byref(nm), None, None))
+        off = np.zeros(ng.value + 1, np.int32); nbr = np.zeros(max(nm.value, 1), np.int32)
+        self._ck(self.lib.cpf_get_mesh_groups(self.h, None, None, _ptr(off), _ptr(nbr)))
+        return off, nbr[:nm.value]
+
     def set_velocity(self, U):
         U = np.ascontiguousarray(U, dtype=np.float64)
         if U.ndim != 2 or U.shape[1] != 3:

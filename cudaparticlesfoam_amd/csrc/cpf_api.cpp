@@ -26,6 +26,7 @@ struct cpf_context {
     int32_t* d_cellOff = nullptr;
     double4* d_planes = nullptr;
     int32_t* d_nbr = nullptr;
+    int32_t *d_groupOff = nullptr, *d_groupNbr = nullptr;
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes)
@@ -113,9 +114,10 @@ void freeDev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 cpf::MeshView meshView(const cpf_context* c) {
     cpf::MeshView m;
     m.cellOff = c->d_cellOff; m.planes = c->d_planes; m.nbr = c->d_nbr; m.U = c->d_U;
+    m.groupOff = c->d_groupOff; m.groupNbr = c->d_groupNbr;
     m.cellRec = c->d_cellRec;
     m.nCells = (int32_t)c->host.nCells;
-    m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6) ? 1 : 0;
+    m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
     m.mixed = (c->d_cellRec && !m.allHex) ? 1 : 0;
     return m;
@@ -147,7 +149,7 @@ int sortEndBit(const cpf_context* ctx) {
 }
 
 void freeMesh(cpf_context* c) {
-    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_cellBox);
+    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_groupOff); freeDev(c->d_groupNbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_cellBox);
     freeDev(c->d_binOff); freeDev(c->d_binCells);
     c->haveMesh = c->haveU = false; c->meshBytes = 0;
 }
@@ -182,21 +184,24 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     CPF_HIP(ctx, up(ctx->d_cellOff, h.cellOff.data(), h.cellOff.size() * 4));
     CPF_HIP(ctx, up(ctx->d_planes, h.planes.data(), h.planes.size() * 8));
     CPF_HIP(ctx, up(ctx->d_nbr, h.nbr.data(), h.nbr.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_groupOff, h.groupOff.data(), h.groupOff.size() * 4));
+    CPF_HIP(ctx, up(ctx->d_groupNbr, h.groupNbr.data(), h.groupNbr.size() * 4));
     CPF_HIP(ctx, up(ctx->d_binOff, h.binOff.data(), h.binOff.size() * 4));
     CPF_HIP(ctx, up(ctx->d_binCells, h.binCells.data(), h.binCells.size() * 4));
     CPF_HIP(ctx, up(ctx->d_cellBox, h.cellBox.data(), h.cellBox.size() * 4));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U, (size_t)nCells * sizeof(double4)));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_U3, (size_t)nCells * 3 * sizeof(double)));
     CPF_HIP(ctx, hipMemset(ctx->d_U, 0, (size_t)nCells * sizeof(double4)));
-    if (ctx->host.minCellFaces == 6 && ctx->host.maxCellFaces == 6) {
+    if (ctx->host.minCellFaces == 6 && ctx->host.maxCellFaces == 6 && ctx->host.nGroups() == 0) {
         CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
         CPF_HIP(ctx, cpf::launch_build_cell_records(ctx->stream, ctx->d_planes, ctx->d_nbr, ctx->d_U, ctx->d_cellRec, nCells));
         CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->meshBytes += (size_t)nCells * 256;
     } else if (ctx->host.nBigCells * 4 <= nCells && ctx->mixedRecords) {
-        // not all-hex, but at most a quarter of the cells have more than six faces (a hex-dominant mesh with refinement
-        // interfaces, prism layers, ...): records for the streaming kernel, padded / header-only where a cell has not
-        // exactly six faces (cpf_walk.h "cell records").  Meshes of mostly polyhedral cells keep the generic CSR walk.
+        // not all-hex, but at most a quarter of the cells have more than six slots (a hex-dominant mesh with refinement
+        // interfaces -- whose split faces are face groups, one slot each --, prism layers, a few polyhedra ...): records
+        // for the streaming kernel, padded / header-only where a cell has not exactly six slots (cpf_walk.h "cell
+        // records").  Meshes of mostly polyhedral cells keep the generic CSR walk.
         CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
         CPF_HIP(ctx, cpf::launch_build_cell_records_mixed(ctx->stream, ctx->d_cellOff, ctx->d_planes, ctx->d_nbr, ctx->d_U,
                                                           ctx->d_cellRec, nCells));
@@ -333,6 +338,18 @@ int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes
     if (cellOff) std::memcpy(cellOff, h.cellOff.data(), h.cellOff.size() * 4);
     if (planes) std::memcpy(planes, h.planes.data(), h.planes.size() * 8);
     if (nbr) std::memcpy(nbr, h.nbr.data(), h.nbr.size() * 4);
+    return CPF_OK;
+}
+
+int cpf_get_mesh_groups(const cpf_context* ctx, int64_t* nGroups, int64_t* nMembers, int32_t* groupOff, int32_t* groupNbr) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_get_mesh_groups: no mesh set");
+    const cpf::HostTables& h = ctx->host;
+    const int64_t g = h.nGroups();
+    if (nGroups) *nGroups = g;
+    if (nMembers) *nMembers = h.groupOff[(size_t)g];
+    if (groupOff) std::memcpy(groupOff, h.groupOff.data(), (size_t)(g + 1) * 4);
+    if (groupNbr) std::memcpy(groupNbr, h.groupNbr.data(), (size_t)h.groupOff[(size_t)g] * 4);
     return CPF_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "cpf.h"
+#include "cpf_internal.h"   // kGroupBase
 
 namespace cpf {
 
@@ -15,13 +16,15 @@ constexpr int kCounterSlots = 1024;   // statistics counters are sharded over th
 struct MeshView {
     const int32_t* cellOff;   // [nCells+1]
     const double4* planes;    // [nSlots]   (nx, ny, nz, d), unit normal into the cell
-    const int32_t* nbr;       // [nSlots]
+    const int32_t* nbr;       // [nSlots]   neighbour cell | -(face + 1) on the boundary | kGroupBase + g: face group g (cpf_mesh.cpp)
+    const int32_t* groupOff;  // [nGroups+1] face groups: the cells behind the coplanar pieces of one slot, in face order
+    const int32_t* groupNbr;
     const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
     const double4* cellRec;   // [nCells][8] packed 256-B records (null: generic walk only); layout: cpf_walk.h "cell records"
     int32_t nCells;
-    int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s)
+    int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s) and there are no face groups
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
-    int32_t mixed;            // records exist although not every cell has 6 faces: padded (< 6) and header-only (> 6) records
+    int32_t mixed;            // records exist although the mesh is not all-hex: padded (< 6 slots) and header-only (> 6) records, face groups
 };
 
 struct GridView {

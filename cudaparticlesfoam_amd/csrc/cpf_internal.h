@@ -8,19 +8,27 @@
 
 namespace cpf {
 
+// neighbour code of face group g; boundary codes -(face + 1) stay above -(2^30), group codes and the walk's few special
+// values (INT32_MIN ... INT32_MIN + 15) below
+constexpr int32_t kGroupBase = INT32_MIN + 16;
+
 // Host-built connectivity, laid out exactly as it is uploaded (DESIGN.md "Data layout in HBM").
 struct HostTables {
     int64_t nCells = 0, nSlots = 0;
+    // one slot per distinct PLANE of a cell (cpf_mesh.cpp: coplanar faces of a cell share a slot)
     std::vector<int32_t> cellOff;   // [nCells+1]   CSR offsets, slot order = mesh.cells()[c] (z-layered meshes: z faces last, see zPairLast)
     std::vector<double> planes;     // [nSlots][4]  unit normal INTO the cell, d = n . faceCentre
-    std::vector<int32_t> nbr;       // [nSlots]     neighbour cell, or -(face+1) on the boundary
+    std::vector<int32_t> nbr;       // [nSlots]     neighbour cell, or -(face+1) on the boundary, or kGroupBase + g: face group g
+    std::vector<int32_t> groupOff;  // [nGroups+1]  face groups: the cells behind the coplanar pieces of one slot ...
+    std::vector<int32_t> groupNbr;  // ... in face order
     // uniform bin grid over the mesh bounding box for the initial locate
     double origin[3] = {0, 0, 0}, invBin[3] = {0, 0, 0}, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int32_t dims[3] = {1, 1, 1};
     std::vector<int32_t> binOff;    // [nBins+1]
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
-    int32_t maxCellFaces = 0, minCellFaces = 0;
-    int64_t nBigCells = 0;          // cells with more than 6 faces
+    int32_t maxCellFaces = 0, minCellFaces = 0;   // slots per cell
+    int64_t nBigCells = 0;          // cells with more than 6 slots
+    int64_t nGroups() const { return (int64_t)groupOff.size() - 1; }
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes

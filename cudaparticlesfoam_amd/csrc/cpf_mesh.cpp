@@ -84,9 +84,6 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
     for (int64_t c = 0; c < nCells; ++c) {
         int32_t k = out.cellOff[(size_t)c + 1];
         if (k < 4) return "cell " + std::to_string(c) + " has fewer than 4 faces";
-        out.maxCellFaces = std::max(out.maxCellFaces, k);
-        if (k > 6) ++out.nBigCells;
-        out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
         out.cellOff[(size_t)c + 1] += out.cellOff[(size_t)c];
     }
     out.planes.resize((size_t)out.nSlots * 4);
@@ -120,6 +117,66 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
                                            : (int32_t)owner[f];
             grow(c, v, nv);
         }
+    }
+
+    // ---- one slot per distinct PLANE of a cell.  Next to a 2:1 refinement a cell holds the four (two) pieces of a split
+    // face, all in one plane; the plane-exit test cannot tell which piece a segment leaves through (their exit parameters
+    // tie, exactly or within rounding), and a particle that came in through one piece sits on its siblings' plane.  So
+    // the faces of a cell that share a plane share a slot: going through the cell's faces in order, a face joins the
+    // first earlier slot of the same kind (internal / boundary) whose plane matches -- each normal component within
+    // kCoplanar, the offsets within kCoplanar * (1 + |d|) -- or else opens the next slot with its own plane.  A boundary
+    // slot keeps its first face's code (all boundary faces reflect alike).  An internal slot with several faces becomes a
+    // FACE GROUP: neighbour code kGroupBase + g, the pieces' cells listed in groupNbr[groupOff[g] ..) in face order;
+    // the walk picks the piece at the exit point (cpf_walk.h, resolve_group).  The reference has no such cells
+    // (src/initCuda.H:64, hexes only); the rule is this repo's, stated here and in oracle/cellwalk.c independently.
+    // A mesh without coplanar faces -- every hex mesh -- passes through unchanged.
+    {
+        constexpr double kCoplanar = 1e-9;
+        if (nFaces >= (int64_t(1) << 30) - 1) return "mesh too large: face ids must stay below 2^30 (face-group codes)";
+        out.groupOff.assign(1, 0);
+        int64_t w = 0;                                       // compacted write position (never ahead of the read position)
+        std::vector<std::pair<int32_t, int32_t>> members;    // (slot, neighbour cell) of the cell's internal faces, face order
+        for (int64_t c = 0; c < nCells; ++c) {
+            const int64_t s0 = out.cellOff[(size_t)c], s1 = out.cellOff[(size_t)c + 1], w0 = w;
+            members.clear();
+            for (int64_t s = s0; s < s1; ++s) {
+                const double* q = &out.planes[4 * (size_t)s];
+                const int32_t nb = out.nbr[(size_t)s];
+                int64_t slot = -1;
+                for (int64_t r = w0; r < w && slot < 0; ++r) {
+                    const double* p = &out.planes[4 * (size_t)r];
+                    if ((out.nbr[(size_t)r] >= 0) != (nb >= 0)) continue;
+                    const bool same = std::fabs(q[0] - p[0]) <= kCoplanar && std::fabs(q[1] - p[1]) <= kCoplanar &&
+                                      std::fabs(q[2] - p[2]) <= kCoplanar && std::fabs(q[3] - p[3]) <= kCoplanar * (1.0 + std::fabs(p[3]));
+                    if (same) slot = r;
+                }
+                if (slot < 0) {
+                    std::memmove(&out.planes[4 * (size_t)w], q, 4 * sizeof(double));
+                    out.nbr[(size_t)w] = nb;
+                    slot = w++;
+                }
+                if (nb >= 0) members.emplace_back((int32_t)slot, nb);
+            }
+            for (int64_t r = w0; r < w; ++r) {
+                if (out.nbr[(size_t)r] < 0) continue;
+                int k = 0;
+                for (const auto& mb : members) k += mb.first == (int32_t)r;
+                if (k < 2) continue;
+                for (const auto& mb : members) if (mb.first == (int32_t)r) out.groupNbr.push_back(mb.second);
+                out.nbr[(size_t)r] = kGroupBase + (int32_t)(out.groupOff.size() - 1);
+                out.groupOff.push_back((int32_t)out.groupNbr.size());
+            }
+            out.cellOff[(size_t)c] = (int32_t)w0;
+            const int32_t k = (int32_t)(w - w0);
+            out.maxCellFaces = std::max(out.maxCellFaces, k);
+            if (k > 6) ++out.nBigCells;
+            out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
+        }
+        out.cellOff[(size_t)nCells] = (int32_t)w;
+        out.nSlots = w;
+        out.planes.resize((size_t)w * 4);
+        out.nbr.resize((size_t)w);
+        if (out.groupNbr.empty()) out.groupNbr.push_back(0);   // (uploads want a non-empty table)
     }
 
     // ---- z-layered meshes: the two z faces of every cell go LAST.  If every cell has exactly six faces of which exactly

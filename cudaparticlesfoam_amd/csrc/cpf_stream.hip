@@ -100,10 +100,6 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
     constexpr int kPool = HIT_IN_REGS ? 1 : (LOOKUP == 2 ? 16 : CPF_STREAM_HIT_POOL);
-    // mixed meshes: the faces of ONE cell with more than six faces, copied in by the whole wave (see the round)
-    constexpr int kBigFaces = 16;
-    __shared__ double4 sBigPl[LOOKUP == 2 ? kBigFaces : 1];
-    __shared__ int sBigNb[LOOKUP == 2 ? kBigFaces : 1];
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -435,44 +431,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                     return E;
                 };
-                // ---- (meshes that are not all-hex) lanes whose slot holds the HEADER record of a cell with more than six
-                // faces: one such cell at a time, the whole wave copies its CSR planes and neighbour ids into LDS -- one
-                // L2 round trip for the cell instead of one per face and lane -- and the cell's lanes walk them there, in
-                // CSR order, with the arithmetic of trace_in_cell.  Cells with more than kBigFaces faces (several refined
-                // neighbours) take the per-lane CSR walk further down.
-                bool bigLane = false, bigDone = false;
-                int bigS0 = 0, bigNf = 0, bigNext = 0, bigOut = 0;
-                if (mixed) {
-                    if (busy && myslot >= 0) {
-                        const int4 hdr = *reinterpret_cast<const int4*>(&slots[0][0] + myslot * kSlotStride + 7);
-                        bigLane = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
-                    }
-                    unsigned long long bigMask = ballot64(bigLane && bigNf <= kBigFaces);
-                    while (bigMask != 0ull) {
-                        const int leader = __ffsll((long long)bigMask) - 1;
-                        const int cb = __builtin_amdgcn_readlane(cur, leader);
-                        const unsigned s0 = (unsigned)__builtin_amdgcn_readlane(bigS0, leader), nf = (unsigned)__builtin_amdgcn_readlane(bigNf, leader);
-                        if (ul < 2u * nf) reinterpret_cast<double2*>(sBigPl)[ul] = reinterpret_cast<const double2*>(m.planes + s0)[ul];
-                        if (ul < nf) sBigNb[ul] = m.nbr[s0 + ul];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const bool mine = bigLane && cur == cb;
-                        if (mine) {
-                            D3 Eb = Epre;
-                            if (token == INT32_MIN) Eb = advect(&slots[0][0] + myslot * kSlotStride);
-                            bigNext = trace_lds_n(S_, Eb, cur, sBigPl, sBigNb, (int)nf, token, bigOut, m.cellOff, m.planes, m.nbr, (int)s0);
-                            bigDone = true;
-                            if (STATS) ++st.hops;
-                        }
-                        bigMask &= ~ballot64(mine);
-                        __builtin_amdgcn_wave_barrier();                               // the staging area is rewritten for the next cell
-                    }
-                }
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane;                             // (assigned on every path that reads it: wherever a boundary face is met)
-                    const bool needAdvect = token == INT32_MIN && !(mixed && bigDone);
+                    const bool needAdvect = token == INT32_MIN;
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
                     if (myslot >= 0) {
@@ -485,22 +447,26 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // it.  ONE instance of the face tests inside a per-lane loop: from its second trip on only the
                         // reflecting lanes are active and most faces drop out wave-uniformly.  Same arithmetic in the same
                         // order as a round per reflection: bit-identical.
-                        const bool bigCell = mixed && bigLane;     // the header record of a cell with more than six faces
+                        // (mixed meshes) the slot may hold the HEADER record of a cell with more than six slots: that lane
+                        // walks the cell's CSR slots, per lane from global memory -- same test, same order
+                        int bigS0 = 0, bigNf = 0;
+                        bool bigCell = false;
+                        if (mixed) {
+                            const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
+                            bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
+                        }
                         bool again;
                         do {
                             again = false;
+                            if (mixed && bigCell) {
+                                next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
+                                if (STATS) ++st.hops;
+                            } else {
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
-                            if (mixed && bigDone) {
-                                next = bigNext; outSlot = bigOut;              // walked above, from the staged copy of the cell's faces
-                            } else if (mixed && bigCell) {
-                                // more than kBigFaces faces: the cell's CSR slots, per lane from global memory (same test, same order)
-                                next = trace_csr(S_, E, cur, m.cellOff, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
-                                if (STATS) ++st.hops;
-                            } else {
-                            next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
-                                                                : trace_lds6<!BROWNIAN>(S_, E, cur, rec, token, outSlot, zLast);
+                            next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
+                                                                : trace_lds6<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot, zLast);
                             if (STATS) ++st.hops;
                             }
                             if (REFLECT && next < 0) {
@@ -543,10 +509,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             if (LOOKUP_FIXED && mixed) {
                                 const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
                                 gBig = hdr.x == kBigCellMark; gS0 = hdr.y;
-                                if (gBig) { next = trace_csr(S_, E, cur, m.cellOff, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
+                                if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
                             }
                             if (!gBig)
-                            next = trace_fixed<6, false>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                            next = trace_fixed<6, false, mixed>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                             if (STATS) ++st.hops;
                             // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
                             // at the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
@@ -556,6 +522,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             }
                         }
                     }
+                    // (mixed meshes) left through a face group -- the coplanar pieces of a split face: the piece is chosen
+                    // at the exit point S_ (cpf_walk.h; rare: per-lane reads of the CSR tables)
+                    if (mixed && next != kSitOut && is_group(next)) next = resolve_group(next, S_, m.cellOff, m.planes, m.groupOff, m.groupNbr);
                     // ---- what the visit led to.  The common outcomes -- the segment ends here, or it crosses into a neighbour --
                     // are applied with selects, not branches: nested branches made the compiler shuttle cell, token and the two
                     // counters between registers at every join (a dozen v_mov per round).  Only the wall is a branch (rare).

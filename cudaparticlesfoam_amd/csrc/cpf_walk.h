@@ -33,46 +33,35 @@ constexpr double kTol = 1e-13;     // query/ConvexQuery.cu:42
 constexpr int kMaxHops = 50;       // query/ConvexQuery.cu:169
 constexpr int kMaxReflect = 5;     // query/ConvexQuery.cu:353
 
-// Cells with MORE THAN SIX faces (next to a 2:1 refinement) have COPLANAR faces -- the pieces of a split face share one
-// plane -- so the plane-exit test cannot tell which of them the segment leaves through: dT ties exactly, or within
-// rounding, and "the first face with the smallest dT" is usually the wrong neighbour.  No reference semantics exist for
-// such cells (src/initCuda.H:64: hexes only).  Two rules (stated independently in oracle/cellwalk.c):
-//   1. OUTWARD CROSSINGS ONLY (den < 0).  A particle that came in through one piece of a split face sits on the plane of
-//      its sibling pieces too, a rounding error outside it (fd = +4e-16), moving inward: the reference's acceptance test
-//      takes that for an exit at dT ~ 2e-13 > tol (in a hex only the entry face can look like this, and the token skips
-//      it).  A convex cell is left against the face's inward normal, so den < 0 loses no real exit.
-//   2. among the faces that pass the acceptance test with dT within kTie of the minimum, take the one whose NEIGHBOUR
-//      CELL holds the exit point X best -- the smallest maximum, over the neighbour's faces, of X's signed plane distance;
-//      a boundary face scores +inf; equal scores: the lower slot.  Always on the cell's CSR slots in global memory (a rare
-//      path: leaving a many-faced cell).
-constexpr double kTie = 1e-9;
-__device__ __forceinline__ void resolve_coplanar(const int32_t* __restrict__ cellOff, const double4* __restrict__ planes,
-                                                 const int32_t* __restrict__ nbr, int s0, int nf, const D3& P0, const D3& Pd,
-                                                 const D3& X, int token, double dTmin, int& next, int& best) {
+// FACE GROUPS (cpf_mesh.cpp): the coplanar faces of a cell -- the pieces of a face split by a 2:1 refinement next door --
+// share ONE slot, whose neighbour code names the group.  Two additions to the reference's rule, only where a slot is a
+// group (no reference semantics exist for such cells, src/initCuda.H:64: hexes only; stated independently in
+// oracle/cellwalk.c):
+//   1. OUTWARD CROSSINGS ONLY (den < 0).  A particle that came in through one piece sits on the group's plane, a rounding
+//      error outside it (fd = +4e-16), moving inward: the reference's acceptance test takes that for an exit at
+//      dT ~ 2e-13 > tol, and the token cannot skip the slot (it names the piece's cell, not the group).  A convex cell
+//      is left against the face's inward normal, so den < 0 loses no real exit.
+//   2. the cell entered is chosen at the exit point X: the piece whose CELL holds X best -- the smallest maximum, over
+//      that cell's slots, of X's signed plane distance; the first piece on equal scores (resolve_group; a rare path:
+//      per-lane reads of the CSR tables).
+__device__ __forceinline__ bool is_group(int nb) { return nb < -(1 << 30); }
+__device__ __forceinline__ int resolve_group(int code, const D3& X, const int32_t* __restrict__ cellOff, const double4* __restrict__ planes,
+                                             const int32_t* __restrict__ groupOff, const int32_t* __restrict__ groupNbr) {
+    const int g = code - kGroupBase;
+    const int k0 = groupOff[g], k1 = groupOff[g + 1];
     double bestScore = 1e301;
-    int pick = best;
-    for (int s = 0; s < nf; ++s) {
-        const double4 pl = planes[s0 + s];
-        const int nb = nbr[s0 + s];
-        const double fd = plane_dist(pl, P0), den = dot3(pl, Pd);
-        double dT = fd / den;
-        if (__builtin_isinf(dT)) dT = -1.0;
-        if (nb == token) continue;
-        if (!(den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0)) continue;
-        if (dT - dTmin > kTie) continue;
-        double score = 1e300;                               // boundary face
-        if (nb >= 0) {
-            score = -1e300;
-            const int q0 = cellOff[nb], q1 = cellOff[nb + 1];
-            for (int q = q0; q < q1; ++q) {
-                const double d = plane_dist(planes[q], X);
-                if (d > score) score = d;
-            }
+    int pick = groupNbr[k0];
+    for (int k = k0; k < k1; ++k) {
+        const int nb = groupNbr[k];
+        double score = -1e300;
+        const int q0 = cellOff[nb], q1 = cellOff[nb + 1];
+        for (int q = q0; q < q1; ++q) {
+            const double d = plane_dist(planes[q], X);
+            if (d > score) score = d;
         }
-        if (score < bestScore) { bestScore = score; pick = s; }
+        if (score < bestScore) { bestScore = score; pick = nb; }
     }
-    next = nbr[s0 + pick];
-    best = pick;
+    return pick;
 }
 
 // One cell of the walk: traceIntet (query/ConvexQuery.cu:32-131) on a polyhedral cell.
@@ -86,7 +75,6 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
     int next = cur, best = -1;
     double dTmin = 1.1;
     const int s0 = m.cellOff[cur], s1 = m.cellOff[cur + 1];
-    const bool big = s1 - s0 > 6;
     for (int s = s0; s < s1; ++s) {
         const double4 pl = m.planes[s];
         const double fd = plane_dist(pl, P0);           // (Cf - P0).n  (<= 0 inside)
@@ -95,17 +83,17 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
         if (__builtin_isinf(dT)) dT = -1.0;             // segment parallel to the face
         const int nb = m.nbr[s];
         if (nb == token) continue;
-        if (big && !(den < 0.0)) continue;              // many-faced cells: outward crossings only (see above)
+        if (is_group(nb) && !(den < 0.0)) continue;     // face groups: outward crossings only (see above)
         if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) {
             dTmin = dT;
             next = nb;
             S = axpy(dT, Pd, P0);
-            best = s - s0;
+            best = s;
         }
     }
     if (best >= 0) {
-        if (s1 - s0 > 6) resolve_coplanar(m.cellOff, m.planes, m.nbr, s0, s1 - s0, P0, Pd, S, token, dTmin, next, best);
-        outSlot = s0 + best;
+        if (is_group(next)) next = resolve_group(next, S, m.cellOff, m.planes, m.groupOff, m.groupNbr);
+        outSlot = best;
     }
     return next;
 }
@@ -118,7 +106,8 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
 // opposite-sign pair can never give dT > tol, and den == 0 / NaN fall out of every comparison
 // exactly like the isinf -> -1 substitution of ConvexQuery.cu:89.
 // `pl`/`nb` may be wave-uniform pointers (scalar loads, one fetch per wave) or per-lane ones.
-template <int NF, bool SKIP_ZERO_DEN>
+// GROUPS: the mesh may hold face groups -- such a slot is only left with den < 0 (see above)
+template <int NF, bool SKIP_ZERO_DEN, bool GROUPS = false>
 __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const double4* __restrict__ pl,
                                            const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
     const D3 P0 = S;
@@ -139,7 +128,7 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
         // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
         // NaNs that slip through give dT = 0 / NaN and fail dT > tol below, as in the reference
         const bool c1 = fabs(fd) <= fabs(den), c2 = (__double2hiint(fd) ^ __double2hiint(den)) >= 0;
-        const bool c3 = fd < kTol, c4 = bs != token;
+        const bool c3 = fd < kTol, c4 = bs != token && !(GROUPS && is_group(bs) && !(den < 0.0));
         const bool cand = c1 && c2 && c3 && c4;
         // wave-uniform skip: hipcc would otherwise if-convert and run the ~12-instruction IEEE division for
         // every face of every lane; most faces have no candidate lane at all.  The vote is the AND of the four
@@ -165,7 +154,7 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
 // chain, not by instruction issue).
 // ZERO_SKIP: try the zero-denominator skip at all -- pointless (a compare and a branch per face) once every particle
 // has a displacement along every axis, i.e. with the Brownian kick; results are the same with or without it.
-template <bool ZERO_SKIP>
+template <bool ZERO_SKIP, bool GROUPS = false>
 __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0, const D3& Pd, int token, int s,
                                           double& dTmin, int& next, int& best) {
     const double den = dot3(p, Pd);
@@ -180,7 +169,8 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
         // c2 only prunes divisions (a face the lane moves away from): "den < 0 or fd >= 0" holds whenever the exact
         // condition "equal sign bits" can still lead to an accepted face, and whatever else slips through has a
         // quotient <= 0 and fails dT > tol below, exactly as in the reference
-        const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
+        // (GROUPS: a face-group slot is only left with den < 0 -- see "face groups" above)
+        const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || (fd >= 0.0 && !(GROUPS && is_group(bs)));
         const bool c3 = fd < kTol, c4 = bs != token;
         if (c1 && c2 && c3 && c4) {
             const double dT = fd / den;
@@ -199,7 +189,7 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
 // are exactly +-0 for every lane -- nx == ny == 0 leaves den = nz * 0 -- so neither face can be accepted
 // (ConvexQuery.cu:86-95) and ONE test replaces two plane fetches, two denominators and two votes.  Exact, not
 // approximate: it is the zero-denominator skip of face_test, decided for the pair up front.
-template <bool ZERO_SKIP = true>
+template <bool ZERO_SKIP = true, bool GROUPS = false>
 __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot, bool zLast = false) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
@@ -210,22 +200,22 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
         double4 p0 = rec[0], p1 = rec[1];
         const int2 b = nb[0];
         CPF_PIN_W(p0, p1)
-        face_test<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
-        face_test<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
     }
     {
         double4 p2 = rec[2], p3 = rec[3];
         const int2 b = nb[1];
         CPF_PIN_W(p2, p3)
-        face_test<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
-        face_test<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
     if (!(zLast && ballot64(Pd.z != 0.0) == 0ull)) {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
         CPF_PIN_W(p4, p5)
-        face_test<ZERO_SKIP>(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
-        face_test<ZERO_SKIP>(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p4, b.x, P0, Pd, token, 4, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p5, b.y, P0, Pd, token, 5, dTmin, next, best);
     }
     if (best >= 0) {
         S = axpy(dTmin, Pd, P0);
@@ -289,10 +279,10 @@ __device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, co
 constexpr int kNullNbr = INT32_MIN + 5;
 constexpr int kBigCellMark = INT32_MIN + 6;
 
-// trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0
-__device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const int32_t* __restrict__ cellOff,
-                                         const double4* __restrict__ planes, const int32_t* __restrict__ nbr, int s0, int nf,
-                                         int token, int& outSlot) {
+// trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0.  A group code may come
+// back as `next`: the caller resolves it (resolve_group), as after the six-slot tests.
+__device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const double4* __restrict__ planes, const int32_t* __restrict__ nbr,
+                                         int s0, int nf, int token, int& outSlot) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
@@ -304,37 +294,11 @@ __device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const int3
         double dT = fd / den;
         if (__builtin_isinf(dT)) dT = -1.0;
         if (nb == token) continue;
-        if (den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
+        if (is_group(nb) && !(den < 0.0)) continue;
+        if (fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
     }
     if (best >= 0) {
         S = axpy(dTmin, Pd, P0);
-        resolve_coplanar(cellOff, planes, nbr, s0, nf, P0, Pd, S, token, dTmin, next, best);
-        outSlot = best;
-    }
-    return next;
-}
-
-// the same walk over nf faces staged in LDS (planes as double4, neighbour ids as int32): every lane of one cell reads the
-// same addresses (broadcast reads)
-__device__ __forceinline__ int trace_lds_n(D3& S, const D3& E, int cur, const double4* planes, const int* nbr, int nf, int token,
-                                           int& outSlot, const int32_t* __restrict__ cellOff, const double4* __restrict__ gPlanes,
-                                           const int32_t* __restrict__ gNbr, int s0) {
-    const D3 P0 = S;
-    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
-    int next = cur, best = -1;
-    double dTmin = 1.1;
-    for (int s = 0; s < nf; ++s) {
-        const double4 pl = planes[s];
-        const int nb = nbr[s];
-        const double fd = plane_dist(pl, P0), den = dot3(pl, Pd);
-        double dT = fd / den;
-        if (__builtin_isinf(dT)) dT = -1.0;
-        if (nb == token) continue;
-        if (den < 0.0 && fd < kTol && dT > kTol && dT <= 1.0 && dT < dTmin) { dTmin = dT; next = nb; best = s; }
-    }
-    if (best >= 0) {
-        S = axpy(dTmin, Pd, P0);
-        resolve_coplanar(cellOff, gPlanes, gNbr, s0, nf, P0, Pd, S, token, dTmin, next, best);
         outSlot = best;
     }
     return next;

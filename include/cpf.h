@@ -111,7 +111,11 @@ int cpf_set_mesh_parts(cpf_context* ctx, const cpf_mesh_part* parts, int nParts)
  *   faceOffsets [nFaces+1], faceVerts [faceOffsets[nFaces]]   mesh.faces() flattened
  *   owner [nFaces], neighbour [nInternal]               mesh.faceOwner()/faceNeighbour()
  * Builds on the host: CSR cell -> face-slot table in mesh.cells() order, per-slot inward unit
- * plane (n, d) and neighbour id, a uniform bin grid for the initial locate; uploads them. */
+ * plane (n, d) and neighbour id, a uniform bin grid for the initial locate; uploads them.
+ * One slot per distinct PLANE of a cell: coplanar faces of a cell (the pieces of a face split by a 2:1
+ * refinement next door) share a slot; where they lead to different cells the slot's neighbour id names
+ * a face group (cpf_get_mesh_groups) and the walk picks the piece at the exit point.  Hex meshes -- all
+ * the reference can run (src/initCuda.H:64) -- have no coplanar faces: slots == faces there. */
 int cpf_set_mesh(cpf_context* ctx, const double* points, int64_t nPoints, const int32_t* faceOffsets,
                  const int32_t* faceVerts, int64_t nFaces, const int32_t* owner, const int32_t* neighbour,
                  int64_t nInternal, int64_t nCells);
@@ -122,6 +126,9 @@ int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nCellFaceSlo
 /* Copy the host-built tables back out (tests: compared against the oracle's own build). Any
  * pointer may be NULL.  cellOff[nCells+1], planes[slots][4], nbr[slots]. */
 int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes, int32_t* nbr);
+/* The face groups: nbr == INT32_MIN + 16 + g marks group g, whose pieces lead to the cells
+ * groupNbr[groupOff[g] .. groupOff[g+1]).  Any pointer may be NULL; groupOff[nGroups+1], groupNbr[nMembers]. */
+int cpf_get_mesh_groups(const cpf_context* ctx, int64_t* nGroups, int64_t* nMembers, int32_t* groupOff, int32_t* groupNbr);
 
 /* Cell-constant velocity U[nCells][3] (host, zero-copy from U.primitiveField()).  Replaces the
  * 12x replication loop + cudaUpdateVelocity of src/advect.H:44-57 (cuda/particles.cu:718-749):

@@ -49,14 +49,32 @@ static inline v3 crossp(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x 
  * exact ties in dT (the lower slot wins, trace_in_cell); the product's mesh layer (csrc/cpf_mesh.cpp) states the same
  * rule so that its kernels can drop both z faces with one test when no lane moves in z.
  *   planes[4*s..] = (nx, ny, nz, d): unit normal pointing INTO the cell, d = n . Cf
- *   nbr[s]        = neighbour cell, or -(face+1) for a boundary face
+ *   nbr[s]        = neighbour cell, or -(face+1) for a boundary face, or CW_GROUP_BASE + g for a face group
+ *
+ * COPLANAR FACES OF ONE CELL ARE ONE SLOT.  Next to a 2:1 refinement a cell has the four (two) pieces of a split face,
+ * all in one plane: the plane-exit test cannot tell which piece a segment leaves through (the exit parameters tie, exactly
+ * or within rounding), so the slots of a cell are its distinct PLANES, not its faces.  In face order, a face joins the
+ * FIRST earlier slot of its cell that is of the same kind (internal / boundary) and whose plane agrees with its own --
+ * every normal component within CW_COPLANAR, offsets within CW_COPLANAR * (1 + |d|) -- and otherwise opens a new slot with
+ * its own plane.  A boundary slot keeps the code of its first face (every boundary face reflects alike).  An internal
+ * slot that collected several faces becomes face group g (numbered in cell, then slot order): nbr = CW_GROUP_BASE + g,
+ * groupNbr[groupOff[g] .. groupOff[g+1]) = the pieces' neighbour cells in face order; which of them a segment enters
+ * is decided at the exit point (resolve_group).  No reference semantics exist for such cells (src/initCuda.H:64: hexes
+ * only; OpenFOAM's own tracking walks the tet decomposition, where the pieces belong to different tets); the product's
+ * mesh layer (csrc/cpf_mesh.cpp) states the same rule.  A hex mesh has no coplanar faces and is untouched.
  * Face centre/area vector: triangle fan about the vertex average (OpenFOAM's
  * primitiveMeshFaceCentresAndAreas scheme, restated; exact for planar faces).
  * ------------------------------------------------------------------------------------------ */
+#define CW_GROUP_BASE (INT_MIN + 16)          /* nbr code of face group g: CW_GROUP_BASE + g */
+#define CW_IS_GROUP(nb) ((nb) < -(1 << 30))   /* boundary codes -(face+1) stay above: nFaces < 2^30 */
+#define CW_COPLANAR 1e-9
+
 int cw_build(const double* points, int nPoints, const int* faceOff, const int* faceVerts, int nFaces,
              const int* owner, const int* neighbour, int nInternal, int nCells,
-             int* cellOff /*nCells+1*/, double* planes /*4*ncf*/, int* nbr /*ncf*/) {
+             int* cellOff /*nCells+1*/, double* planes /*4*ncf*/, int* nbr /*ncf*/,
+             int* groupOff /*ncf+1*/, int* groupNbr /*ncf*/, int* nGroupsOut) {
     (void)nPoints;
+    if (nFaces >= (1 << 30) - 1) return -1;
     int* cnt = (int*)calloc((size_t)nCells + 1, sizeof(int));
     if (!cnt) return -1;
     for (int f = 0; f < nFaces; ++f) cnt[owner[f]]++;
@@ -100,6 +118,51 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
         }
     }
     free(cnt);
+    /* coplanar faces of a cell -> one slot (see above); compacts the tables in place */
+    {
+        int w = 0, nGroups = 0, nMembers = 0;
+        /* members are collected per cell in a scratch list: (logical slot, neighbour) in face order */
+        int* memSlot = NULL; int* memNbr = NULL; int memCap = 0;
+        groupOff[0] = 0;
+        for (int c = 0; c < nCells; ++c) {
+            const int s0 = cellOff[c], s1 = cellOff[c + 1];
+            const int w0 = w;
+            int nMem = 0;
+            if (s1 - s0 > memCap) { memCap = s1 - s0; memSlot = (int*)realloc(memSlot, sizeof(int) * memCap); memNbr = (int*)realloc(memNbr, sizeof(int) * memCap); }
+            for (int s = s0; s < s1; ++s) {
+                const double* q = planes + 4 * s;
+                const int nb = nbr[s];
+                int into = -1;
+                for (int r = w0; r < w && into < 0; ++r) {
+                    const double* pr = planes + 4 * r;
+                    const int nr = nbr[r];
+                    if ((nr >= 0) != (nb >= 0)) continue;
+                    if (fabs(q[0] - pr[0]) <= CW_COPLANAR && fabs(q[1] - pr[1]) <= CW_COPLANAR && fabs(q[2] - pr[2]) <= CW_COPLANAR &&
+                        fabs(q[3] - pr[3]) <= CW_COPLANAR * (1.0 + fabs(pr[3]))) into = r;
+                }
+                if (into < 0) {                        /* a new slot (w <= s: compaction never overtakes the read position) */
+                    memmove(planes + 4 * w, q, 4 * sizeof(double));
+                    nbr[w] = nb;
+                    into = w++;
+                }
+                if (nb >= 0) { memSlot[nMem] = into; memNbr[nMem] = nb; ++nMem; }
+            }
+            /* internal slots with more than one member become groups, in slot order */
+            for (int r = w0; r < w; ++r) {
+                if (nbr[r] < 0) continue;
+                int k = 0;
+                for (int i = 0; i < nMem; ++i) k += memSlot[i] == r;
+                if (k < 2) continue;
+                for (int i = 0; i < nMem; ++i) if (memSlot[i] == r) groupNbr[nMembers++] = memNbr[i];
+                nbr[r] = CW_GROUP_BASE + nGroups;
+                groupOff[++nGroups] = nMembers;
+            }
+            cellOff[c] = w0;
+        }
+        cellOff[nCells] = w;
+        free(memSlot); free(memNbr);
+        *nGroupsOut = nGroups;
+    }
     /* z-layered meshes: z faces last (see above) */
     int layered = 1;
     for (int c = 0; c < nCells && layered; ++c) {
@@ -123,33 +186,42 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
     return cellOff[nCells];
 }
 
-#define CW_TIE 1e-9        /* two exit parameters dT closer than this count as a tie (cells with more than six faces) */
+typedef struct {            /* the tables of cw_build */
+    const int* cellOff; const double* planes; const int* nbr; const int* groupOff; const int* groupNbr;
+} cw_tables;
+
+/* Which piece of face group g does a segment enter that leaves the cell at X?  The piece whose CELL holds X best: the
+ * smallest maximum, over that cell's slots, of X's signed plane distance (<= 0 inside); the first piece on equal scores. */
+static int resolve_group(int g, v3 X, const cw_tables* t) {
+    double bestScore = 1e301;
+    int pick = t->groupNbr[t->groupOff[g]];
+    for (int k = t->groupOff[g]; k < t->groupOff[g + 1]; ++k) {
+        const int nb = t->groupNbr[k];
+        double score = -1e300;
+        for (int q = t->cellOff[nb]; q < t->cellOff[nb + 1]; ++q) {
+            const double d = plane_dist(V(t->planes[4 * q], t->planes[4 * q + 1], t->planes[4 * q + 2]), t->planes[4 * q + 3], X);
+            if (d > score) score = d;
+        }
+        if (score < bestScore) { bestScore = score; pick = nb; }
+    }
+    return pick;
+}
 
 /* One cell of the walk (traceIntet on a polyhedral cell).  `token` identifies the face we came
  * in through: the previous cell id after a hop, the boundary code after a reflection.
  *
- * Cells with MORE THAN SIX faces (next to a 2:1 refinement) have COPLANAR faces -- the four (two) pieces of a split face
- * share one plane -- so the plane-exit test cannot tell which of them the segment leaves through: dT ties exactly (or
- * within rounding, where the pieces' planes were computed from different vertices) and "the first face with the smallest
- * dT" is usually the wrong neighbour.  No reference semantics exist for such cells (src/initCuda.H:64: hexes only;
- * OpenFOAM's own tracking walks the cell's tet decomposition, where the pieces belong to different tets).  Two rules,
- * stated here and in the kernels (csrc/cpf_walk.h) alike, for cells with more than six faces only:
- *   1. outward crossings only (n.Pd < 0 for the inward-signed plane): a particle that came in through one piece of a
- *      split face lies on the plane of the sibling pieces too, a rounding error outside (fd = +4e-16) and moving inward,
- *      which the reference's acceptance test takes for an exit at dT ~ 2e-13 > tol; in a hex only the entry face can look
- *      like that and the token skips it.  A convex cell is only ever left with n.Pd < 0.
- *   2. among the faces that pass the acceptance test with dT within CW_TIE of the minimum, take the one whose NEIGHBOUR
- *      CELL holds the exit point best -- the smallest maximum, over the neighbour's faces, of the exit point's signed
- *      plane distance; a boundary face scores +inf (it only wins where no internal face competes); equal scores: the
- *      lower slot.
- * Cells with up to six faces keep the reference's rule (first smallest dT). */
-static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const double* planes, const int* nbr,
-                         int token, int* outSlot) {
+ * Face groups (cw_build) add two things to the reference's rule, both only where a slot IS a group:
+ *   1. outward crossings only (n.Pd < 0 for the inward-signed plane).  A particle that came in through one piece of a
+ *      group lies on the group's plane, a rounding error outside it (fd = +4e-16) and moving inward, which the
+ *      reference's acceptance test takes for an exit at dT ~ 2e-13 > tol; the token cannot skip the slot (it names the
+ *      piece's cell, not the group).  A convex cell is only ever left with n.Pd < 0, so no real exit is lost.
+ *   2. the cell entered is chosen at the exit point (resolve_group). */
+static int trace_in_cell(v3* Ps, v3 Pe, int cur, const cw_tables* t, int token, int* outSlot) {
+    const int* cellOff = t->cellOff; const double* planes = t->planes; const int* nbr = t->nbr;
     const v3 P0 = *Ps;
     const v3 Pd = sub(Pe, P0);
     int next = cur, best = -1;
     double dTmin = 1.1;
-    const int big = cellOff[cur + 1] - cellOff[cur] > 6;
     for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
         v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
         double fd = plane_dist(n, planes[4 * s + 3], P0);  /* (Cf - P0).n, <= 0 inside */
@@ -157,7 +229,7 @@ static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const doubl
         double dT = fd / den;
         if (isinf(dT)) dT = -1.0;
         if (nbr[s] == token) continue;
-        if (big && !(den < 0.0)) continue;                 /* rule 1 */
+        if (CW_IS_GROUP(nbr[s]) && !(den < 0.0)) continue;
         if (fd < CW_TOL && dT > CW_TOL && dT <= 1.0 && dT < dTmin) {
             dTmin = dT;
             next = nbr[s];
@@ -166,34 +238,7 @@ static int trace_in_cell(v3* Ps, v3 Pe, int cur, const int* cellOff, const doubl
             best = s;
         }
     }
-    if (best >= 0 && cellOff[cur + 1] - cellOff[cur] > 6) {
-        const v3 X = *Ps;                                   /* the exit point */
-        double bestScore = 1e301;
-        int pick = best;
-        for (int s = cellOff[cur]; s < cellOff[cur + 1]; ++s) {
-            v3 n = V(planes[4 * s], planes[4 * s + 1], planes[4 * s + 2]);
-            double fd = plane_dist(n, planes[4 * s + 3], P0);
-            double den = dotf(n, Pd);
-            double dT = fd / den;
-            if (isinf(dT)) dT = -1.0;
-            if (nbr[s] == token) continue;
-            if (!(den < 0.0)) continue;
-            if (!(fd < CW_TOL && dT > CW_TOL && dT <= 1.0)) continue;
-            if (dT - dTmin > CW_TIE) continue;
-            double score = 1e300;                           /* boundary face */
-            const int nb = nbr[s];
-            if (nb >= 0) {
-                score = -1e300;
-                for (int q = cellOff[nb]; q < cellOff[nb + 1]; ++q) {
-                    const double d = plane_dist(V(planes[4 * q], planes[4 * q + 1], planes[4 * q + 2]), planes[4 * q + 3], X);
-                    if (d > score) score = d;
-                }
-            }
-            if (score < bestScore) { bestScore = score; pick = s; }
-        }
-        next = nbr[pick];
-        *outSlot = pick;
-    }
+    if (best >= 0 && CW_IS_GROUP(next)) next = resolve_group(next - CW_GROUP_BASE, *Ps, t);
     return next;
 }
 
@@ -265,8 +310,9 @@ typedef struct { long long hops, reflections, lost; } cw_stats;
 
 /* advect + locate + reflect + move for one particle (src/advect.H:96-161, D = 0) */
 static void step_one(int i, double* px, double* py, double* pz, int* cell, double* vel_out, double dt,
-                     const int* cellOff, const double* planes, const int* nbr, const double* U, cw_stats* st,
+                     const cw_tables* t, const double* U, cw_stats* st,
                      double D, const int64_t* gid, uint32_t step, uint32_t seed) {
+    const double* planes = t->planes;
     int cur = cell[i];
     if (cur < 0) { if (cur == CW_LOST) cell[i] = CW_FROZEN; return; }
     const v3 P = V(px[i], py[i], pz[i]);
@@ -283,7 +329,7 @@ static void step_one(int i, double* px, double* py, double* pz, int* cell, doubl
     int token = INT_MIN, next = cur, outSlot = -1, reflected = 0;
     for (int j = 0; j < CW_MAX_REFLECT; ++j) {
         for (int h = 0; h < CW_MAX_HOPS; ++h) {
-            next = trace_in_cell(&Ps, Pe, cur, cellOff, planes, nbr, token, &outSlot);
+            next = trace_in_cell(&Ps, Pe, cur, t, token, &outSlot);
             st->hops++;
             if (next == cur) break;
             if (next < 0) break;
@@ -309,16 +355,17 @@ static void step_one(int i, double* px, double* py, double* pz, int* cell, doubl
 }
 
 void cw_step(double* px, double* py, double* pz, int* cell, double* vel_out, int n, double dt, int cycles,
-             const int* cellOff, const double* planes, const int* nbr, const double* U, int nthreads,
-             long long* stats /* [hops, reflections, lost] or NULL */,
+             const int* cellOff, const double* planes, const int* nbr, const int* groupOff, const int* groupNbr,
+             const double* U, int nthreads, long long* stats /* [hops, reflections, lost] or NULL */,
              double D, const int64_t* gid, uint32_t step0, uint32_t seed) {
     long long H = 0, R = 0, L = 0;
+    const cw_tables tab = {cellOff, planes, nbr, groupOff, groupNbr};
     /* particles are independent: all cycles of one particle back to back, one parallel region */
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : H, R, L)
     for (int i = 0; i < n; ++i) {
         cw_stats st = {0, 0, 0};
         for (int c = 0; c < cycles; ++c)
-            step_one(i, px, py, pz, cell, vel_out, dt, cellOff, planes, nbr, U, &st, D, gid, step0 + (uint32_t)c, seed);
+            step_one(i, px, py, pz, cell, vel_out, dt, &tab, U, &st, D, gid, step0 + (uint32_t)c, seed);
         H += st.hops; R += st.reflections; L += st.lost;
     }
     if (stats) { stats[0] = H; stats[1] = R; stats[2] = L; }
@@ -398,11 +445,13 @@ int cw_max_threads(void) {
 
 /* diagnostics: one cycle, per-particle number of cell visits and reflections (divergence studies) */
 void cw_step_count(double* px, double* py, double* pz, int* cell, int n, double dt, const int* cellOff,
-                   const double* planes, const int* nbr, const double* U, int nthreads, int* visits, int* reflections) {
+                   const double* planes, const int* nbr, const int* groupOff, const int* groupNbr, const double* U,
+                   int nthreads, int* visits, int* reflections) {
+    const cw_tables tab = {cellOff, planes, nbr, groupOff, groupNbr};
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
     for (int i = 0; i < n; ++i) {
         cw_stats st = {0, 0, 0};
-        step_one(i, px, py, pz, cell, NULL, dt, cellOff, planes, nbr, U, &st, 0.0, NULL, 0, 0);
+        step_one(i, px, py, pz, cell, NULL, dt, &tab, U, &st, 0.0, NULL, 0, 0);
         visits[i] = (int)st.hops; reflections[i] = (int)st.reflections;
     }
 }

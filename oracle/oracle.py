@@ -208,8 +208,18 @@ class TetWalk(_TetApi):
 
 
 class CellTables:
-    def __init__(self, cell_off, planes, nbr, n_cells):
+    """cw_build's tables: one slot per distinct PLANE of a cell; coplanar internal faces form a face group
+    (nbr = GROUP_BASE + g, the pieces' cells in group_nbr[group_off[g]:group_off[g+1]])."""
+    GROUP_BASE = -2 ** 31 + 16
+
+    def __init__(self, cell_off, planes, nbr, n_cells, group_off=None, group_nbr=None):
         self.cell_off, self.planes, self.nbr, self.n_cells = cell_off, planes, nbr, n_cells
+        self.group_off = np.zeros(1, np.int32) if group_off is None else group_off
+        self.group_nbr = np.zeros(1, np.int32) if group_nbr is None else group_nbr
+
+    @property
+    def n_groups(self):
+        return self.group_off.shape[0] - 1
 
 
 class CellWalk:
@@ -219,8 +229,8 @@ class CellWalk:
             raise FileNotFoundError(path)
         L = self.lib = C.CDLL(path)
         L.cw_build.restype = C.c_int
-        L.cw_build.argtypes = [_dp, C.c_int, _ip, _ip, C.c_int, _ip, _ip, C.c_int, C.c_int, _ip, _dp, _ip]
-        L.cw_step.argtypes = [_dp, _dp, _dp, _ip, C.c_void_p, C.c_int, C.c_double, C.c_int, _ip, _dp, _ip, _dp,
+        L.cw_build.argtypes = [_dp, C.c_int, _ip, _ip, C.c_int, _ip, _ip, C.c_int, C.c_int, _ip, _dp, _ip, _ip, _ip, _ip]
+        L.cw_step.argtypes = [_dp, _dp, _dp, _ip, C.c_void_p, C.c_int, C.c_double, C.c_int, _ip, _dp, _ip, _ip, _ip, _dp,
                               C.c_int, _lp, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32]
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
@@ -235,12 +245,15 @@ class CellWalk:
     def build(self, mesh) -> CellTables:
         ncf = int(mesh.n_faces + mesh.n_internal)
         off = np.empty(mesh.n_cells + 1, np.int32); planes = np.empty((ncf, 4)); nbr = np.empty(ncf, np.int32)
+        goff = np.zeros(ncf + 1, np.int32); gnbr = np.zeros(ncf, np.int32); ng = np.zeros(1, np.int32)
         r = self.lib.cw_build(_c(mesh.points, np.float64), mesh.n_points, _c(mesh.face_offsets, np.int32),
                               _c(mesh.face_verts, np.int32), mesh.n_faces, _c(mesh.owner, np.int32),
-                              _c(mesh.neighbour, np.int32), mesh.n_internal, mesh.n_cells, off, planes, nbr)
-        if r != ncf:
+                              _c(mesh.neighbour, np.int32), mesh.n_internal, mesh.n_cells, off, planes, nbr, goff, gnbr, ng)
+        if r < 0 or r != off[-1]:
             raise RuntimeError("cw_build")
-        return CellTables(off, planes, nbr, mesh.n_cells)
+        g = int(ng[0])
+        return CellTables(off, planes[:r].copy(), nbr[:r].copy(), mesh.n_cells, goff[:g + 1].copy(),
+                          gnbr[:max(int(goff[g]), 1)].copy())
 
     def advect_vertex(self, P, cells, vels, disps, dt, tets, tets_per_cell, positions, vertvel, nthreads=1):
         """cpf_stage_advect_vertex's CPU statement: "VertexVelocity" advect on cell ids (tets: [nCells*tpc][4])."""
@@ -253,8 +266,8 @@ class CellWalk:
         U = _c(U, np.float64)
         vp = None if vel_out is None else vel_out.ctypes.data_as(C.c_void_p)
         gp = None if gid is None else _c(gid, np.int64).ctypes.data_as(C.c_void_p)
-        self.lib.cw_step(x, y, z, cell, vp, x.shape[0], dt, cycles, t.cell_off, t.planes, t.nbr, U, nthreads,
-                         stats, D, gp, step0, seed)
+        self.lib.cw_step(x, y, z, cell, vp, x.shape[0], dt, cycles, t.cell_off, t.planes, t.nbr, t.group_off, t.group_nbr,
+                         U, nthreads, stats, D, gp, step0, seed)
         return stats
 
     def locate_initial(self, x, y, z, t: CellTables, nthreads=1):

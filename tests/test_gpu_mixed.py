@@ -1,9 +1,10 @@
 """GPU: meshes that are NOT all-hex keep the streaming kernel (BASELINE configs[4] "polyMesh").
 
 The reference cannot run them at all (``src/initCuda.H:64``: ``tetsPerCell = 12``); the bar is this repo's own: the HIP
-path is bit-identical to the CPU statement ``oracle/cellwalk.c`` on them -- cells, positions, visit and reflection
-counters -- whichever kernel runs: the streaming kernel with mixed cell records (padded records for cells with fewer than
-six faces, header records + CSR walk for cells with more), or the generic CSR walk.
+path is bit-identical to the CPU statement ``oracle/cellwalk.c`` on them -- mesh tables (slots = distinct planes, face
+groups for the coplanar pieces of a split face), cells, positions, visit and reflection counters -- whichever kernel runs:
+the streaming kernel with mixed cell records (padded records for cells with fewer than six slots, header records + CSR walk
+for cells with more, face groups resolved at the exit point), or the generic CSR walk.
 """
 import numpy as np
 import pytest
@@ -39,6 +40,10 @@ def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, w
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+        off, planes, nbr = ctx.mesh_tables()        # the product's own mesh layer against the CPU statement's, bit for bit
+        goff, gnbr = ctx.mesh_groups()
+        assert np.array_equal(off, t.cell_off) and np.array_equal(nbr, t.nbr) and np.array_equal(planes, t.planes)
+        assert np.array_equal(goff, t.group_off) and np.array_equal(gnbr, t.group_nbr[:goff[-1]])
         ctx.locate_initial()
         _, cell0 = ctx.get_particles()
         assert np.array_equal(cell0, ref0), opts
@@ -65,8 +70,9 @@ def _kernel_for(opts):
 @pytest.mark.parametrize("seed", [1, 2])
 def test_refined_box_cells_with_9_to_21_faces(seed, oracle_libs, gpu_ctx_factory):
     """A graded 3-D box with a 2:1-refined block in the middle: the unrefined cells around it have 9, 12, 15, 18 or 21
-    faces.  Random cell-constant field, steps that cross several cells and bounce off walls, 40 000 particles all over
-    the box (many start in and cross the many-faced cells)."""
+    faces -- six slots each, one to five of them face groups of four pieces.  Random cell-constant field, steps that cross
+    several cells and bounce off walls, 40 000 particles all over the box (many start in and cross the many-faced
+    cells)."""
     from cudaparticlesfoam_amd.cases import refined_box
     mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
     off, _ = mesh.cell_faces()
@@ -112,9 +118,42 @@ def test_refined_pitzdaily_1e6(oracle_libs, gpu_ctx_factory, pitz):
     _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1e-4, 20, [dict(), dict(step_variant=0)], _kernel_for)
 
 
+@pytest.mark.parametrize("every", [4, 5])
+def test_pentagonal_prisms_use_header_records(every, oracle_libs, gpu_ctx_factory):
+    """Cells with SEVEN distinct planes (pentagonal prisms: squares of an extruded grid with a corner cut off) among
+    triangular prisms (five: padded records), hexes, and hexes with a hanging node (a face group of two pieces): the
+    streaming kernel walks the seven-slot cells from their header record over the CSR tables."""
+    from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
+    mesh, kinds = cut_corner_box(11, 8, 3, every=every)
+    assert min(kinds.values()) > 0
+    rng = np.random.default_rng(40 + every)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 1.2
+    xyz = rng.uniform([0, 0, 0], [11, 8, 3], size=(40000, 3))
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    slots = np.diff(t.cell_off)
+    assert set(slots) == {5, 6, 7} and (slots == 7).sum() * 4 <= mesh.n_cells and t.n_groups > 50
+    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for)
+    assert (c >= 0).all() and (slots[c] == 7).sum() > 1000 and (slots[c] == 5).sum() > 300
+
+
 def test_mostly_polyhedral_mesh_keeps_the_generic_walk(oracle_libs, gpu_ctx_factory):
-    """Every cell with TEN faces (pairs of hexes of a box glued along x: convex, coplanar face pairs on four sides): more
-    than a quarter of the cells have more than six faces, so no records are built and the generic CSR walk runs."""
+    """EVERY square of the grid cut: half of the cells are pentagonal prisms with seven (and, with their own hanging nodes,
+    face-grouped) slots -- more than a quarter of the cells have more than six slots, so no records are built and the
+    generic CSR walk runs."""
+    from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
+    mesh, kinds = cut_corner_box(7, 5, 2, every=1)
+    assert kinds["pentagons"] == 35 and kinds["triangles"] == 35
+    rng = np.random.default_rng(3)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 0.8
+    xyz = rng.uniform([0, 0, 0], [7, 5, 2], size=(20000, 3))
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict()], lambda o: "cpf::step_kernel<0,")
+
+
+def test_glued_hexes_are_six_slot_cells(oracle_libs, gpu_ctx_factory):
+    """Pairs of hexes of a box glued along x: TEN faces each, four coplanar pairs -- six slots, four of them face groups of
+    two (towards the glued pairs above, below, in front and behind... which are each ONE cell: both pieces lead to the
+    same neighbour, the group holds it twice).  The streaming kernel runs; bit-identical to the CPU statement."""
     from cudaparticlesfoam_amd.cases import box_mesh, build_polymesh_from_cells
     from cudaparticlesfoam_amd.cases.blockmesh import HEX_FACES
     m0 = box_mesh(8, 3, 3)
@@ -126,10 +165,12 @@ def test_mostly_polyhedral_mesh_keeps_the_generic_walk(oracle_libs, gpu_ctx_fact
         cells.append(loops)
     mesh = build_polymesh_from_cells(m0.points, cells)
     assert set(np.diff(mesh.cell_faces()[0])) == {10} and mesh.n_cells == 36
+    t = oracle_libs.CellWalk().build(mesh)
+    assert set(np.diff(t.cell_off)) == {6}
     rng = np.random.default_rng(3)
     U = rng.normal(size=(mesh.n_cells, 3)) * 0.8
     xyz = rng.uniform([0, 0, 0], [8, 3, 3], size=(20000, 3))
-    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict()], lambda o: "cpf::step_kernel<0,")
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict(), dict(step_variant=0)], _kernel_for)
 
 
 def test_every_lane_of_a_tile_reflects_hit_pool_overflows(oracle_libs, gpu_ctx_factory):
@@ -189,7 +230,7 @@ def test_diffusion_on_a_mixed_mesh_loses_nobody(oracle_libs, gpu_ctx_factory):
     xyzw, cell = ctx.get_particles()
     after = ctx.counters()
     assert (cell >= 0).all() and after["lost"] == before["lost"] and after["reflections"] > before["reflections"]
-    nf = np.diff(t.cell_off)
+    nf = np.diff(mesh.cell_faces()[0])
     assert (nf[cell] > 6).sum() > 1000                             # plenty of them ended in a many-faced cell
     w = worst_outside(t, xyzw[:, :3], cell)
     assert w.max() <= 1e-9, (int((w > 1e-9).sum()), float(w.max()))

@@ -4,8 +4,9 @@ The reference cannot run such meshes (``src/initCuda.H:64``: ``tetsPerCell = 12`
 them on; what the CPU statement must satisfy is the domain's own invariant.  A many-faced cell has COPLANAR faces (the
 pieces of a split face), where the reference's plane-exit test is ambiguous twice over: the exit parameters of the pieces
 tie, and a particle that came in through one piece sits on its siblings' plane a rounding error outside it, moving
-inward.  ``oracle/cellwalk.c`` (trace_in_cell) states the two rules that settle both; with the reference's rule alone this
-test finds hundreds of particles in the wrong cell after a single cycle (741 of 2e5 on the refined box).
+inward.  ``oracle/cellwalk.c`` makes the coplanar faces of a cell ONE slot (cw_build: a face group) and settles the piece
+at the exit point (trace_in_cell, resolve_group); with the reference's rule on the raw faces this test finds hundreds of
+particles in the wrong cell after a single cycle (741 of 2e5 on the refined box).
 """
 import numpy as np
 import pytest
@@ -29,7 +30,8 @@ def test_refined_box_everybody_inside_the_claimed_cell(D, oracle_libs):
     mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
     cw = oracle_libs.CellWalk()
     t = cw.build(mesh)
-    nf = np.diff(t.cell_off)
+    nf = np.diff(mesh.cell_faces()[0])                            # faces; the tables hold one slot per distinct plane
+    assert nf.max() >= 18 and np.diff(t.cell_off).max() == 6 and t.n_groups == 86
     rng = np.random.default_rng(23)
     n = 100_000
     xyz = rng.uniform([0, 0, 0], [8, 6, 5], size=(n, 3))
