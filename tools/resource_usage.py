@@ -32,7 +32,7 @@ def collect():
 
 
 def main():
-    label = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    label = sys.argv[1] if len(sys.argv) > 1 else "r03"
     rows = collect()
     out = ["# Compiler resource usage of the step kernels: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off",
            "# -Rpass-analysis=kernel-resource-usage (ROCm 7.2).  tools/resource_usage.py " + label,
