@@ -3,7 +3,10 @@
 statement, bit for bit.  Random graded/sheared hex blocks (tests/test_oracle_random._case), random cell-constant U,
 time steps that cross several cells and bounce off several walls; every case runs with the statistics on and off
 (two instantiations), plain and fused launches, sorted and unsorted clouds, and with exactly axis-aligned flow
-(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count]"""
+(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed]
+"mixed": a random subset of the block's cells is split 2 x 2 x 2 (2 x 2 x 1 for every third seed) first -- coarse cells
+with one to six split faces, i.e. face groups in every combination -- and the CPU statement's result is also checked
+against the domain's own invariant (nobody lost, everybody inside the cell they claim)."""
 import os
 import sys
 import time
@@ -17,6 +20,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"
     import torch  # noqa: F401  (its HIP runtime first)
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -28,6 +32,13 @@ def main():
     t0 = time.time()
     for seed in range(first, first + count):
         rng, mesh, U, dt = _case(seed)
+        if mixed:
+            from cudaparticlesfoam_amd.cases.refine import refine_hexes
+            mask = rng.random(mesh.n_cells) < rng.choice([0.1, 0.3, 0.5])
+            mask[int(rng.integers(mesh.n_cells))] = True
+            mesh, parent = refine_hexes(mesh.points, mesh.hexes, mask, split_z=bool(seed % 3))
+            U = U[parent] + rng.normal(size=(mesh.n_cells, 3)) * 0.1 * float(np.abs(U).max())
+            dt = dt * 0.5
         mode = seed % 4
         if mode == 1:                                    # axis-aligned flow: whole families of faces have den == 0
             amp = float(np.abs(U).max()) or 1.0
@@ -43,6 +54,14 @@ def main():
         steps = [1, 5, 24]
         for k in steps:
             cw.step(x, y, z, c, dt, k, t, U, nthreads=cw.max_threads)
+        if mixed:
+            from test_oracle_mixed import worst_outside
+            alive = c >= 0
+            w = worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive])
+            if (c[ref0 >= 0] < 0).any() or w.max() > 1e-9 * float((hi - lo).max()):
+                bad += 1
+                print("INVARIANT seed %d: %d lost, %d outside their cell (worst %.3e)" %
+                      (seed, int((c[ref0 >= 0] < 0).sum()), int((w > 1e-9 * float((hi - lo).max())).sum()), float(w.max())), flush=True)
         for stats in (0, 1):
             for fused in (0, 1):
                 ctx = Context(0)
