@@ -119,7 +119,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
-    m.mixed = (c->d_cellRec && !m.allHex) ? 1 : 0;
+    m.mixed = (c->d_cellRec && !m.allHex) ? (c->host.nBigCells > 0 ? 2 : 1) : 0;
     return m;
 }
 cpf::GridView gridView(const cpf_context* c) {

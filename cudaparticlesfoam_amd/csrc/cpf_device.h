@@ -24,7 +24,7 @@ struct MeshView {
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s) and there are no face groups
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
-    int32_t mixed;            // records exist although the mesh is not all-hex: padded (< 6 slots) and header-only (> 6) records, face groups
+    int32_t mixed;            // records exist although the mesh is not all-hex: 1 = padded records (< 6 slots) and face groups only, 2 = header-only records (> 6 slots) as well
 };
 
 struct GridView {
@@ -59,7 +59,7 @@ struct StreamState {
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
-int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 2 fixed compare + mixed records
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 2 / 3 fixed compare + mixed records with / without header records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 8;       // fused launches of this many cycles or more run the wave-cooperative kernel (round 3: the

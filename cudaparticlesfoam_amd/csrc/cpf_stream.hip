@@ -71,7 +71,7 @@ static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell)
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
-struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP == 2 ? 5 : 6) : (LOOKUP == 2 ? 6 : CPF_STREAM_WAVES)); };
+struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP >= 2 ? 5 : 6) : (LOOKUP >= 2 ? 6 : CPF_STREAM_WAVES)); };   // (LOOKUP 3 as 0 / 1)
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    constexpr int kPool = HIT_IN_REGS ? 1 : (LOOKUP == 2 ? 16 : CPF_STREAM_HIT_POOL);
+    constexpr int kPool = HIT_IN_REGS ? 1 : (LOOKUP >= 2 ? 16 : CPF_STREAM_HIT_POOL);
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -112,10 +112,12 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     const unsigned slotBase = uniform32(lds_addr(slots));
     const int tpc = sa.tilesPerChunk;
     // LOOKUP: how a wave finds its cells in its record cache, and which records can turn up --
-    //   0 loop over the distinct cells of the wave, 1 fixed tag compare, 2 fixed tag compare on a mesh that is not all-hex
-    //   (MeshView::mixed: header records of cells with more than six faces may turn up)
+    //   0 loop over the distinct cells of the wave, 1 fixed tag compare, 2 / 3 fixed tag compare on a mesh that is not
+    //   all-hex (MeshView::mixed): 3 = every cell has at most six slots -- face groups and padded records only, the usual
+    //   2:1-refined hex mesh --, 2 = header records of cells with more than six slots may turn up as well
     constexpr bool LOOKUP_FIXED = LOOKUP != 0;
-    constexpr bool mixed = LOOKUP == 2;
+    constexpr bool mixed = LOOKUP >= 2;
+    constexpr bool bigCells = LOOKUP == 2;
     const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
@@ -451,14 +453,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // walks the cell's CSR slots, per lane from global memory -- same test, same order
                         int bigS0 = 0, bigNf = 0;
                         bool bigCell = false;
-                        if (mixed) {
+                        if (bigCells) {
                             const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
                             bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
                         }
                         bool again;
                         do {
                             again = false;
-                            if (mixed && bigCell) {
+                            if (bigCells && bigCell) {
                                 next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
                                 if (STATS) ++st.hops;
                             } else {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             if (REFLECT && next < 0) {
                                 // The wall's plane is read HERE, where the record's address space is known (one expression
                                 // choosing between the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0).
-                                if (mixed && bigCell) {
+                                if (bigCells && bigCell) {
                                     wallPlane = m.planes[bigS0 + outSlot];
                                     asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));   // arrives HERE
                                 } else wallPlane = rec[outSlot];
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             if (needAdvect) E = advect(rec);
                             int gS0 = 0;
                             bool gBig = false;
-                            if (LOOKUP_FIXED && mixed) {
+                            if (LOOKUP_FIXED && bigCells) {
                                 const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
                                 gBig = hdr.x == kBigCellMark; gS0 = hdr.y;
                                 if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
@@ -673,7 +675,7 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
 int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
-    if (m.mixed) return 2;                     // not all-hex: the instantiations that know header records (cells with > 6 faces)
+    if (m.mixed) return m.mixed == 2 ? 2 : 3;  // not all-hex: with / without header records (cells with more than six slots)
     return (ss.lookup >= 0 ? ss.lookup != 0 : n < 128 * (int64_t)m.nCells) ? 1 : 0;
 }
 
@@ -684,6 +686,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
     const int lf = stream_lookup_mode(n, m, ss);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
+        if (lf == 3) return launch_stream_inst<B, R, SV, ST, 3>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 2) return launch_stream_inst<B, R, SV, ST, 2>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 1) return launch_stream_inst<B, R, SV, ST, 1>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         return launch_stream_inst<B, R, SV, ST, 0>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);         \

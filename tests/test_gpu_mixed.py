@@ -64,7 +64,13 @@ def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, w
 def _kernel_for(opts):
     if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
         return "cpf::step_kernel<0,"
-    return ", 2>"                                   # step_kernel_stream<..., 2>: fixed compare + mixed records
+    return ", 3>"                                   # step_kernel_stream<..., 3>: fixed compare + mixed records, no cell with > 6 slots
+
+
+def _kernel_for_big(opts):
+    if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
+        return "cpf::step_kernel<0,"
+    return ", 2>"                                   # ... 2>: header records of cells with more than six slots as well
 
 
 @pytest.mark.parametrize("seed", [1, 2])
@@ -133,7 +139,7 @@ def test_pentagonal_prisms_use_header_records(every, oracle_libs, gpu_ctx_factor
     t = cw.build(mesh)
     slots = np.diff(t.cell_off)
     assert set(slots) == {5, 6, 7} and (slots == 7).sum() * 4 <= mesh.n_cells and t.n_groups > 50
-    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for)
+    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for_big)
     assert (c >= 0).all() and (slots[c] == 7).sum() > 1000 and (slots[c] == 5).sum() > 300
 
 
@@ -207,18 +213,25 @@ def test_every_lane_of_a_tile_reflects_hit_pool_overflows(oracle_libs, gpu_ctx_f
             assert after["lost"] - before["lost"] == int(stats[2])
 
 
-def test_diffusion_on_a_mixed_mesh_loses_nobody(oracle_libs, gpu_ctx_factory):
-    """The Brownian kick on the refined box (the LOOKUP = 2 instantiation with the kick, hit points in the per-wave pool):
-    parity with the CPU statement is statistical there, so the check is the domain's own -- every boundary reflects, so
-    after 60 kicked cycles nobody is lost and every particle lies inside the cell it claims (all plane distances <= 0),
-    many-faced cells included."""
-    from cudaparticlesfoam_amd.cases import refined_box
-    mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
+@pytest.mark.parametrize("which", ["refined_box", "cut_corners"])
+def test_diffusion_on_a_mixed_mesh_loses_nobody(which, oracle_libs, gpu_ctx_factory):
+    """The Brownian kick on the refined box (LOOKUP = 3 with the kick: face groups, hit points in the per-wave pool) and
+    on the cut-corner grid (LOOKUP = 2: header records as well).  Parity with the CPU statement is statistical there, so
+    the check is the domain's own -- every boundary reflects, so after 60 kicked cycles nobody is lost and every particle
+    lies inside the cell it claims (all plane distances <= 0), many-faced cells included."""
+    if which == "refined_box":
+        from cudaparticlesfoam_amd.cases import refined_box
+        mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
+        hi, want = [8, 6, 5], ", 3>"
+    else:
+        from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
+        mesh, _ = cut_corner_box(11, 8, 3, every=4)
+        hi, want = [11, 8, 3], ", 2>"
     cw = oracle_libs.CellWalk()
     t = cw.build(mesh)
     rng = np.random.default_rng(23)
     n = 200_000
-    xyz = rng.uniform([0, 0, 0], [8, 6, 5], size=(n, 3))
+    xyz = rng.uniform([0, 0, 0], hi, size=(n, 3))
     U = rng.normal(size=(mesh.n_cells, 3)) * 0.5
     ctx = gpu_ctx_factory()
     ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
@@ -226,7 +239,7 @@ def test_diffusion_on_a_mixed_mesh_loses_nobody(oracle_libs, gpu_ctx_factory):
     ctx.sort_by_cell()
     before = ctx.counters()
     ctx.step(0.05, 0.4, 60)                                        # sigma = sqrt(2 D dt) = 0.2 cell widths per cycle
-    assert ", 2>" in ctx.step_kernel_name(0.4, 0)
+    assert want in ctx.step_kernel_name(0.4, 0)
     xyzw, cell = ctx.get_particles()
     after = ctx.counters()
     assert (cell >= 0).all() and after["lost"] == before["lost"] and after["reflections"] > before["reflections"]

@@ -25,10 +25,13 @@ def main():
     m0 = pz.pitzdaily_mesh()
     patch, _ = refined_pitzdaily()
     every, _ = refine_hexes(m0.points, m0.hexes, np.ones(m0.n_cells, bool), split_z=False)
+    one = np.zeros(m0.n_cells, bool); one[m0.n_cells // 2] = True
+    single, _ = refine_hexes(m0.points, m0.hexes, one, split_z=False)          # what the mixed instantiation itself costs
     cases = [("pitzDaily, patch refined 2x2x1: mixed records (streaming kernel)", patch, {}),
              ("same mesh, generic CSR walk", patch, {"mixed_records": 0}),
              ("pitzDaily refined 2x2x1 everywhere: all-hex", every, {}),
-             ("pitzDaily as it is: all-hex", m0, {})]
+             ("pitzDaily as it is: all-hex", m0, {}),
+             ("pitzDaily with ONE cell refined: mixed records (the instantiation's own cost)", single, {})]
     if os.environ.get("CPF_MIXED_3D", "1") != "0":
         # a 3-D mesh: graded 40 x 40 x 40 box with its central 20 x 20 x 20 block refined 2 x 2 x 2 (120 000 cells, the
         # ~2 400 unrefined cells around the block have 9 ... 21 faces), swirling field, particles over the whole box
@@ -36,9 +39,12 @@ def main():
         lo3, hi3 = (0.0, 0.0, 0.0), (0.3, 0.05, 0.05)
         b3, _ = refined_box(40, 40, 40, lo3, hi3, ((0.075, 0.0125, 0.0125), (0.225, 0.0375, 0.0375)), grading=(2.0, 1.0, 0.5))
         h3 = box_mesh(49, 49, 50, lower=lo3, upper=hi3, grading=(2.0, 1.0, 0.5))          # all-hex, about the same cell count
+        one3 = np.zeros(h3.n_cells, bool); one3[h3.n_cells // 2] = True
+        s3, _ = refine_hexes(h3.points, h3.hexes, one3, split_z=True)
         cases += [("3-D box, central block refined 2x2x2: mixed records", b3, {}, (lo3, hi3)),
                   ("same mesh, generic CSR walk", b3, {"mixed_records": 0}, (lo3, hi3)),
-                  ("3-D box of the same cell count: all-hex", h3, {}, (lo3, hi3))]
+                  ("3-D box of the same cell count: all-hex", h3, {}, (lo3, hi3)),
+                  ("that all-hex box with ONE cell refined: mixed records", s3, {}, (lo3, hi3))]
     for case in cases:
         label, mesh, opts = case[:3]
         box3 = case[3] if len(case) > 3 else None
