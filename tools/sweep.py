@@ -45,6 +45,9 @@ def main():
     n = int(args.particles)
     x0, y0, z0, c0 = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
     g0 = torch.arange(n, dtype=torch.int64, device=dev)
+    for kv in args.opt:                      # (before the sort: some options shape the sort key)
+        k, v = kv.split("=")
+        ctx.set_option(k, float(v))
     if not args.unsorted:
         ctx.sort_by_cell_dev(x0.data_ptr(), y0.data_ptr(), z0.data_ptr(), c0.data_ptr(), g0.data_ptr(), n)
     torch.cuda.synchronize()
@@ -52,9 +55,6 @@ def main():
     rows = []
     if args.no_stats:
         ctx.set_option("stats", 0)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        ctx.set_option(k, float(v))
     for v in [int(s) for s in args.variants.split(",")]:
         ctx.set_option("step_variant", v)
         x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
