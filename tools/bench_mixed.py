@@ -34,7 +34,7 @@ def main():
              ("pitzDaily with ONE cell refined: mixed records (the instantiation's own cost)", single, {})]
     if os.environ.get("CPF_MIXED_3D", "1") != "0":
         # a 3-D mesh: graded 40 x 40 x 40 box with its central 20 x 20 x 20 block refined 2 x 2 x 2 (120 000 cells, the
-        # ~2 400 unrefined cells around the block have 9 ... 21 faces), swirling field, particles over the whole box
+        # 2 242 unrefined cells around the block have 9 faces), swirling field, particles over the whole box
         from cudaparticlesfoam_amd.cases import box_mesh, refined_box
         lo3, hi3 = (0.0, 0.0, 0.0), (0.3, 0.05, 0.05)
         b3, _ = refined_box(40, 40, 40, lo3, hi3, ((0.075, 0.0125, 0.0125), (0.225, 0.0375, 0.0375)), grading=(2.0, 1.0, 0.5))
