@@ -18,7 +18,8 @@ def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
     v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
                   [0, 0.05, 0.05]], float)
-    mesh = block_mesh(v, [dict(hex=range(8), n=(64, 64, 60), simple=(2.0, 1.0, 0.5))])
+    nbox = tuple(int(k) for k in os.environ.get("CPF_BOX_N", "64,64,60").split(","))     # e.g. 128,128,128: motorBike scale (2.1e6 cells)
+    mesh = block_mesh(v, [dict(hex=range(8), n=nbox, simple=(2.0, 1.0, 0.5))])
     tjunction = os.environ.get("CPF_TJUNCTION")           # the reference's TJunction tutorial mesh instead (248 000 cells)
     if tjunction:
         from cudaparticlesfoam_amd.cases import tjunction as tj
