@@ -173,6 +173,7 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
             out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
         }
         out.cellOff[(size_t)nCells] = (int32_t)w;
+        if ((int64_t)out.groupOff.size() > (int64_t(1) << 30) - 32) return "too many face groups for 32-bit neighbour codes";
         out.nSlots = w;
         out.planes.resize((size_t)w * 4);
         out.nbr.resize((size_t)w);

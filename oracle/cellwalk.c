@@ -161,6 +161,7 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
         }
         cellOff[nCells] = w;
         free(memSlot); free(memNbr);
+        if (nGroups > (1 << 30) - 32) return -1;
         *nGroupsOut = nGroups;
     }
     /* z-layered meshes: z faces last (see above) */
