@@ -250,6 +250,28 @@ class Context:
         return a.value, b.value
 
 
+def build_mesh_tables_host(mesh):
+    """What ``Context.set_mesh(mesh)`` would build and upload, computed on the host alone (no GPU, no context): a dict with
+    cell_off, planes (n_slots, 4), nbr, group_off, group_nbr -- one slot per distinct plane of a cell, face groups for the
+    coplanar pieces of a split face (``include/cpf.h``: cpf_build_mesh_tables_host)."""
+    lib = L.load()
+    a = [np.ascontiguousarray(mesh.points, dtype=np.float64), np.ascontiguousarray(mesh.face_offsets, dtype=np.int32),
+         np.ascontiguousarray(mesh.face_verts, dtype=np.int32), np.ascontiguousarray(mesh.owner, dtype=np.int32),
+         np.ascontiguousarray(mesh.neighbour, dtype=np.int32)]
+    ns, ng, nm = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+
+    def call(*out):
+        st = lib.cpf_build_mesh_tables_host(_ptr(a[0]), mesh.n_points, _ptr(a[1]), _ptr(a[2]), mesh.n_faces, _ptr(a[3]), _ptr(a[4]),
+                                            mesh.n_internal, mesh.n_cells, C.byref(ns), C.byref(ng), C.byref(nm), *out)
+        if st != L.CPF_OK:
+            raise L.CpfError(st, "cpf_build_mesh_tables_host")
+    call(None, None, None, None, None)
+    off = np.empty(mesh.n_cells + 1, np.int32); planes = np.empty((ns.value, 4), np.float64); nbr = np.empty(ns.value, np.int32)
+    goff = np.empty(ng.value + 1, np.int32); gnbr = np.empty(max(nm.value, 1), np.int32)
+    call(_ptr(off), _ptr(planes), _ptr(nbr), _ptr(goff), _ptr(gnbr))
+    return dict(cell_off=off, planes=planes, nbr=nbr, group_off=goff, group_nbr=gnbr[:nm.value])
+
+
 def pack_mesh_parts(parts):
     """(ctypes array of cpf_mesh_part, the numpy arrays it points into)."""
     arr = (L.MeshPart * len(parts))()

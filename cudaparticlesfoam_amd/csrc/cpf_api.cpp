@@ -322,6 +322,30 @@ int cpf_set_mesh_l64(cpf_context* ctx, const double* points, int64_t nPoints, co
                                 nCells);
 }
 
+int cpf_build_mesh_tables_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                               int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                               int64_t* nSlots, int64_t* nGroups, int64_t* nMembers, int32_t* cellOff, double* planes,
+                               int32_t* nbr, int32_t* groupOff, int32_t* groupNbr) {
+    if (!points || !faceOffsets || !faceVerts || !owner || (!neighbour && nInternal != 0)) return CPF_ERR_ARG;
+    cpf::HostTables t;
+    try {
+        const std::string why = cpf::build_tables<int32_t>(points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour, nInternal, nCells, t);
+        if (!why.empty()) return CPF_ERR_MESH;
+    } catch (const std::bad_alloc&) {
+        return CPF_ERR_NOMEM;
+    }
+    const int64_t g = t.nGroups(), mem = t.groupOff[(size_t)g];
+    if (nSlots) *nSlots = t.nSlots;
+    if (nGroups) *nGroups = g;
+    if (nMembers) *nMembers = mem;
+    if (cellOff) std::memcpy(cellOff, t.cellOff.data(), t.cellOff.size() * 4);
+    if (planes) std::memcpy(planes, t.planes.data(), t.planes.size() * 8);
+    if (nbr) std::memcpy(nbr, t.nbr.data(), t.nbr.size() * 4);
+    if (groupOff) std::memcpy(groupOff, t.groupOff.data(), (size_t)(g + 1) * 4);
+    if (groupNbr) std::memcpy(groupNbr, t.groupNbr.data(), (size_t)mem * 4);
+    return CPF_OK;
+}
+
 int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nSlots, int64_t* deviceBytes) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_mesh_info: no mesh set");

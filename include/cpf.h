@@ -130,6 +130,15 @@ int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes
  * groupNbr[groupOff[g] .. groupOff[g+1]).  Any pointer may be NULL; groupOff[nGroups+1], groupNbr[nMembers]. */
 int cpf_get_mesh_groups(const cpf_context* ctx, int64_t* nGroups, int64_t* nMembers, int32_t* groupOff, int32_t* groupNbr);
 
+/* The tables cpf_set_mesh would build and upload, on the host alone: no context, no GPU (a check of the mesh layer on a
+ * machine without a device; what an exotic mesh is ingested as).  Call with the array pointers NULL for the sizes, then
+ * again with cellOff[nCells+1], planes[nSlots][4], nbr[nSlots], groupOff[nGroups+1], groupNbr[nMembers].  CPF_ERR_MESH
+ * for a mesh cpf_set_mesh would refuse. */
+int cpf_build_mesh_tables_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                               int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                               int64_t* nSlots, int64_t* nGroups, int64_t* nMembers, int32_t* cellOff, double* planes,
+                               int32_t* nbr, int32_t* groupOff, int32_t* groupNbr);
+
 /* Cell-constant velocity U[nCells][3] (host, zero-copy from U.primitiveField()).  Replaces the
  * 12x replication loop + cudaUpdateVelocity of src/advect.H:44-57 (cuda/particles.cu:718-749):
  * nCells*24 B cross PCIe instead of 12*nCells*24 B. */

@@ -1,0 +1,58 @@
+"""CPU: the product's mesh layer (csrc/cpf_mesh.cpp through the C-ABI's host-only entry cpf_build_mesh_tables_host) builds
+the tables the CPU statement (oracle/cellwalk.c, cw_build) builds -- offsets, planes, neighbour codes and face groups, bit
+for bit -- on hex meshes (the only ones the reference runs, src/initCuda.H:64: slots == faces there) and on meshes with
+coplanar faces, prisms and true polyhedra.  The two are written independently; the GPU tests repeat the comparison on the
+tables actually uploaded."""
+import numpy as np
+import pytest
+
+
+def _same(mesh, oracle_libs):
+    from cudaparticlesfoam_amd.api import build_mesh_tables_host
+    t = oracle_libs.CellWalk().build(mesh)
+    h = build_mesh_tables_host(mesh)
+    assert np.array_equal(h["cell_off"], t.cell_off) and np.array_equal(h["nbr"], t.nbr)
+    assert np.array_equal(h["planes"], t.planes.reshape(-1, 4))                 # bit-exact plane coefficients
+    assert np.array_equal(h["group_off"], t.group_off) and np.array_equal(h["group_nbr"], t.group_nbr[:t.group_off[-1]])
+    return t
+
+
+def test_pitzdaily_and_tjunction_have_no_groups(oracle_libs, pitz):
+    from cudaparticlesfoam_amd.cases import tjunction as tj
+    t = _same(pitz["mesh"], oracle_libs)
+    assert t.n_groups == 0 and t.cell_off[-1] == 49180 + 24170                   # slots == faces + internal faces
+    t = _same(tj.tjunction_mesh(), oracle_libs)                                  # 248 000 cells, multi-block
+    assert t.n_groups == 0 and t.cell_off[-1] == 6 * 248000
+
+
+def test_refined_meshes_merge_coplanar_pieces(oracle_libs):
+    from cudaparticlesfoam_amd.cases import refined_box, refined_pitzdaily
+    mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
+    t = _same(mesh, oracle_libs)
+    assert np.diff(mesh.cell_faces()[0]).max() >= 18 and np.diff(t.cell_off).max() == 6 and t.n_groups == 86
+    assert set(np.diff(t.group_off)) == {4}                                      # a face split 2 x 2: four pieces
+    g = t.nbr[t.nbr < -(1 << 30)] - t.GROUP_BASE
+    assert np.array_equal(np.sort(g), np.arange(t.n_groups))                     # every group is some slot's neighbour code, once
+    mesh, _ = refined_pitzdaily()
+    t = _same(mesh, oracle_libs)
+    assert t.n_groups == 87 and set(np.diff(t.group_off)) == {2} and set(np.diff(t.cell_off)) == {6}
+
+
+@pytest.mark.parametrize("every", [1, 4])
+def test_cut_corner_grid_keeps_seven_slot_cells(every, oracle_libs):
+    from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
+    mesh, kinds = cut_corner_box(9, 7, 2, every=every)
+    t = _same(mesh, oracle_libs)
+    slots = np.diff(t.cell_off)
+    assert (slots == 7).sum() == 2 * kinds["pentagons"] and (slots == 5).sum() == 2 * kinds["triangles"]
+    assert t.n_groups >= 2 * kinds["squares_with_hanging_node"]
+
+
+def test_a_mesh_the_product_refuses_is_refused_here_too():
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import build_mesh_tables_host
+    from cudaparticlesfoam_amd.cases import box_mesh
+    m = box_mesh(2, 2, 2)
+    m.owner = m.owner.copy(); m.owner[0] = 99                                     # out of range
+    with pytest.raises(L.CpfError):
+        build_mesh_tables_host(m)
