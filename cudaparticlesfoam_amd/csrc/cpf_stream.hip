@@ -37,12 +37,22 @@ namespace cpf {
 #ifndef CPF_STREAM_SLOTS
 #define CPF_STREAM_SLOTS 6
 #endif
+#ifndef CPF_STREAM_SLOTS_FIXED
+#define CPF_STREAM_SLOTS_FIXED 9
+#endif
 #ifndef CPF_STREAM_WAVES
 #define CPF_STREAM_WAVES 7
 #endif
-constexpr int kStreamSlots = CPF_STREAM_SLOTS;          // record slots per wave (4..32)
+// Record slots per wave (4..32) and records requested per round, by lookup method.  Many particles per cell (the loop lookup:
+// 1-3 distinct cells per round): 6 slots, up to 4 requests.  Few particles per cell (the fixed compare: 5-13 distinct cells per
+// tile): 9 slots -- what fits under the LDS a 7th wave leaves, 5632 of 5851 bytes -- and up to 8 requests per round, so that
+// fewer lanes sit a round out for want of a slot.  Measured on one box, 6 / 4 -> 9 / 8: 3-D bench box 0.2759 -> 0.2663 ms,
+// TJunction 0.1595 / 0.1757 -> 0.1557 / 0.1683, 2.1e6-cell box with 5 particles per cell 0.738 -> 0.682 (12 slots: a wave
+// per SIMD less, 0.267 / 0.692); pitzDaily with 9 / 8 LOSES 5 % (0.1190 -> 0.1250), hence per lookup method.
+constexpr int kStreamSlots = CPF_STREAM_SLOTS;
+constexpr int kStreamSlotsFixed = CPF_STREAM_SLOTS_FIXED;
 constexpr int kSlotStride = 8;                          // double4 per slot = one 256-byte record, see `slots`
-static_assert(kStreamSlots >= 4 && kStreamSlots <= 32, "slots");
+static_assert(kStreamSlots >= 4 && kStreamSlots <= 32 && kStreamSlotsFixed >= 4 && kStreamSlotsFixed <= 32, "slots");
 #ifndef CPF_STREAM_GATHER_LANES
 #define CPF_STREAM_GATHER_LANES 32
 #endif
@@ -78,7 +88,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,   // read through kernarg_cloud_ptrs()
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
-    constexpr int NS = kStreamSlots;
+    // (with the kick the landing zone and the hit pool are larger: 7 slots keep the sixth wave, 6600 of 6826 bytes)
+    constexpr int NS = LOOKUP == 0 ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? 7 : kStreamSlotsFixed);
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
     // the wave's record cache.  (256 bytes per slot is one full turn of the 64 LDS banks, so lanes reading the same plane
     // of different slots conflict: 50 conflict cycles per tile on pitzDaily, 351 on the 3-D bench mesh.  Padding the
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         todo &= ~same;
                     }
                 }
-                // ---- misses: up to four records per round, each a 256-byte LDS-DMA by lanes 0..15 straight into its
+                // ---- misses: up to four (fixed lookup: eight) records per round, each a 256-byte LDS-DMA by lanes 0..15 straight into its
                 // slot; victims are taken oldest-first among the slots nobody reads this round
                 int nJobs = 0;
                 if (missLanes != 0ull) {
@@ -387,6 +398,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         nJobs = J + 1;                                                                      \
                     }
                     CPF_JOB(0) CPF_JOB(1) CPF_JOB(2) CPF_JOB(3)
+                    if (LOOKUP != 0) { CPF_JOB(4) CPF_JOB(5) CPF_JOB(6) CPF_JOB(7) }
 #undef CPF_JOB
                 }
                 int younger = 0;
