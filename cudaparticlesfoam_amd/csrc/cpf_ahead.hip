@@ -366,9 +366,9 @@ static hipError_t launch_ahead_inst(hipStream_t st, double* x, double* y, double
     }
     const int64_t nTiles = (n + 63) >> 6;
     const int64_t slotsOnChip = (int64_t)(ss.wavesPerCU > 0 ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
-    int tpc = ss.tilesPerChunk;
+    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : 4;
     while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc >>= 1;
-    int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - ss.tailFraction));
+    int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - (ss.tailFraction >= 0.0 ? ss.tailFraction : 0.1)));
     if (tpc == 1 || bigChunks < 0) bigChunks = 0;
     const int64_t nChunks = bigChunks + (nTiles - bigChunks * tpc);
     int64_t R = slotsOnChip / kStreamGroups;

@@ -49,11 +49,11 @@ struct StreamState {
     int hitSpillWaves = 0;          // wave slots d_hitSpill has room for (the launcher never starts more single-wave workgroups)
     int parity = 0;
     int numCU = 256;
-    int tilesPerChunk = 4;    // "stream_tiles_per_chunk"
+    int tilesPerChunk = 0;    // "stream_tiles_per_chunk"; 0 = by lookup method: 4 (loop lookup), 3 (fixed lookup: slower tiles, finer dealing)
     int wavesPerCU = 0;       // "stream_waves_per_cu": 0 = what the occupancy query says
     int coopMaxCells = 0;     // "coop_max_cells": test hook, lowers the wave-cooperative kernel's 2^24-cell limit (0 = the limit)
     int lookup = -1;          // "stream_lookup": 0 loop over distinct cells, 1 fixed tag compare, -1 = by particles per cell
-    double tailFraction = 0.1;  // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch
+    double tailFraction = -1.0; // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch; < 0 = by lookup method: 0.1 / 0.2
     int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
 };
 

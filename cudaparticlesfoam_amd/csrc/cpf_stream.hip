@@ -660,10 +660,15 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     if (nTiles >= ((int64_t)1 << 31)) return hipErrorInvalidValue;      // the kernel numbers tiles and chunks in 32 bits
     const int64_t slotsOnChip = (int64_t)(ss.wavesPerCU > 0 ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
     // small clouds: shorter chunks, so that every wave slot still gets several
-    int tpc = ss.tilesPerChunk;
-    while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc >>= 1;
+    // dealing knobs, by lookup method unless set: few particles per cell = slower tiles (more rounds, record misses), so
+    // finer chunks and a longer tile-by-tile tail (tools/sweep3d_opts.sh: 3 / 0.2 against 4 / 0.1 on the 3-D box 0.2632 /
+    // 0.2701 -> 0.2585 / 0.2661 ms, TJunction 0.1581 / 0.1708 -> 0.1569 / 0.1687, 5 particles per cell 0.682 / 0.670 -> 0.677 /
+    // 0.636; pitzDaily is at its optimum with 4 / 0.1, tools/tail_sweep.sh)
+    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : (LF == 0 ? 4 : 3);
+    const double tailFraction = ss.tailFraction >= 0.0 ? ss.tailFraction : (LF == 0 ? 0.1 : 0.2);
+    while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc = tpc > 2 ? tpc - 1 : 1;
     // the first (1 - tailFraction) of the cloud in chunks of tpc tiles, the rest tile by tile
-    int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - ss.tailFraction));
+    int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - tailFraction));
     if (tpc == 1 || bigChunks < 0) bigChunks = 0;
     const int64_t nChunks = bigChunks + (nTiles - bigChunks * tpc);
     int64_t R = slotsOnChip / kStreamGroups;                 // waves per group

@@ -206,7 +206,7 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   quarter of the cells have more than six faces: cells with fewer than six faces get padded records,
  *                   cells with more a header record and are walked through the CSR tables inside kernel 4.  0 = such
  *                   meshes run the generic walk (kernel 0)
- *   "stream_tiles_per_chunk" (4), "stream_tail_fraction" (0.1), "stream_waves_per_cu" (0 = occupancy query):
+ *   "stream_tiles_per_chunk" (4; 3 on meshes with few particles per cell), "stream_tail_fraction" (0.1; 0.2), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare): how a wave finds its cells in its record cache;
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
