@@ -716,7 +716,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         return CPF_OK;
     }
     if (k == "stream_lookup") {
-        CPF_REQUIRE(ctx, value >= -1 && value <= 1, CPF_ERR_ARG, "stream_lookup must be -1 (auto), 0 or 1");
+        CPF_REQUIRE(ctx, value == -1 || value == 0 || value == 1 || value == 4, CPF_ERR_ARG, "stream_lookup must be -1 (auto), 0, 1 or 4");
         ctx->streamState.lookup = (int)value;
         return CPF_OK;
     }

@@ -68,6 +68,7 @@ constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a
 #ifndef CPF_STREAM_HIT_POOL
 #define CPF_STREAM_HIT_POOL 40
 #endif
+constexpr int kStreamSparsePerCell = 8;                      // fewer particles per cell than this: the sparse instantiation (LOOKUP 4)
 constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
 // The kernel's parameter list as the kernarg segment lays it out (each parameter at its natural alignment, in order):
@@ -81,7 +82,11 @@ static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell)
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
-struct StreamOccupancy { static constexpr int waves = (STORE_VEL || STATS) ? 1 : (BROWNIAN ? (LOOKUP >= 2 ? 5 : 6) : (LOOKUP >= 2 ? 6 : CPF_STREAM_WAVES)); };   // (LOOKUP 3 as 0 / 1)
+// LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
+struct StreamOccupancy {
+    static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3;
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (kMixed ? 6 : CPF_STREAM_WAVES)));
+};
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
 __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    constexpr int kPool = HIT_IN_REGS ? 1 : (LOOKUP >= 2 ? 16 : CPF_STREAM_HIT_POOL);
+    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3) ? 16 : CPF_STREAM_HIT_POOL);
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -126,9 +131,15 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   0 loop over the distinct cells of the wave, 1 fixed tag compare, 2 / 3 fixed tag compare on a mesh that is not
     //   all-hex (MeshView::mixed): 3 = every cell has at most six slots -- face groups and padded records only, the usual
     //   2:1-refined hex mesh --, 2 = header records of cells with more than six slots may turn up as well
+    //   4 = fixed tag compare for SPARSE clouds on all-hex meshes (fewer than kStreamSparsePerCell particles per cell: nearly
+    //   every lane of a tile sits in a cell of its own and walks by per-lane gathers from L2 / HBM): the gather walk keeps three
+    //   planes in flight instead of one -- two dependent round trips per visit instead of six -- for 24 more registers, i.e.
+    //   five waves per SIMD.  2.1e6-cell box: 1.25e6 particles (one rank's share of BASELINE configs[4]) 0.187 -> 0.141 ms,
+    //   1e7 particles 0.673 / 0.631 -> 0.641 / 0.607; in the dense regime the same change costs 6 % (0.259 -> 0.277)
     constexpr bool LOOKUP_FIXED = LOOKUP != 0;
-    constexpr bool mixed = LOOKUP >= 2;
+    constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3;
     constexpr bool bigCells = LOOKUP == 2;
+    constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
     const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                 if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
                             }
                             if (!gBig)
-                            next = trace_fixed<6, false, mixed>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
+                            next = trace_fixed<6, false, mixed, kGatherAhead>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                             if (STATS) ++st.hops;
                             // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
                             // at the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
@@ -693,7 +704,9 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
 int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
     if (m.mixed) return m.mixed == 2 ? 2 : 3;  // not all-hex: with / without header records (cells with more than six slots)
-    return (ss.lookup >= 0 ? ss.lookup != 0 : n < 128 * (int64_t)m.nCells) ? 1 : 0;
+    if (ss.lookup >= 0) return ss.lookup;      // "stream_lookup": 0, 1 or 4
+    if (n < kStreamSparsePerCell * (int64_t)m.nCells) return 4;
+    return n < 128 * (int64_t)m.nCells ? 1 : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
@@ -703,6 +716,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
     const int lf = stream_lookup_mode(n, m, ss);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
+        if (lf == 4) return launch_stream_inst<B, R, SV, ST, 4>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 3) return launch_stream_inst<B, R, SV, ST, 3>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 2) return launch_stream_inst<B, R, SV, ST, 2>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 1) return launch_stream_inst<B, R, SV, ST, 1>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

@@ -107,23 +107,39 @@ __device__ __forceinline__ int trace_in_cell(D3& S, const D3& E, int cur, const 
 // exactly like the isinf -> -1 substitution of ConvexQuery.cu:89.
 // `pl`/`nb` may be wave-uniform pointers (scalar loads, one fetch per wave) or per-lane ones.
 // GROUPS: the mesh may hold face groups -- such a slot is only left with den < 0 (see above)
-template <int NF, bool SKIP_ZERO_DEN, bool GROUPS = false>
+// AHEAD: request that many planes (and all neighbour ids) before the first test and keep that many in flight -- per-lane
+// gathers from L2 / HBM, where six dependent round trips are the cost of the visit
+template <int NF, bool SKIP_ZERO_DEN, bool GROUPS = false, int AHEAD = 0>
 __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const double4* __restrict__ pl,
                                            const int32_t* __restrict__ nb, int token, int& outSlot, int slotBase) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
     double dTmin = 1.1;
+    double4 ahead[AHEAD > 0 ? AHEAD : 1];
+    int nbAll[AHEAD > 0 ? NF : 1];
+    if (AHEAD > 0) {
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s) ahead[s] = pl[s];
+#pragma unroll
+        for (int s = 0; s < NF; ++s) nbAll[s] = nb[s];
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s) asm volatile("" : "+v"(ahead[s].x), "+v"(ahead[s].y), "+v"(ahead[s].z), "+v"(ahead[s].w));
+    }
 #pragma unroll
     for (int s = 0; s < NF; ++s) {
-        const double4 p = pl[s];
+        double4 p;
+        if (AHEAD > 0) {
+            p = ahead[s % AHEAD];
+            if (s + AHEAD < NF) ahead[s % AHEAD] = pl[s + AHEAD];
+        } else p = pl[s];
         const double den = dot3(p, Pd);
         // no lane of the wave moves across this face's plane (den == +-0 exactly, e.g. the front/back
         // faces of a one-cell-thick mesh, or wall-parallel faces in aligned flow): dT would be +-inf
         // (-> -1) or NaN, never accepted (ConvexQuery.cu:86-95), so the face costs nothing more
         // (only worth a branch when the planes are already on chip: it would serialise global gathers)
         if (SKIP_ZERO_DEN && ballot64(den != 0.0) == 0ull) continue;
-        const int bs = nb[s];
+        const int bs = AHEAD > 0 ? nbAll[s] : nb[s];
         const double fd = plane_dist(p, P0);
         // |fd| <= |den| (one compare with abs modifiers) and equal sign bits (integer test); zeros and
         // NaNs that slip through give dT = 0 / NaN and fail dT > tol below, as in the reference

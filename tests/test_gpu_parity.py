@@ -748,12 +748,12 @@ def test_config5_transient_velocity_on_refined_mesh(oracle_libs, gpu_ctx_factory
     assert upload / 5 < 0.05                        # 4.7 MB per refresh; the reference would move 56 MB
 
 
-@pytest.mark.parametrize("lookup", [0, 1])
+@pytest.mark.parametrize("lookup", [0, 1, 4])
 @pytest.mark.parametrize("sort", [True, False])
 def test_stream_record_lookup_methods(setup, lookup, sort):
     """The streaming kernel finds a wave's cells in its record cache either by a loop over the distinct cells or by a
-    fixed compare against the tag vector (option stream_lookup; picked per launch from the particles per cell).  Both,
-    on a sorted cloud (1-3 cells per wave) and an unsorted one (up to 64: gather rounds, lanes sitting rounds out),
+    fixed compare against the tag vector, the latter also in its form for sparse clouds (pipelined per-lane gathers;
+    option stream_lookup; picked per launch from the particles per cell).  All three, on a sorted cloud (1-3 cells per wave) and an unsorted one (up to 64: gather rounds, lanes sitting rounds out),
     with and without the Brownian kick: bit-identical to the CPU statement."""
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     U = setup["pitz"]["U_analytic"]
@@ -772,7 +772,7 @@ def test_stream_record_lookup_methods(setup, lookup, sort):
         x, y, z = (xyz[:, k].copy() for k in range(3))
         c = cell0.copy()
         name = ctx.step_kernel_name(D)
-        assert name.endswith(", %d>" % (1 if lookup else 0)) and "step_kernel_stream" in name
+        assert name.endswith(", %d>" % lookup) and "step_kernel_stream" in name
         if D == 0.0:
             for k in (1, 12):
                 ctx.step(1e-4, D, k)
@@ -793,7 +793,7 @@ def test_stream_record_lookup_methods(setup, lookup, sort):
             ctx.synchronize()
             got = tuple(a.cpu().numpy() for a in (tx, ty, tz, tc))
             ref = setup.setdefault("_lookup_ref", {})
-            if sort in ref:                                       # the two methods agree bit for bit with each other
+            if sort in ref:                                       # the methods agree bit for bit with each other
                 assert all(np.array_equal(a, b) for a, b in zip(ref[sort], got))
             else:
                 ref[sort] = got
