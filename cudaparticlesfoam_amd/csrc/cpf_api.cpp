@@ -27,6 +27,7 @@ struct cpf_context {
     double4* d_planes = nullptr;
     int32_t* d_nbr = nullptr;
     int32_t *d_groupOff = nullptr, *d_groupNbr = nullptr;
+    bool zFold = true;               // "z_fold": mirror the kicked end point about the planes of a one-cell-thick mesh before the walk
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes)
@@ -119,6 +120,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
+    m.zThin = (c->host.zThin && c->zFold) ? 1 : 0;
     m.mixed = (c->d_cellRec && !m.allHex) ? (c->host.nBigCells > 0 ? 2 : 1) : 0;
     return m;
 }
@@ -677,6 +679,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
                     "step_variant 1, 2 and 5 are experiments (measured slower on every mesh) and not in this build: make EXPERIMENTS=1");
 #endif
         ctx->stepVariant = (int)value;
+        return CPF_OK;
+    }
+    if (k == "z_fold") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "z_fold must be 0 or 1");
+        ctx->zFold = value != 0;
         return CPF_OK;
     }
     if (k == "mixed_records") {

@@ -24,6 +24,7 @@ struct MeshView {
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s) and there are no face groups
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
+    int32_t zThin;            // ... and both are boundary faces in every cell: one cell thick in z (cpf_walk.h, fold_z)
     int32_t mixed;            // records exist although the mesh is not all-hex: 1 = padded records (< 6 slots) and face groups only, 2 = header-only records (> 6 slots) as well
 };
 

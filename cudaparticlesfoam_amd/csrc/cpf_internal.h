@@ -29,6 +29,7 @@ struct HostTables {
     int32_t maxCellFaces = 0, minCellFaces = 0;   // slots per cell
     int64_t nBigCells = 0;          // cells with more than 6 slots
     int64_t nGroups() const { return (int64_t)groupOff.size() - 1; }
+    bool zThin = false;             // zPairLast and the two z faces of every cell are boundary faces (one cell thick in z)
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes

@@ -41,6 +41,14 @@ __device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView
         }
         // ---- locate + reflect (ConvexQuery.cu:135-216, :320-436)
         D3 E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+        bool folded = false;
+        if (BROWNIAN && REFLECT && m.zThin) {                    // one cell thick in z: cpf_walk.h, fold_z
+            const int s0 = m.cellOff[cur];
+            const int nb = fold_z(E.z, m.planes[s0 + 4], m.planes[s0 + 5]);
+            st.refl += nb;
+            if (nb & 1) v.z = -v.z;
+            folded = nb != 0;
+        }
         D3 S = P, hit = P;
         int token = INT32_MIN, next = cur, outSlot = 0;
         bool reflected = false;
@@ -64,7 +72,7 @@ __device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView
         }
         // ---- move (particles.cu:693-701); reflected: p = P_hit, disp = P_end - P_hit
         if (reflected) P = {hit.x + (E.x - hit.x), hit.y + (E.y - hit.y), hit.z + (E.z - hit.z)};
-        else P = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+        else P = {P.x + disp.x, P.y + disp.y, folded ? E.z : P.z + disp.z};
         if (next < 0) { next = CPF_CELL_LOST; ++st.lost; }
         cur = next;
     }
@@ -215,6 +223,11 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                             disp = axpy(sigma, xi, disp);
                         }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                        if (BROWNIAN && REFLECT && m.zThin) {                      // one cell thick in z: cpf_walk.h, fold_z
+                            const int nb = fold_z(E.z, rec[4], rec[5]);
+                            if (STATS) st.refl += nb;
+                            if (STORE_VEL && (nb & 1)) v.z = -v.z;
+                        }
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;
                     }
@@ -234,6 +247,11 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                             disp = axpy(sigma, xi, disp);
                         }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
+                        if (BROWNIAN && REFLECT && m.zThin) {
+                            const int nb = fold_z(E.z, rec[4], rec[5]);
+                            if (STATS) st.refl += nb;
+                            if (STORE_VEL && (nb & 1)) v.z = -v.z;
+                        }
                         sE[0][tid] = E.x; sE[1][tid] = E.y; sE[2][tid] = E.z;
                         needAdvect = false;
                     }

@@ -46,6 +46,20 @@ bool face_plane(const double* pts, const Label* verts, int nv, Vec& n, Vec& cent
     double len = std::sqrt(dot(sumN, sumN));
     if (!(len > 0.0)) return false;
     n = {sumN.x / len, sumN.y / len, sumN.z / len};
+    // Components that are rounding noise (|n_k| <= 1e-12 of a unit normal: the cross products of a face that lies in a
+    // coordinate plane leave 1e-16 ... 1e-13 there) are ZERO: an axis-aligned face then has an exactly axis-aligned
+    // normal, its denominator n . Pd is exactly 0 for every particle that does not move along that axis, and the walk's
+    // zero-denominator skips (cpf_walk.h) -- in particular the one test that drops both z faces of a 2-D case -- can
+    // fire.  pitzDaily: 30 % of the front/back faces came out with |nx|, |ny| ~ 1e-16, which switched the z-pair skip
+    // off for the whole mesh.  Stated independently in oracle/cellwalk.c (the tables are compared bit for bit).
+    const bool sx = std::fabs(n.x) <= 1e-12, sy = std::fabs(n.y) <= 1e-12, sz = std::fabs(n.z) <= 1e-12;
+    if (sx || sy || sz) {
+        if (sx) n.x = 0.0;
+        if (sy) n.y = 0.0;
+        if (sz) n.z = 0.0;
+        const double l2 = std::sqrt(dot(n, n));
+        n = {n.x / l2, n.y / l2, n.z / l2};
+    }
     return true;
 }
 
@@ -217,6 +231,12 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
             std::memcpy(&out.planes[4 * s0], pl, sizeof(pl));
             std::memcpy(&out.nbr[s0], nb, sizeof(nb));
         }
+    }
+
+    out.zThin = out.zPairLast;
+    for (int64_t c = 0; c < nCells && out.zThin; ++c) {
+        const size_t s0 = (size_t)out.cellOff[(size_t)c];
+        if (out.nbr[s0 + 4] >= 0 || out.nbr[s0 + 5] >= 0) out.zThin = false;
     }
 
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
+    const bool zFold = BROWNIAN && REFLECT && m.zThin != 0;
     const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
@@ -452,7 +453,12 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
                         disp = axpy(sigma, xi, disp);
                     }
-                    const D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
+                    D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
+                    if (BROWNIAN && REFLECT && zFold) {                           // one cell thick in z: cpf_walk.h, fold_z
+                        const int nb = fold_z(E.z, rec[4], rec[5]);
+                        if (STATS) st.refl += nb;
+                        if (STORE_VEL && (nb & 1)) v.z = -v.z;
+                    }
                     sE[0][lane] = E.x; sE[1][lane] = E.y; sE[2][lane] = E.z;
                     return E;
                 };

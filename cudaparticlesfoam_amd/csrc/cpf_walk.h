@@ -64,6 +64,29 @@ __device__ __forceinline__ int resolve_group(int code, const D3& X, const int32_
     return pick;
 }
 
+// THIN z-LAYERED MESHES AND THE BROWNIAN KICK (MeshView::zThin: every cell is a hex whose slots 4, 5 are boundary faces with
+// normals exactly along z -- a 2-D case extruded one cell thick, both tutorials' pitzDaily).  With the kick 5-10 % of the
+// particles cross the front or back plane per cycle; the reference walks each of them to the plane, mirrors the end point
+// and walks on (ConvexQuery.cu:286-309).  The side faces of such a mesh have nz == 0 exactly, so the cells a segment
+// crosses depend on its x-y projection alone, and mirroring about a z plane leaves that projection alone: the end point
+// can be mirrored about the planes BEFORE the walk -- same cells, same final point (E' = E - 2 (n.E - d) n, the
+// reference's own formula, applied to the end point instead of at the hit) -- and the walk never meets the planes.  In exact
+// arithmetic the two are the same trajectory; in floating point the final z differs by the rounding of the hit point the
+// reference passes through (parity with the kick is statistical by contract, SURVEY.md 8c: the generator differs).  Only
+// with the kick and reflecting walls; D = 0 runs keep the reference's order of operations bit for bit.
+// Returns the number of mirrorings (statistics; an odd number flips the stored velocity's z).
+__device__ __forceinline__ int fold_z(double& ez, const double4& pa, const double4& pb) {
+    const double za = pa.w * pa.z, zb = pb.w * pb.z;          // plane (0, 0, nz, d), nz = +-1: z = d / nz = d * nz, exactly
+    const double lo = fmin(za, zb), hi = fmax(za, zb);
+    int nb = 0;
+#pragma unroll 1
+    for (int k = 0; k < kMaxReflect && ballot64(ez < lo || ez > hi) != 0ull; ++k) {
+        if (ez < lo) { ez = fma(-2.0, ez - lo, ez); ++nb; }
+        else if (ez > hi) { ez = fma(-2.0, ez - hi, ez); ++nb; }
+    }
+    return nb;
+}
+
 // One cell of the walk: traceIntet (query/ConvexQuery.cu:32-131) on a polyhedral cell.
 // Exit through the face slot with the smallest admissible dT in (tol, 1]; the slot we came in
 // through (nbr == token) is skipped.  Returns the next cell (== cur: segment ends here; < 0:

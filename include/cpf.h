@@ -202,6 +202,9 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   1, 2, 5 experiments, measured SLOWER than 3 / 4 on every mesh: per-lane gathers,
  *                     + scalar plane fetches, run-ahead lanes (cpf_ahead.hip).  Only in libraries built with
  *                     `make EXPERIMENTS=1`; the default build answers CPF_ERR_ARG
+ *   "z_fold" (1)    with the Brownian kick on a mesh that is one cell thick in z, mirror the kicked end point about the front /
+ *                   back plane before the walk instead of at the hit (same trajectory, fewer cell visits; 0 = the reference's
+ *                   order of operations, what the staged entry points always use)
  *   "mixed_records" (1; set BEFORE cpf_set_mesh) on a mesh that is not all-hex, build cell records anyway if at most a
  *                   quarter of the cells have more than six faces: cells with fewer than six faces get padded records,
  *                   cells with more a header record and are walked through the CSR tables inside kernel 4.  0 = such

@@ -110,6 +110,15 @@ int cw_build(const double* points, int nPoints, const int* faceOff, const int* f
             v3 Cf = sumA > 0.0 ? V(sumAc.x / (3.0 * sumA), sumAc.y / (3.0 * sumA), sumAc.z / (3.0 * sumA)) : est;
             double len = sqrt(dotp(sumN, sumN));
             v3 n = V(sumN.x / len, sumN.y / len, sumN.z / len);   /* owner -> neighbour (outward for owner) */
+            /* rounding noise in a unit normal (|n_k| <= 1e-12) is zero: axis-aligned faces get exactly axis-aligned normals
+             * (the product's mesh layer states the same rule; what it is for: csrc/cpf_mesh.cpp) */
+            if (fabs(n.x) <= 1e-12 || fabs(n.y) <= 1e-12 || fabs(n.z) <= 1e-12) {
+                if (fabs(n.x) <= 1e-12) n.x = 0.0;
+                if (fabs(n.y) <= 1e-12) n.y = 0.0;
+                if (fabs(n.z) <= 1e-12) n.z = 0.0;
+                double l2 = sqrt(dotp(n, n));
+                n = V(n.x / l2, n.y / l2, n.z / l2);
+            }
             if (pass == 0) n = V(-n.x, -n.y, -n.z);               /* inward for the owner */
             planes[4 * s] = n.x; planes[4 * s + 1] = n.y; planes[4 * s + 2] = n.z;
             planes[4 * s + 3] = dotp(n, Cf);

@@ -17,8 +17,9 @@ DICT = dict(numParticles=20000, dt=1e-4, diffusionCoeff=0.0, saveInterval=10, st
 DELTA_T = 35e-4                                                               # 35 Lagrangian cycles
 
 
-def _expected(pitz, gpu_ctx_factory, D=0.0, cycles=35):
+def _expected(pitz, gpu_ctx_factory, D=0.0, cycles=35, z_fold=1):
     ctx = gpu_ctx_factory()
+    ctx.set_option("z_fold", z_fold)
     ctx.set_mesh(pitz["mesh"]); ctx.set_velocity(pitz["U_analytic"])
     ctx.seed_box(DICT["numParticles"], *DICT["seedingBox"], 1)
     n_out = ctx.locate_initial()
@@ -124,7 +125,10 @@ def test_parallel_fragments_equal_the_serial_run(tmp_path, pitz, n_procs):
 
 def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
     """cudaAdvect -> cudaBrownianMotion -> convexTetQuery -> convexWallReflect -> cudaMoveParticles on the
-    reference's AoS arrays == the fused kernel, bit for bit (D = 0 and D > 0: same counter-based stream)."""
+    reference's AoS arrays == the fused kernel, bit for bit (D = 0 and D > 0: same counter-based stream).  The stages
+    keep the reference's order of operations; with the kick on this one-cell-thick mesh the fused kernel by default
+    mirrors the end point about the front / back plane BEFORE the walk (cpf_walk.h, fold_z): bit-identical with that
+    switched off, and the same trajectory to rounding with it on."""
     from case_dump import dump_case
     for D in (0.0, 1.5e-5):
         d = dict(DICT, diffusionCoeff=D)
@@ -132,9 +136,11 @@ def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
         dump_case(case, pitz["mesh"], pitz["U_analytic"], d, 1.0, DELTA_T)
         wd = tmp_path / ("run%g" % D); wd.mkdir()
         xyzw, cell, out = _run("mockStagedFoam", case, str(wd))
-        ex, ec, _ = _expected(pitz, gpu_ctx_factory, D=D)
+        ex, ec, _ = _expected(pitz, gpu_ctx_factory, D=D, z_fold=0)
         assert np.array_equal(cell, ec)
         assert np.array_equal(xyzw[:, :3], ex[:, :3])
+        fx, fc, _ = _expected(pitz, gpu_ctx_factory, D=D)                      # the default: end point mirrored before the walk
+        assert (fc == ec).mean() > 0.9995 and np.abs(fx[:, :3] - ex[:, :3])[fc == ec].max() < 1e-12
         assert os.path.exists(str(wd / "particle_0035.vtu")) and "System Kinetic Energy" in out
 
 

@@ -117,3 +117,53 @@ def test_tail_of_the_deviates_reaches_beyond_the_23_bit_cap(oracle_libs, gpu_ctx
     r = torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2) / sigma
     assert float(r.max()) < 6.7638 and float(r.max()) >= np.hypot(d[0], d[1]) - 1e-9
     ctx.use_own_stream()
+
+
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_front_and_back_planes_mirrored_before_the_walk_equal_the_reference_order(variant, pitz, oracle_libs, gpu_ctx_factory):
+    """pitzDaily is one cell thick in z: with the kick the kernels mirror the END POINT about the front / back plane before
+    the walk (cpf_walk.h, fold_z) instead of walking to the plane, mirroring there and walking on, as the reference and
+    its CPU statement do (ConvexQuery.cu:286-309).  Same trajectory in exact arithmetic, so particle by particle -- the
+    ones that bounce off a z plane included -- the two agree to the rounding of the deviates (fp32 hardware transcendentals
+    against libm: a few 1e-6 sigma), in position AND cell; with the option off the kernels take the reference's order.
+    100x the tutorial's D: a third of the particles meets a z plane in one cycle, some of them twice."""
+    pz, mesh = pitz["pz"], pitz["mesh"]
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    U = pitz["U_analytic"]
+    n = 200_000
+    xyz = pz.uniform_points(5, 260_000, *pz.DOMAIN_BOX)
+    c0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    xyz = xyz[c0 >= 0][:n]
+    assert xyz.shape[0] == n
+    Db = 100 * D
+    sigma = np.sqrt(2 * Db * DT)
+    res = {}
+    for fold in (1, 0):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("step_variant", variant); ctx.set_option("z_fold", fold); ctx.set_option("stats", 1)
+        ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+        assert ctx.locate_initial() == 0
+        ctx.set_seed(77)
+        before = ctx.counters()
+        ctx.step(DT, Db, 1)
+        xyzw, cell = ctx.get_particles()
+        res[fold] = (xyzw[:, :3].copy(), cell.copy(), ctx.counters()["reflections"] - before["reflections"])
+    x, y, z = (xyz[:, k].copy() for k in range(3))
+    c = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
+    stats = cw.step(x, y, z, c, DT, 1, t, U, nthreads=cw.max_threads, D=Db, gid=np.arange(n, dtype=np.int64), step0=0, seed=77)
+    ref = np.stack([x, y, z], 1)
+    zlo, zhi = mesh.bounds()[0][2], mesh.bounds()[1][2]
+    crossed = np.abs(xyz[:, 2] - (zlo + zhi) / 2) + 3 * sigma > (zhi - zlo) / 2          # could have met a z plane
+    assert stats[1] > 0.2 * n and crossed.sum() > 0.3 * n
+    for fold in (1, 0):
+        pos, cell, refl = res[fold]
+        assert (cell >= 0).all() and pos[:, 2].min() >= zlo and pos[:, 2].max() <= zhi
+        same_cell = cell == c
+        assert same_cell.mean() > 0.9999, (fold, float(same_cell.mean()))              # (a 1e-6 sigma shift can move a particle across a face)
+        err = np.abs(pos - ref)[same_cell].max()
+        assert err < 2e-4 * sigma, (fold, err / sigma)
+        assert abs(refl - int(stats[1])) <= 3e-4 * n, (fold, refl, int(stats[1]))      # as many mirrorings as the reference counts
+    # and the two orders agree with each other more closely still: same deviates, rounding of one hit point apart
+    both = (res[0][1] == res[1][1])
+    assert both.mean() > 0.99999 and np.abs(res[0][0] - res[1][0])[both].max() < 1e-12
