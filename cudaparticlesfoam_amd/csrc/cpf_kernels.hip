@@ -44,7 +44,8 @@ __device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView
         bool folded = false;
         if (BROWNIAN && REFLECT && m.zThin) {                    // one cell thick in z: cpf_walk.h, fold_z
             const int s0 = m.cellOff[cur];
-            const int nb = fold_z(E.z, m.planes[s0 + 4], m.planes[s0 + 5]);
+            bool clear;
+            const int nb = fold_z(E.z, m.planes[s0 + 4], m.planes[s0 + 5], clear);
             st.refl += nb;
             if (nb & 1) v.z = -v.z;
             folded = nb != 0;
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         if (BROWNIAN && REFLECT && m.zThin) {                      // one cell thick in z: cpf_walk.h, fold_z
-                            const int nb = fold_z(E.z, rec[4], rec[5]);
+                            bool clear;
+                            const int nb = fold_z(E.z, rec[4], rec[5], clear);
                             if (STATS) st.refl += nb;
                             if (STORE_VEL && (nb & 1)) v.z = -v.z;
                         }
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(kCoopBlock, (CoopOccupancy<BROWNIAN, STORE_VEL, STA
                         }
                         E = {P.x + disp.x, P.y + disp.y, P.z + disp.z};
                         if (BROWNIAN && REFLECT && m.zThin) {
-                            const int nb = fold_z(E.z, rec[4], rec[5]);
+                            bool clear;
+                            const int nb = fold_z(E.z, rec[4], rec[5], clear);
                             if (STATS) st.refl += nb;
                             if (STORE_VEL && (nb & 1)) v.z = -v.z;
                         }

@@ -233,10 +233,23 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
+    // ---- one cell thick in z: z-layered, the two z faces of every cell are boundary faces, and all cells share the two
+    // planes (to 1e-12 of the thickness: the offsets come out of per-face centroids).  What it is for: cpf_walk.h, fold_z.
     out.zThin = out.zPairLast;
-    for (int64_t c = 0; c < nCells && out.zThin; ++c) {
-        const size_t s0 = (size_t)out.cellOff[(size_t)c];
-        if (out.nbr[s0 + 4] >= 0 || out.nbr[s0 + 5] >= 0) out.zThin = false;
+    {
+        double loMin = 1e300, loMax = -1e300, hiMin = 1e300, hiMax = -1e300;
+        for (int64_t c = 0; c < nCells && out.zThin; ++c) {
+            const size_t s0 = (size_t)out.cellOff[(size_t)c];
+            if (out.nbr[s0 + 4] >= 0 || out.nbr[s0 + 5] >= 0) { out.zThin = false; break; }
+            const double za = out.planes[4 * (s0 + 4) + 3] * out.planes[4 * (s0 + 4) + 2];
+            const double zb = out.planes[4 * (s0 + 5) + 3] * out.planes[4 * (s0 + 5) + 2];
+            const double lo = std::min(za, zb), hi = std::max(za, zb);
+            loMin = std::min(loMin, lo); loMax = std::max(loMax, lo); hiMin = std::min(hiMin, hi); hiMax = std::max(hiMax, hi);
+        }
+        if (out.zThin) {
+            const double thick = hiMin - loMax;
+            if (!(thick > 0.0) || loMax - loMin > 1e-12 * thick || hiMax - hiMin > 1e-12 * thick) out.zThin = false;
+        }
     }
 
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             // crossed or hit in this cycle), it has been reflected iff j != 0, and it is lost in this cycle iff
             // j >= kMaxReflect (still on a wall after 5 bounces; a wall without reflection sets j = kMaxReflect too).
             bool busy = false;
+            bool zUnclear = false;                   // (kick on a one-cell-thick mesh) some lane's mirrored end point is not clear of the z planes
             int token = INT32_MIN, h = 0, j = 0;
             int hitAt = -1;                          // pool: where this lane's hit point is parked (< kPool: pool entry)
             // parks the wall hit point of a lane that is being reflected (it is read back once, by the move at cycle end)
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 busy = cur >= 0;
                 token = INT32_MIN; h = 0; j = 0;
                 if (!HIT_IN_REGS && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
+                zUnclear = false;
                 if (STATS && busy) ++st.steps;
             };
 
@@ -455,7 +457,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     }
                     D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                     if (BROWNIAN && REFLECT && zFold) {                           // one cell thick in z: cpf_walk.h, fold_z
-                        const int nb = fold_z(E.z, rec[4], rec[5]);
+                        bool clear;
+                        const int nb = fold_z(E.z, rec[4], rec[5], clear);
+                        zUnclear |= ballot64(!clear) != 0ull;                      // (wave-uniform; the advecting lanes vote)
                         if (STATS) st.refl += nb;
                         if (STORE_VEL && (nb & 1)) v.z = -v.z;
                     }
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
-                                                                : trace_lds6<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot, zLast);
+                                                                : trace_lds6<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
                             if (STATS) ++st.hops;
                             }
                             if (REFLECT && next < 0) {

@@ -75,7 +75,14 @@ __device__ __forceinline__ int resolve_group(int code, const D3& X, const int32_
 // reference passes through (parity with the kick is statistical by contract, SURVEY.md 8c: the generator differs).  Only
 // with the kick and reflecting walls; D = 0 runs keep the reference's order of operations bit for bit.
 // Returns the number of mirrorings (statistics; an odd number flips the stored velocity's z).
-__device__ __forceinline__ int fold_z(double& ez, const double4& pa, const double4& pb) {
+// `clear`: the mirrored end point lies between the planes with a margin of 1e-9 of the slab's thickness.  Then NO visit of
+// this particle's walk can accept a z face, in the reference's own arithmetic: from inside, fd = z_wall - S.z and den =
+// fl(E.z - S.z) have equal signs only if the segment heads for that plane, and then |den| <= (|S.z - z_wall| - margin)(1 +
+// 2^-53) < |fd|, so fl(fd / den) > 1 and the face is rejected (cpf_walk.h, trace_fixed: the <= 1 test is exact); the
+// planes of all cells of such a mesh agree to 1e-12 of the thickness (cpf_mesh.cpp), far inside the margin, and a
+// reflection off a side wall (nz == 0 exactly) leaves E.z alone.  A wave whose lanes are all clear may therefore leave both
+// z faces out of its rounds -- bit-identical to testing them.
+__device__ __forceinline__ int fold_z(double& ez, const double4& pa, const double4& pb, bool& clear) {
     const double za = pa.w * pa.z, zb = pb.w * pb.z;          // plane (0, 0, nz, d), nz = +-1: z = d / nz = d * nz, exactly
     const double lo = fmin(za, zb), hi = fmax(za, zb);
     int nb = 0;
@@ -84,6 +91,8 @@ __device__ __forceinline__ int fold_z(double& ez, const double4& pa, const doubl
         if (ez < lo) { ez = fma(-2.0, ez - lo, ez); ++nb; }
         else if (ez > hi) { ez = fma(-2.0, ez - hi, ez); ++nb; }
     }
+    const double margin = 1e-9 * (hi - lo);
+    clear = ez > lo + margin && ez < hi - margin;
     return nb;
 }
 
@@ -153,8 +162,9 @@ __device__ __forceinline__ int trace_fixed(D3& S, const D3& E, int cur, const do
     for (int s = 0; s < NF; ++s) {
         double4 p;
         if (AHEAD > 0) {
-            p = ahead[s % AHEAD];
-            if (s + AHEAD < NF) ahead[s % AHEAD] = pl[s + AHEAD];
+            constexpr int A = AHEAD > 0 ? AHEAD : 1;
+            p = ahead[s % A];
+            if (s + AHEAD < NF) ahead[s % A] = pl[s + AHEAD];
         } else p = pl[s];
         const double den = dot3(p, Pd);
         // no lane of the wave moves across this face's plane (den == +-0 exactly, e.g. the front/back
@@ -228,8 +238,11 @@ __device__ __forceinline__ void face_test(const double4& p, int bs, const D3& P0
 // are exactly +-0 for every lane -- nx == ny == 0 leaves den = nz * 0 -- so neither face can be accepted
 // (ConvexQuery.cu:86-95) and ONE test replaces two plane fetches, two denominators and two votes.  Exact, not
 // approximate: it is the zero-denominator skip of face_test, decided for the pair up front.
+// zNever (wave-uniform): no active lane can leave through a z face at all (the Brownian kick on a one-cell-thick mesh with
+// every end point mirrored clear of the planes: fold_z) -- the pair is left out whatever Pd.z is.
 template <bool ZERO_SKIP = true, bool GROUPS = false>
-__device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot, bool zLast = false) {
+__device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot, bool zLast = false,
+                                          bool zNever = false) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
     int next = cur, best = -1;
@@ -249,7 +262,7 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
         face_test<ZERO_SKIP, GROUPS>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
         face_test<ZERO_SKIP, GROUPS>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
     }
-    if (!(zLast && ballot64(Pd.z != 0.0) == 0ull)) {
+    if (!(zNever || (zLast && ballot64(Pd.z != 0.0) == 0ull))) {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
         CPF_PIN_W(p4, p5)
