@@ -60,7 +60,7 @@ struct StreamState {
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
-int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 2 / 3 fixed compare + mixed records with / without header records
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 8;       // fused launches of this many cycles or more run the wave-cooperative kernel (round 3: the

@@ -84,7 +84,7 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
-    static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3;
+    static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (kMixed ? 6 : CPF_STREAM_WAVES)));
 };
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
     // (with the kick the landing zone and the hit pool are larger: 7 slots keep the sixth wave, 6600 of 6826 bytes)
-    constexpr int NS = LOOKUP == 0 ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? 7 : kStreamSlotsFixed);
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? 7 : kStreamSlotsFixed);
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
     // the wave's record cache.  (256 bytes per slot is one full turn of the 64 LDS banks, so lanes reading the same plane
     // of different slots conflict: 50 conflict cycles per tile on pitzDaily, 351 on the 3-D bench mesh.  Padding the
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3) ? 16 : CPF_STREAM_HIT_POOL);
+    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5) ? 16 : CPF_STREAM_HIT_POOL);
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -136,8 +136,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   planes in flight instead of one -- two dependent round trips per visit instead of six -- for 24 more registers, i.e.
     //   five waves per SIMD.  2.1e6-cell box: 1.25e6 particles (one rank's share of BASELINE configs[4]) 0.187 -> 0.141 ms,
     //   1e7 particles 0.673 / 0.631 -> 0.641 / 0.607; in the dense regime the same change costs 6 % (0.259 -> 0.277)
-    constexpr bool LOOKUP_FIXED = LOOKUP != 0;
-    constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3;
+    //   5 = as 3 (mixed records without header records) with the LOOP lookup and six slots: a refined mesh that still holds
+    //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see DESIGN.md 5.6)
+    constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5;
+    constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
     const bool zFold = BROWNIAN && REFLECT && m.zThin != 0;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         nJobs = J + 1;                                                                      \
                     }
                     CPF_JOB(0) CPF_JOB(1) CPF_JOB(2) CPF_JOB(3)
-                    if (LOOKUP != 0) { CPF_JOB(4) CPF_JOB(5) CPF_JOB(6) CPF_JOB(7) }
+                    if (LOOKUP_FIXED) { CPF_JOB(4) CPF_JOB(5) CPF_JOB(6) CPF_JOB(7) }
 #undef CPF_JOB
                 }
                 int younger = 0;
@@ -685,8 +687,8 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     // finer chunks and a longer tile-by-tile tail (tools/sweep3d_opts.sh: 3 / 0.2 against 4 / 0.1 on the 3-D box 0.2632 /
     // 0.2701 -> 0.2585 / 0.2661 ms, TJunction 0.1581 / 0.1708 -> 0.1569 / 0.1687, 5 particles per cell 0.682 / 0.670 -> 0.677 /
     // 0.636; pitzDaily is at its optimum with 4 / 0.1, tools/tail_sweep.sh)
-    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : (LF == 0 ? 4 : 3);
-    const double tailFraction = ss.tailFraction >= 0.0 ? ss.tailFraction : (LF == 0 ? 0.1 : 0.2);
+    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : ((LF == 0 || LF == 5) ? 4 : 3);
+    const double tailFraction = ss.tailFraction >= 0.0 ? ss.tailFraction : ((LF == 0 || LF == 5) ? 0.1 : 0.2);
     while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc = tpc > 2 ? tpc - 1 : 1;
     // the first (1 - tailFraction) of the cloud in chunks of tpc tiles, the rest tile by tile
     int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - tailFraction));
@@ -713,7 +715,9 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
 int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
-    if (m.mixed) return m.mixed == 2 ? 2 : 3;  // not all-hex: with / without header records (cells with more than six slots)
+    // not all-hex: with / without header records (cells with more than six slots); without them and with many particles per
+    // cell, the loop lookup
+    if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * (int64_t)m.nCells) ? 5 : 3);
     if (ss.lookup >= 0) return ss.lookup;      // "stream_lookup": 0, 1 or 4
     if (n < kStreamSparsePerCell * (int64_t)m.nCells) return 4;
     return n < 128 * (int64_t)m.nCells ? 1 : 0;
@@ -726,6 +730,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
     const int lf = stream_lookup_mode(n, m, ss);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
+        if (lf == 5) return launch_stream_inst<B, R, SV, ST, 5>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 4) return launch_stream_inst<B, R, SV, ST, 4>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 3) return launch_stream_inst<B, R, SV, ST, 3>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 2) return launch_stream_inst<B, R, SV, ST, 2>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

@@ -53,7 +53,8 @@ def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, w
         name = ctx.step_kernel_name(0.0, 0)
         xyzw, cell = ctx.get_particles()
         after = ctx.counters()
-        assert want_kernel(opts) in name, (opts, name)
+        want = want_kernel(opts)
+        assert any(w in name for w in ((want,) if isinstance(want, str) else want)), (opts, name)
         assert np.array_equal(cell, c), (opts, int((cell != c).sum()))
         assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z), opts
         assert after["cells_visited"] - before["cells_visited"] == int(stats[0]), opts
@@ -64,7 +65,9 @@ def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, w
 def _kernel_for(opts):
     if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
         return "cpf::step_kernel<0,"
-    return ", 3>"                                   # step_kernel_stream<..., 3>: fixed compare + mixed records, no cell with > 6 slots
+    # step_kernel_stream<..., 3>: fixed compare + mixed records, no cell with > 6 slots; 5: the same with the loop lookup
+    # (picked above 128 particles per cell, or by the option)
+    return {0: ", 5>", 1: ", 3>"}.get(opts.get("stream_lookup"), (", 3>", ", 5>"))
 
 
 def _kernel_for_big(opts):
@@ -88,7 +91,7 @@ def test_refined_box_cells_with_9_to_21_faces(seed, oracle_libs, gpu_ctx_factory
     U = rng.normal(size=(mesh.n_cells, 3)) * 2.0 + np.array([1.0, 0.3, -0.2])
     xyz = rng.uniform([0, 0, 0], [8, 6, 5], size=(40000, 3))
     c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.15, 30,
-                  [dict(), dict(mixed_records=0), dict(step_variant=0), dict(stream_lookup=0)], _kernel_for)
+                  [dict(), dict(mixed_records=0), dict(step_variant=0), dict(stream_lookup=0), dict(stream_lookup=1)], _kernel_for)
     assert (c >= 0).all() and (nf[c] > 6).sum() > 500          # every boundary reflects; many END in a many-faced cell
 
 
@@ -121,7 +124,7 @@ def test_refined_pitzdaily_1e6(oracle_libs, gpu_ctx_factory, pitz):
     c0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
     xyz = xyz[c0 >= 0][:1_000_000]
     assert xyz.shape[0] == 1_000_000
-    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1e-4, 20, [dict(), dict(step_variant=0)], _kernel_for)
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1e-4, 20, [dict(), dict(stream_lookup=0), dict(step_variant=0)], _kernel_for)
 
 
 @pytest.mark.parametrize("every", [4, 5])
@@ -222,7 +225,7 @@ def test_diffusion_on_a_mixed_mesh_loses_nobody(which, oracle_libs, gpu_ctx_fact
     if which == "refined_box":
         from cudaparticlesfoam_amd.cases import refined_box
         mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
-        hi, want = [8, 6, 5], ", 3>"
+        hi, want = [8, 6, 5], ", 5>"                                  # 360 particles per cell: the loop lookup
     else:
         from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
         mesh, _ = cut_corner_box(11, 8, 3, every=4)

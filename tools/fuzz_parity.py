@@ -70,7 +70,7 @@ def main():
                 ctx.set_option("stats", stats)
                 if os.environ.get("CPF_FUZZ_VARIANT"):
                     ctx.set_option("step_variant", int(os.environ["CPF_FUZZ_VARIANT"]))
-                ctx.set_option("stream_lookup", (0, 1, 4)[(seed // 2 + stats) % 3])      # all record-lookup methods of the streaming kernel
+                ctx.set_option("stream_lookup", (0, 1) [(seed // 2 + stats) % 2] if mixed else (0, 1, 4)[(seed // 2 + stats) % 3])      # all record-lookup methods of the streaming kernel
                 ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
                 ctx.locate_initial()
                 _, cell0 = ctx.get_particles()
