@@ -212,7 +212,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "stream_tiles_per_chunk" (4; 3 on meshes with few particles per cell), "stream_tail_fraction" (0.1; 0.2), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare, 4 the same for sparse clouds -- fewer than 8 particles
- *                   per cell --: pipelined per-lane record gathers): how a wave finds its cells in its record cache;
+ *                   per cell --: pipelined per-lane record gathers; on meshes that are not all-hex only 0 / 1 apply): how a wave finds its cells
+ *                   in its record cache;
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
