@@ -167,3 +167,29 @@ def test_front_and_back_planes_mirrored_before_the_walk_equal_the_reference_orde
     # and the two orders agree with each other more closely still: same deviates, rounding of one hit point apart
     both = (res[0][1] == res[1][1])
     assert both.mean() > 0.99999 and np.abs(res[0][0] - res[1][0])[both].max() < 1e-12
+
+
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_stored_velocity_is_mirrored_with_the_end_point(variant, pitz, gpu_ctx_factory):
+    """The velocity an output step stores is mirrored at every wall (ConvexQuery.cu:286-309).  With the end point mirrored
+    about the front / back plane before the walk the stored velocity's z flips once per mirroring: same stored velocities
+    as with the reference's order, where the particle kept its cell."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, mesh = pitz["pz"], pitz["mesh"]
+    rng = np.random.default_rng(9)
+    U = pitz["U_analytic"].copy(); U[:, 2] = rng.normal(size=U.shape[0]) * 0.5            # a z component to mirror
+    xyz = pz.uniform_points(11, 120_000, *pz.DOMAIN_BOX)
+    res = {}
+    for fold in (1, 0):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("step_variant", variant); ctx.set_option("z_fold", fold)
+        ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+        ctx.locate_initial(); ctx.set_seed(5)
+        ctx.step(DT, 100 * D, 1, L.STEP_STORE_VEL)
+        xyzw, cell, vel = ctx.get_particles(want_vel=True)
+        res[fold] = (xyzw[:, :3].copy(), cell.copy(), vel.copy())
+    inside = (res[0][1] >= 0) & (res[1][1] == res[0][1])
+    assert inside.mean() > 0.9
+    flipped = np.sign(res[1][2][inside, 2]) != np.sign(U[np.maximum(res[1][1][inside], 0), 2])
+    assert flipped.mean() > 0.05                                       # many stored velocities did get mirrored
+    assert np.array_equal(res[1][2][inside], res[0][2][inside])        # and identically in both orders
