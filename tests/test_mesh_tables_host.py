@@ -56,3 +56,21 @@ def test_a_mesh_the_product_refuses_is_refused_here_too():
     m.owner = m.owner.copy(); m.owner[0] = 99                                     # out of range
     with pytest.raises(L.CpfError):
         build_mesh_tables_host(m)
+
+
+def test_rounding_noise_in_face_normals_is_zero_and_pitzdaily_is_z_layered(pitz):
+    """A component of a unit face normal of magnitude <= 1e-12 is stored as zero (csrc/cpf_mesh.cpp, restated in
+    oracle/cellwalk.c): 35 % of pitzDaily's faces carry such noise out of the cross products, and with it in place neither
+    the z-pair skip nor the zero-denominator skips of the walk can fire.  After it every cell of the mesh has its two
+    faces with an exactly z-parallel unit normal in slots 4 and 5."""
+    from cudaparticlesfoam_amd.api import build_mesh_tables_host
+    h = build_mesh_tables_host(pitz["mesh"])
+    pl = h["planes"].reshape(-1, 6, 4)
+    n = pl[:, :, :3]
+    assert not ((np.abs(n) <= 1e-12) & (n != 0)).any()
+    assert np.allclose((n ** 2).sum(2), 1.0, rtol=0, atol=4e-16)
+    isz = (n[:, :, 0] == 0) & (n[:, :, 1] == 0)
+    assert isz[:, 4:].all() and not isz[:, :4].any() and (np.abs(n[:, 4:, 2]) == 1.0).all()
+    assert (h["nbr"].reshape(-1, 6)[:, 4:] < 0).all()                            # front / back: boundary faces, one cell thick
+    zw = pl[:, 4:, 3] * pl[:, 4:, 2]                                             # the planes' z positions agree to rounding
+    assert np.ptp(zw.min(1)) < 1e-15 and np.ptp(zw.max(1)) < 1e-15
