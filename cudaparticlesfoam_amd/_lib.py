@@ -60,6 +60,7 @@ SIGNATURES = {
     "cpf_mesh_info": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "cpf_get_mesh_tables": (_int, [_ctx, _vp, _vp, _vp]),
     "cpf_get_mesh_groups": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
+    "cpf_get_mesh_flags": (_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cpf_build_mesh_tables_host": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64),
                                           C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     "cpf_set_velocity": (_int, [_ctx, _vp, _i64]),

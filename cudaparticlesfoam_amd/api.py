@@ -106,6 +106,12 @@ class Context:
         self._ck(self.lib.cpf_get_mesh_tables(self.h, _ptr(off), _ptr(planes), _ptr(nbr)))
         return off, planes, nbr
 
+    def mesh_flags(self) -> Dict[str, int]:
+        """Which shortcuts of the walk the mesh layer found live: all_hex, z_layered, z_thin, mixed (include/cpf.h)."""
+        v = [C.c_int32(0) for _ in range(4)]
+        self._ck(self.lib.cpf_get_mesh_flags(self.h, *[C.byref(x) for x in v]))
+        return dict(all_hex=v[0].value, z_layered=v[1].value, z_thin=v[2].value, mixed=v[3].value)
+
     def mesh_groups(self):
         """Face groups of the mesh (coplanar faces of a cell that lead to different cells share one slot): (group_off
         [n_groups + 1], group_nbr); slot neighbour id INT32_MIN + 16 + g marks group g."""

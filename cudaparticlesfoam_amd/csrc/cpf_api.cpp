@@ -379,6 +379,17 @@ int cpf_get_mesh_groups(const cpf_context* ctx, int64_t* nGroups, int64_t* nMemb
     return CPF_OK;
 }
 
+int cpf_get_mesh_flags(const cpf_context* ctx, int32_t* allHex, int32_t* zLayered, int32_t* zThin, int32_t* mixed) {
+    CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
+    CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_get_mesh_flags: no mesh set");
+    const cpf::MeshView m = meshView(ctx);
+    if (allHex) *allHex = m.allHex;
+    if (zLayered) *zLayered = m.zPairLast;
+    if (zThin) *zThin = m.zThin;
+    if (mixed) *mixed = m.mixed;
+    return CPF_OK;
+}
+
 int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_velocity: call cpf_set_mesh first");

@@ -130,6 +130,12 @@ int cpf_get_mesh_tables(const cpf_context* ctx, int32_t* cellOff, double* planes
  * groupNbr[groupOff[g] .. groupOff[g+1]).  Any pointer may be NULL; groupOff[nGroups+1], groupNbr[nMembers]. */
 int cpf_get_mesh_groups(const cpf_context* ctx, int64_t* nGroups, int64_t* nMembers, int32_t* groupOff, int32_t* groupNbr);
 
+/* What the mesh layer recognised, i.e. which shortcuts of the walk are live (any pointer may be NULL): allHex = six slots per
+ * cell and no face groups; zLayered = ... and the two faces of every cell with an exactly z-parallel normal sit in slots 4, 5
+ * (one test drops both when nothing moves in z); zThin = ... and they are boundary faces on two common planes (one cell thick:
+ * with the Brownian kick the end point is mirrored before the walk, option "z_fold"); mixed = 1 / 2: cell records for a mesh
+ * that is not all-hex, without / with header records. */
+int cpf_get_mesh_flags(const cpf_context* ctx, int32_t* allHex, int32_t* zLayered, int32_t* zThin, int32_t* mixed);
 /* The tables cpf_set_mesh would build and upload, on the host alone: no context, no GPU (a check of the mesh layer on a
  * machine without a device; what an exotic mesh is ingested as).  Call with the array pointers NULL for the sizes, then
  * again with cellOff[nCells+1], planes[nSlots][4], nbr[nSlots], groupOff[nGroups+1], groupNbr[nMembers].  CPF_ERR_MESH

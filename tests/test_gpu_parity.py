@@ -51,6 +51,24 @@ def test_mesh_tables_match_oracle_build(setup):
     assert info["n_cells"] == 12225 and info["n_slots"] == 49180 + 24170
 
 
+def test_mesh_layer_recognises_what_the_walk_shortcuts_need(setup, gpu_ctx_factory):
+    """pitzDaily must come out all-hex, z-layered and one cell thick -- the z-pair skip and the mirrored end point of the
+    Brownian kick depend on it, silently (for most of round 3 rounding noise in the face normals kept both switched off);
+    a 3-D box is all-hex and neither; a refined pitzDaily is z-layered with mixed records."""
+    from cudaparticlesfoam_amd.cases import box_mesh, refined_pitzdaily
+    assert setup["ctx"].mesh_flags() == dict(all_hex=1, z_layered=1, z_thin=1, mixed=0)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(box_mesh(5, 4, 3))
+    assert ctx.mesh_flags() == dict(all_hex=1, z_layered=1, z_thin=0, mixed=0)       # three layers: z faces exact, not all on the boundary
+    ctx.set_mesh(box_mesh(5, 4, 1))
+    assert ctx.mesh_flags() == dict(all_hex=1, z_layered=1, z_thin=1, mixed=0)
+    ctx.set_option("z_fold", 0)
+    assert ctx.mesh_flags()["z_thin"] == 0
+    ctx.set_option("z_fold", 1)
+    ctx.set_mesh(refined_pitzdaily()[0])
+    assert ctx.mesh_flags() == dict(all_hex=0, z_layered=1, z_thin=1, mixed=1)
+
+
 def test_initial_locate_matches_bruteforce(setup):
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     n = 20000
