@@ -69,6 +69,16 @@ def test_mesh_layer_recognises_what_the_walk_shortcuts_need(setup, gpu_ctx_facto
     assert ctx.mesh_flags() == dict(all_hex=0, z_layered=1, z_thin=1, mixed=1)
 
 
+def test_lookup_method_follows_the_particles_per_cell(setup):
+    """Which instantiation of the streaming kernel a step launches (cpf_step_kernel_name): sparse clouds (< 8 particles per
+    cell) the pipelined-gather one, up to 128 per cell the fixed tag compare, above that the loop over distinct cells."""
+    ctx, pz = setup["ctx"], setup["pz"]
+    ctx.set_option("step_variant", -1); ctx.set_option("stream_lookup", -1)
+    for n, want in ((20_000, ", 4>"), (300_000, ", 1>"), (1_700_000, ", 0>")):                 # 12 225 cells: 1.6, 24.5, 139 per cell
+        ctx.set_particles(_seed_points(pz, n, pz.DOMAIN_BOX, seed=3))
+        assert ctx.step_kernel_name(0.0, 0).endswith(want), (n, ctx.step_kernel_name(0.0, 0))
+
+
 def test_initial_locate_matches_bruteforce(setup):
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     n = 20000
