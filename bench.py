@@ -497,6 +497,8 @@ def run(args, M):
                                        "config and reports this cloud on one GPU as config.strong_anchor_1e8)"
                                        % (n_total, world, M.collectives, args.scaling))),
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
+                       # which shortcuts of the walk the mesh layer found live on this mesh (include/cpf.h, cpf_get_mesh_flags)
+                       "mesh_flags": ctx.mesh_flags() if hasattr(ctx, "mesh_flags") else None,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
                        "rebalance_interval": args.rebalance_interval if world > 1 else None,
                        "overlap_steps": args.overlap_steps if dist_on else None,
