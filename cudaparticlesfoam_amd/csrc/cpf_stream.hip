@@ -1,4 +1,5 @@
-// Streaming step kernel (gfx950 / CDNA4, wave64) for all-hex meshes.
+// Streaming step kernel (gfx950 / CDNA4, wave64): all-hex meshes, and meshes with a minority of other cells (mixed cell
+// records: padded, face groups, header records -- the LOOKUP 2 / 3 / 5 instantiations; DESIGN.md 5.2 has the table).
 //
 // Same fused cycle and the same per-particle arithmetic as step_kernel_coop (cpf_kernels.hip) -- advect -> Brownian
 // kick -> plane-exit walk -> wall reflect -> move, src/advect.H:96-161 -- organised around what the measurements of
