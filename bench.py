@@ -70,6 +70,16 @@ def parse(argv=None):
     ap.add_argument("--self-launch", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by "
                          "itself when no launcher set WORLD_SIZE)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launched ranks (--gpus N without a launcher): wall-clock limit of the child process tree; on expiry "
+                         "it is killed and ONE JSON line {\"error\": ..., \"stage\": ...} is printed, exit code 124")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="N>1: torch.distributed process-group timeout in seconds -- a collective that does not complete raises "
+                         "in every rank instead of hanging the job")
+    ap.add_argument("--ipc-legacy", choices=["0", "1", "unset", "inherit"], default="inherit",
+                    help="HSA_ENABLE_IPC_MODE_LEGACY for the ranks: inherit = keep the environment's value and export 0 if it has "
+                         "none (this pool's driver only supports dmabuf IPC); unset = remove it; 0 / 1 = force")
+    ap.add_argument("--child-script", default=None, help=argparse.SUPPRESS)      # tests: the rank program self_launch starts
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--sort-interval", type=int, default=100, help="re-sort the cloud by cell every that many steps")
@@ -79,6 +89,18 @@ def parse(argv=None):
     ap.add_argument("--brownian-extra", type=int, default=20,
                     help="after the timed region (N = 1): that many launches with the tutorial's D = 1.5e-5, reported "
                          "as config.brownian; 0 = skip")
+    ap.add_argument("--brownian-steady-steps", type=int, default=100,
+                    help="after the timed region (N = 1): a freshly seeded cloud of the same size stepped that many times with "
+                         "the tutorial's D = 1.5e-5 and the fragments' own sort interval for diffusing clouds (25), sorts "
+                         "included, reported as config.brownian_steady; 0 = skip")
+    ap.add_argument("--analytic-extra", type=int, default=20,
+                    help="after the timed region (N = 1): that many steps of the frozen analytic step-flow field (SURVEY.md 8d "
+                         "config 3(ii)) on a freshly seeded, sorted cloud, reported as config.analytic_field; 0 = skip")
+    ap.add_argument("--tjunction-steps", type=int, default=100,
+                    help="after the timed region (N = 1): the reference's second tutorial as its dictionary runs it -- 4e6 "
+                         "particles from the seeding box, D = 1.5e-5, on the 248 000-cell TJunction mesh -- that many steps, "
+                         "reported as config.tjunction_as_run; 0 = skip")
+    ap.add_argument("--tjunction-particles", type=float, default=4e6)
     ap.add_argument("--anchor-particles", type=float, default=1e8,
                     help="after the timed region (N = 1): the strong-scaling experiment's total cloud (what --gpus N > 1 "
                          "shards) stepped on this ONE GPU, reported as config.strong_anchor_1e8 -- the N = 1 point of "
@@ -158,32 +180,140 @@ def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None, chunk=20_00
     return cat(xs), cat(ys), cat(zs), cat(cs)
 
 
+_STAGE = "launch"
+STAGES = ("launch", "rccl_init", "first_exchange", "warmup", "timed_region", "extras", "done")
+
+
+def stage(name):
+    """Rank 0 leaves a trail of where the run is (the parent's watchdog reports the last entry when it has to kill the
+    ranks): one line on stderr and, if BENCH_STAGE_FILE is set (self_launch sets it), the name in that file."""
+    global _STAGE
+    _STAGE = name
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    print("[bench stage] %s" % name, file=sys.stderr, flush=True)
+    path = os.environ.get("BENCH_STAGE_FILE")
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(name)
+        except OSError:
+            pass
+
+
+def rank_watchdog(args, rank, world):
+    """Ranks started by somebody else's launcher (the driver's torch.distributed.run) have no parent of ours watching them:
+    every rank of an N > 1 run arms a timer of its own.  On expiry rank 0 prints the error line (the run's one JSON line
+    then) and every rank leaves with os._exit(124) -- from a thread, so a main thread stuck inside a collective does not
+    matter."""
+    import threading
+    if world <= 1 or args.launch_timeout <= 0:
+        return None
+
+    def expire():
+        if rank == 0:
+            print(json.dumps({"error": "rank watchdog: no result after %.0f s" % args.launch_timeout, "stage": _STAGE,
+                              "n_gpus": world}), flush=True)
+        print("[bench rank %d] watchdog expired in stage %s" % (rank, _STAGE), file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(args.launch_timeout, expire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def rank_env(args, base=None):
+    """Environment of the rank processes (see --ipc-legacy)."""
+    env = dict(os.environ if base is None else base)
+    if args.ipc_legacy == "inherit":
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    elif args.ipc_legacy == "unset":
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    else:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = args.ipc_legacy
+    return env
+
+
 def self_launch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks here as a CHILD process -- this process has
+    """`python bench.py --gpus N` without a launcher: start the N ranks here as a CHILD process tree -- this process has
     not touched the GPU and never does -- the way the driver starts them for N > 1, forward rank 0's one JSON line as
     this process's only stdout line (anything else the ranks wrote to stdout goes to stderr) and return the child's
-    exit code.  (The reference has no counterpart: one GPU, driven by the MPI master only, src/advect.H:59-89.)"""
+    exit code.  The child runs under a wall-clock limit (--launch-timeout): when it expires the whole process group is
+    killed and the one stdout line is {"error": ..., "stage": ..., "n_gpus": N} with exit code 124 -- a hang becomes a
+    diagnosis.  Never a re-exec: a fresh child or a non-zero exit.
+    (The reference has no counterpart: one GPU, driven by the MPI master only, src/advect.H:59-89.)"""
+    import signal
     import socket
     import subprocess
+    import tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif a == "--child-script":
+            skip = True
+        elif a != "--self-launch" and not a.startswith("--child-script="):
+            argv.append(a)
+    script = os.path.abspath(args.child_script or __file__)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC (RCCL across processes)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + argv
+    fd, stage_file = tempfile.mkstemp(prefix="bench_stage_"); os.close(fd)
+    env = rank_env(args)
+    env["BENCH_STAGE_FILE"] = stage_file
+    with open(stage_file, "w") as f:
+        f.write("launch")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    timed_out = False
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout if args.launch_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig in (signal.SIGTERM, signal.SIGKILL):          # the launcher, its ranks and whatever they started: one group
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out, _ = proc.communicate(timeout=10)
+        except Exception:
+            out = ""
+    try:
+        last = open(stage_file).read().strip() or "launch"
+    except OSError:
+        last = "launch"
+    finally:
+        try:
+            os.unlink(stage_file)
+        except OSError:
+            pass
     json_lines = []
-    for ln in r.stdout.splitlines():
+    for ln in (out or "").splitlines():
         if ln.startswith("{"):
             json_lines.append(ln)
         else:
             print(ln, file=sys.stderr)
-    if r.returncode == 0 and len(json_lines) != 1:
+    if timed_out:
+        print(json.dumps({"error": "ranks killed after --launch-timeout %.0f s" % args.launch_timeout, "stage": last,
+                          "n_gpus": args.gpus}), flush=True)
+        return 124
+    if proc.returncode != 0:
+        # (rank 0's own error line, if it got one out, says more than this process can)
+        print(json_lines[-1] if json_lines else
+              json.dumps({"error": "ranks exited with code %d" % proc.returncode, "stage": last, "n_gpus": args.gpus}), flush=True)
+        return proc.returncode
+    if len(json_lines) != 1:
         print("bench.py: expected ONE JSON line from rank 0, got %d" % len(json_lines), file=sys.stderr)
+        print(json.dumps({"error": "expected one JSON line from rank 0, got %d" % len(json_lines), "stage": last,
+                          "n_gpus": args.gpus}), flush=True)
         return 3
-    if json_lines:
-        print(json_lines[-1], flush=True)
-    return r.returncode
+    print(json_lines[-1], flush=True)
+    return 0
 
 
 class GpuMachine:
@@ -209,15 +339,27 @@ class GpuMachine:
             if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
                 os.environ["NCCL_DEBUG"] = "WARN"
             os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+            import datetime
+            # a stuck collective must raise (and take the rank down), not hang: process-group timeout + the watchdog's abort
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            tmo = datetime.timedelta(seconds=max(1.0, args.collective_timeout))
+            # who is where, before the first collective (stderr; one line per rank)
+            print("[bench rank %d/%d] device cuda:%d of %d visible, pid %d, HSA_ENABLE_IPC_MODE_LEGACY=%s"
+                  % (rank, world, local, torch.cuda.device_count(), os.getpid(), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")),
+                  file=sys.stderr, flush=True)
+            stage("rccl_init")
             if "WORLD_SIZE" not in os.environ:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.device)
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.device, timeout=tmo)
             else:
-                dist.init_process_group("nccl", device_id=self.device)
+                dist.init_process_group("nccl", device_id=self.device, timeout=tmo)
+            if rank == 0:
+                print("[bench] rccl_ranks %d" % dist.get_world_size(), file=sys.stderr, flush=True)
         self.ctx = Context(local)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def set_case(self, mesh, U):
+        self._case = (mesh, U)
         self.ctx.set_mesh(mesh)
         self.ctx.set_velocity(U)
 
@@ -353,7 +495,121 @@ class GpuMachine:
                       "Mparticle_steps_per_s": round(na * args.anchor_steps / ta / 1e6, 1),
                       "note": "one GPU, no sharding, no hand-off: divide the --gpus N value by this for the strong-scaling ratio"}
             del ax, ay, az, ac, ag
-        return brown, fused, steady, anchor
+        more = {}
+        more["brownian_steady"] = self._brownian_steady(cloud, dt, args, box)
+        more["analytic_field"] = self._analytic_field(cloud, dt, args, box)
+        more["tjunction_as_run"] = self._tjunction_as_run(dt, args)
+        return brown, fused, steady, anchor, more
+
+    # ---- what the tutorials actually run (never `value`)
+    def _fresh_cloud(self, n, box, seed, ctx=None, sort_interval=0):
+        """A new single-rank cloud of n particles seeded over the fluid domain, located and sorted, on `ctx`."""
+        from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+        torch = self.torch
+        ctx = ctx or self.ctx
+        x, y, z, c = seed_in_fluid(ctx, torch, n, box, seed, self.device)
+        cl = ShardedCloud(HipOps(ctx), [0, ctx.mesh_info()["n_cells"]], n + 4096, self.device, send_fraction=0.0)
+        cl.set_particles(x, y, z, c, torch.arange(n, dtype=torch.int64, device=self.device))
+        del x, y, z, c
+        cl.sort_interval = sort_interval
+        cl.sort()
+        torch.cuda.synchronize()
+        return cl
+
+    @staticmethod
+    def _timed_steps(torch, ctx, cl, dt, steps, D, bytes_per):
+        ctx.set_option("timing_stride", 4)
+        ctx.timing_enable(True); ctx.timing_read()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cl.step(dt, steps, D=D)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        launches, ms = ctx.timing_read()
+        ctx.timing_enable(False)
+        k = ms / max(launches, 1)
+        per = el / steps * 1e3
+        return {"steps": steps, "ms_per_step": round(per, 4), "kernel_avg_ms": round(k, 4),
+                "Mparticle_steps_per_s": round(cl.n / per / 1e3, 1),
+                "algorithmic_bytes_per_particle_step": bytes_per,
+                "frac": round(bytes_per * cl.n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel_frac": round(bytes_per * cl.n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k > 0 else None}
+
+    def _brownian_steady(self, cloud, dt, args, box):
+        """Sustained rate with the tutorial's diffusion: a fresh cloud, the fragments' sort interval for diffusing clouds
+        (compat/src/initCuda.H: 25), the sorts inside the clock (pitzDaily/system/cudaParticlesDict:17-29)."""
+        if args.brownian_steady_steps <= 0:
+            return None
+        torch, ctx = self.torch, self.ctx
+        Db, interval = 1.5e-5, 25
+        cl = self._fresh_cloud(cloud.n, box, 2025, sort_interval=interval)
+        cl.step(dt, 10, D=Db)
+        cl.step_index = 0                                       # (the sort cadence restarts with the clock)
+        r = self._timed_steps(torch, ctx, cl, dt, args.brownian_steady_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
+        r.update({"D": Db, "sort_interval": interval, "sorts_inside": args.brownian_steady_steps // interval,
+                  "kernel": ctx.step_kernel_name(Db, 0), "particles": cl.n,
+                  "note": "frac = 64 B x particles / ms_per_step (sorts included); kernel_frac = the step kernel alone"})
+        del cl
+        return r
+
+    def _analytic_field(self, cloud, dt, args, box):
+        """the frozen (analytic step-flow) field instead of the uniform one."""
+        if args.analytic_extra <= 0:
+            return None
+        from cudaparticlesfoam_amd.cases import pitzdaily as pz
+        torch, ctx = self.torch, self.ctx
+        mesh, U0 = self._case
+        centres, _ = mesh.cell_centres_volumes()
+        ctx.set_velocity(pz.analytic_step_u(mesh, centres))
+        cl = self._fresh_cloud(cloud.n, box, 2026)
+        ctx.set_option("stats", 1); c0 = ctx.counters()
+        cl.step(dt, 5)
+        torch.cuda.synchronize(); c1 = ctx.counters(); ctx.set_option("stats", 0)
+        r = self._timed_steps(torch, ctx, cl, dt, args.analytic_extra, 0.0, ALGO_BYTES_PER_PARTICLE_STEP)
+        r.update({"field": "analytic step-flow (cases/pitzdaily.py: analytic_step_u)", "kernel": ctx.step_kernel_name(0.0, 0),
+                  "particles": cl.n, "first_step": 5,
+                  "cells_visited_per_particle_step": round((c1["cells_visited"] - c0["cells_visited"]) /
+                                                           max(1, c1["particle_steps"] - c0["particle_steps"]), 3)})
+        del cl
+        ctx.set_velocity(U0)
+        return r
+
+    def _tjunction_as_run(self, dt, args):
+        """The reference's second tutorial as its dictionary runs it (TJunction/system/cudaParticlesDict:17-28: 4e6 particles
+        from the seeding box, diffusionCoeff 1.5e-05, dt 1e-4) on the 248 000-cell mesh of system/blockMeshDict:68-81 --
+        Brownian AND 3-D.  pimpleFoam's field is replaced by the closed-form split flow of cases/tjunction.py."""
+        if args.tjunction_steps <= 0:
+            return None
+        from cudaparticlesfoam_amd.api import Context
+        from cudaparticlesfoam_amd.cases import tjunction as tj
+        torch = self.torch
+        mesh = tj.tjunction_mesh()
+        centres, _ = mesh.cell_centres_volumes()
+        d = tj.PARTICLE_DICT
+        ctx2 = Context(self.device.index or 0)
+        ctx2.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            ctx2.set_mesh(mesh)
+            ctx2.set_velocity(tj.split_flow_u(mesh, centres, d["startTime"]))
+            n, interval, Db = int(args.tjunction_particles), 25, d["diffusionCoeff"]
+            cl = self._fresh_cloud(n, d["seedingBox"], 2027, ctx=ctx2, sort_interval=interval)
+            ctx2.set_option("stats", 1); c0 = ctx2.counters()
+            cl.step(dt, 10, D=Db)
+            torch.cuda.synchronize(); c1 = ctx2.counters(); ctx2.set_option("stats", 0)
+            cl.step_index = 0
+            r = self._timed_steps(torch, ctx2, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
+            rec_once = 256 * mesh.n_cells
+            r.update({"D": Db, "particles": n, "cells": mesh.n_cells, "sort_interval": interval,
+                      "sorts_inside": args.tjunction_steps // interval, "kernel": ctx2.step_kernel_name(Db, 0),
+                      "mesh_flags": ctx2.mesh_flags(), "records_bytes_once": rec_once,
+                      "cells_visited_per_particle_step": round((c1["cells_visited"] - c0["cells_visited"]) /
+                                                               max(1, c1["particle_steps"] - c0["particle_steps"]), 3),
+                      "seeding_box": [list(d["seedingBox"][0]), list(d["seedingBox"][1])],
+                      "field": "closed-form split flow, u0 = 3 m/s at t = 0.5 s (stand-in for pimpleFoam's U)"})
+            del cl
+        finally:
+            ctx2.close()
+        return r
 
     def finish(self):
         if self.dist_on:
@@ -408,6 +664,7 @@ def run(args, M):
     cloud.set_particles(x, y, z, c, gid)
     del x, y, z, c, gid
     if dist_on:
+        stage("first_exchange")
         cloud.rebalance(mesh.n_cells)         # also pays RCCL's one-time all-reduce / all-to-all set-up before timing
         cloud.exchange()
     if not args.no_sort:
@@ -422,6 +679,7 @@ def run(args, M):
     spinup = M.spinup(cloud, dt, args.spinup_ms)
     ctx.set_option("stats", 1)
     counters0 = ctx.counters()
+    stage("warmup")
     cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
     M.sync(); barrier()
     counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
@@ -436,6 +694,7 @@ def run(args, M):
     hhost0, ncomm0, ex0 = cloud.handoff_host_ms, len(cloud._comm_events), cloud.exchanges
     cloud.profile_comm = True                      # keep the (start, end) events of the hand-offs' collectives
     M.sync(); barrier()
+    stage("timed_region")
     t0 = time.perf_counter()
     cloud.step(dt, args.steps)
     cloud.flush()                                  # a hand-off still in flight belongs to the timed region
@@ -464,8 +723,10 @@ def run(args, M):
     n_after = cloud.global_count()
 
     brown = fused = steady = anchor = None
+    more = {}
     if world == 1 and not args.force_dist:
-        brown, fused, steady, anchor = M.extras(cloud, dt, args, full_box)
+        stage("extras")
+        brown, fused, steady, anchor, more = M.extras(cloud, dt, args, full_box)
 
     out = None
     if rank == 0:
@@ -514,6 +775,9 @@ def run(args, M):
                                          if dist_on else None),
                        "ms_per_step_steady": steady, "brownian": brown, "device_spinup": spinup,
                        "extra_fused_cycles": fused, "strong_anchor_1e8": anchor,
+                       # what the tutorials actually run, after the timed region (never `value`)
+                       "brownian_steady": more.get("brownian_steady"), "analytic_field": more.get("analytic_field"),
+                       "tjunction_as_run": more.get("tjunction_as_run"),
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
                        "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},
@@ -532,6 +796,7 @@ def run(args, M):
                 out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
                                        "sample": "unavailable: %r" % (e,)}
     M.finish()
+    stage("done")
     return out
 
 
@@ -544,7 +809,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
-    out = run(args, GpuMachine(args, rank, world, local))
+    dog = rank_watchdog(args, rank, world)
+    try:
+        out = run(args, GpuMachine(args, rank, world, local))
+    except Exception as e:                          # a failed collective, a HIP error ...: say where, leave non-zero
+        import traceback
+        traceback.print_exc()
+        if rank == 0 and world > 1:
+            print(json.dumps({"error": "%s: %s" % (type(e).__name__, str(e)[:400]), "stage": _STAGE, "n_gpus": world}), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(1)                                 # (not sys.exit: a process group left half-initialised may hang in its destructor)
+    if dog is not None:
+        dog.cancel()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: anything a library left in C stdio's buffer goes out before it
         try:

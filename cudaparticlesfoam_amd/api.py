@@ -278,6 +278,20 @@ def build_mesh_tables_host(mesh):
     return dict(cell_off=off, planes=planes, nbr=nbr, group_off=goff, group_nbr=gnbr[:nm.value])
 
 
+def mesh_flags_host(mesh):
+    """What ``Context.mesh_flags()`` would report after ``set_mesh(mesh)``, computed on the host alone (cpf_mesh_flags_host)."""
+    lib = L.load()
+    a = [np.ascontiguousarray(mesh.points, dtype=np.float64), np.ascontiguousarray(mesh.face_offsets, dtype=np.int32),
+         np.ascontiguousarray(mesh.face_verts, dtype=np.int32), np.ascontiguousarray(mesh.owner, dtype=np.int32),
+         np.ascontiguousarray(mesh.neighbour, dtype=np.int32)]
+    v = [C.c_int32(0) for _ in range(4)]
+    st = lib.cpf_mesh_flags_host(_ptr(a[0]), mesh.n_points, _ptr(a[1]), _ptr(a[2]), mesh.n_faces, _ptr(a[3]), _ptr(a[4]),
+                                 mesh.n_internal, mesh.n_cells, *[C.byref(k) for k in v])
+    if st != L.CPF_OK:
+        raise L.CpfError(st, "cpf_mesh_flags_host")
+    return dict(all_hex=v[0].value, z_layered=v[1].value, z_thin=v[2].value, mixed=v[3].value)
+
+
 def pack_mesh_parts(parts):
     """(ctypes array of cpf_mesh_part, the numpy arrays it points into)."""
     arr = (L.MeshPart * len(parts))()

@@ -348,6 +348,26 @@ int cpf_build_mesh_tables_host(const double* points, int64_t nPoints, const int3
     return CPF_OK;
 }
 
+int cpf_mesh_flags_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                        int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                        int32_t* allHex, int32_t* zLayered, int32_t* zThin, int32_t* mixed) {
+    if (!points || !faceOffsets || !faceVerts || !owner || (!neighbour && nInternal != 0)) return CPF_ERR_ARG;
+    cpf::HostTables t;
+    try {
+        const std::string why = cpf::build_tables<int32_t>(points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour, nInternal, nCells, t);
+        if (!why.empty()) return CPF_ERR_MESH;
+    } catch (const std::bad_alloc&) {
+        return CPF_ERR_NOMEM;
+    }
+    // (as meshView() derives them from a context's tables, with the default options)
+    const bool hex = t.minCellFaces == 6 && t.maxCellFaces == 6 && t.nGroups() == 0;
+    if (allHex) *allHex = hex ? 1 : 0;
+    if (zLayered) *zLayered = t.zPairLast ? 1 : 0;
+    if (zThin) *zThin = t.zThin ? 1 : 0;
+    if (mixed) *mixed = hex ? 0 : (t.nBigCells * 4 <= nCells ? (t.nBigCells > 0 ? 2 : 1) : 0);
+    return CPF_OK;
+}
+
 int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nSlots, int64_t* deviceBytes) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_mesh_info: no mesh set");

@@ -241,6 +241,12 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         for (int64_t c = 0; c < nCells && out.zThin; ++c) {
             const size_t s0 = (size_t)out.cellOff[(size_t)c];
             if (out.nbr[s0 + 4] >= 0 || out.nbr[s0 + 5] >= 0) { out.zThin = false; break; }
+            // ... and the four side faces have nz == 0 EXACTLY: fold_z's argument (a segment's cells depend on its x-y
+            // projection alone; a reflection off a side wall leaves E.z alone) needs it.  A one-cell-thick mesh with
+            // sheared or tapered side faces keeps its z faces in the walk.
+            for (int s = 0; s < 4; ++s)
+                if (out.planes[4 * (s0 + s) + 2] != 0.0) out.zThin = false;
+            if (!out.zThin) break;
             const double za = out.planes[4 * (s0 + 4) + 3] * out.planes[4 * (s0 + 4) + 2];
             const double zb = out.planes[4 * (s0 + 5) + 3] * out.planes[4 * (s0 + 5) + 2];
             const double lo = std::min(za, zb), hi = std::max(za, zb);

@@ -177,6 +177,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     unsigned tlTiles = 0, tlRounds = 0;
     // time (100 MHz ticks) spent in the wait for missing records / in the wait that ends a tile, and rounds with a miss
     unsigned tlWaitRec = 0, tlWaitEnd = 0, tlMissRounds = 0;
+    // census of the rounds (tools/stream_timeline.py --census), behind the per-wave rows in the same array: busy lanes per
+    // round index, lanes that sat a round out, rounds per tile against the tile's largest visit count
+    unsigned long long* const tlH = (!STORE_VEL && vel != nullptr) ? reinterpret_cast<unsigned long long*>(vel) + 8 * 16384 : nullptr;
+    unsigned tlVis = 0, tlRoundIdx = 0;
 #endif
 
     for (unsigned k = blockIdx.x; k < (unsigned)kStreamGroups; k += gridDim.x)
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             auto round = [&](bool hookDue, bool cycleStart, int c) __attribute__((always_inline)) {
 #ifdef CPF_STREAM_TIMELINE
                 ++tlRounds;
+                bool tlSat = false;
 #endif
                 // ---- record cache lookup, two ways (LOOKUP_FIXED, chosen per launch by stream_lookup_mode()).  Few particles per cell
                 // (3-D meshes: 5-10 distinct cells per round): every lane compares its cell with the NS tags (tag k
@@ -566,6 +571,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     // ---- what the visit led to.  The common outcomes -- the segment ends here, or it crosses into a neighbour --
                     // are applied with selects, not branches: nested branches made the compiler shuttle cell, token and the two
                     // counters between registers at every join (a dozen v_mov per round).  Only the wall is a branch (rare).
+#ifdef CPF_STREAM_TIMELINE
+                    if (next == kSitOut) tlSat = true; else ++tlVis;
+#endif
                     const bool ends = next == cur;                                 // segment ends in this cell
                     const bool wall = next < 0 && next != kSitOut;                 // a boundary face (kSitOut: no visit this round)
                     const bool cross = next >= 0 && !ends;
@@ -589,6 +597,17 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     h += cross ? 1 : 0;
                     busy = !(ends || (cross && h == kMaxHops) || (wall && j >= kMaxReflect));   // hop cap: keep the last cell
                 }
+#ifdef CPF_STREAM_TIMELINE
+                {
+                    const unsigned nb = (unsigned)__popcll(busyMask), ns = (unsigned)__popcll(ballot64(tlSat));
+                    const unsigned r = tlRoundIdx < 15u ? tlRoundIdx : 15u;
+                    if (tlH != nullptr && lane == 0) {
+                        atomicAdd(&tlH[r * 65u + nb], 1ull); atomicAdd(&tlH[16 * 65 + r], (unsigned long long)ns);
+                        atomicAdd(&tlH[16 * 65 + 16 + 256 + r], (unsigned long long)nJobs);
+                    }
+                    ++tlRoundIdx;
+                }
+#endif
             };
 
             auto cycle_end = [&]() __attribute__((always_inline)) {
@@ -614,9 +633,34 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 // A cycle's first round always runs, even with no busy lane (cycle 0's carries the hook).
                 for (int c = 0; c < nCyc; ++c) {
                     cycle_begin(c);
+#ifdef CPF_STREAM_TIMELINE
+                    tlVis = 0; tlRoundIdx = 0;
+#endif
                     bool hookDue = c == 0, cycleStart = true;
+#ifdef CPF_STREAM_CAP_TEST
+                    // upper-bound experiment (results are WRONG): a cycle stops after CPF_STREAM_CAP_TEST rounds; lanes still busy
+                    // then do not move in this step (position and cell re-read from global memory)
+                    int capRounds = 0, capLimit = CPF_STREAM_CAP_TEST;
+                    asm volatile("" : "+s"(capLimit));                      // (opaque: a constant bound makes hipcc unroll the round loop)
+                    do { round(hookDue, cycleStart, c); hookDue = false; cycleStart = false; ++capRounds; } while (ballot64(busy) != 0ull && capRounds < capLimit);
+                    const bool capDropped = busy;
+                    const D3 capKeep = S_;
+                    const int capCur = cur;
+#else
                     do { round(hookDue, cycleStart, c); hookDue = false; cycleStart = false; } while (ballot64(busy) != 0ull);
+#endif
+#ifdef CPF_STREAM_TIMELINE
+                    {
+                        unsigned mx = tlVis;
+                        for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = o > mx ? o : mx; }
+                        const unsigned r = tlRoundIdx < 15u ? tlRoundIdx : 15u, iv = mx < 15u ? mx : 15u;
+                        if (tlH != nullptr && lane == 0) atomicAdd(&tlH[16 * 65 + 16 + r * 16u + iv], 1ull);
+                    }
+#endif
                     cycle_end();
+#ifdef CPF_STREAM_CAP_TEST
+                    if (capDropped) { S_ = capKeep; cur = capCur; }       // stops where its last crossing left it (a consistent state)
+#endif
                 }
             } else {
                 const D3 prev = {sE[0][lane], sE[1][lane], sE[2][lane]};

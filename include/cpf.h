@@ -144,6 +144,10 @@ int cpf_build_mesh_tables_host(const double* points, int64_t nPoints, const int3
                                int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
                                int64_t* nSlots, int64_t* nGroups, int64_t* nMembers, int32_t* cellOff, double* planes,
                                int32_t* nbr, int32_t* groupOff, int32_t* groupNbr);
+/* ... and the flags cpf_get_mesh_flags would report for it (same meaning; any pointer may be NULL). */
+int cpf_mesh_flags_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                        int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                        int32_t* allHex, int32_t* zLayered, int32_t* zThin, int32_t* mixed);
 
 /* Cell-constant velocity U[nCells][3] (host, zero-copy from U.primitiveField()).  Replaces the
  * 12x replication loop + cudaUpdateVelocity of src/advect.H:44-57 (cuda/particles.cu:718-749):

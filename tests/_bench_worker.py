@@ -90,7 +90,7 @@ class CpuMachine:
         return 0.0
 
     def extras(self, cloud, dt, args, box):
-        return None, None, None, None
+        return None, None, None, None, {}
 
     def finish(self):
         dist.barrier()
@@ -99,6 +99,10 @@ class CpuMachine:
 
 def main():
     args = bench.parse(sys.argv[1:])
+    bench.stage("rccl_init")
+    if os.environ.get("BENCH_TEST_HANG_RANK") == os.environ.get("RANK"):
+        import time
+        time.sleep(3600)                                 # a rank that never reaches its first collective (test_bench_contract.py)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == args.gpus

@@ -77,6 +77,46 @@ def test_world_2_orchestration_over_gloo_prints_one_strong_scaling_line():
     assert "configs[3]" in c["workload"] and "strong" in c["workload"]
 
 
+def test_a_rank_that_hangs_becomes_an_error_line_within_the_limit():
+    """`python bench.py --gpus 2` starts its ranks as a child process tree under a wall-clock limit.  Here rank 1 never
+    reaches its first collective (the CPU stand-in over gloo sleeps instead): the parent must kill the whole tree when
+    --launch-timeout expires, print ONE JSON line {"error", "stage", "n_gpus"} and exit non-zero -- a hang in the first
+    multi-GPU run turns into a diagnosis instead of burning the caller's time limit."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BENCH_TEST_HANG_RANK="1", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "2000", "--steps", "2",
+                        "--warmup", "1", "--launch-timeout", "25", "--child-script", os.path.join(ROOT, "tests", "_bench_worker.py")],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert r.returncode == 124, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    assert 25 <= took < 90
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stage"] == "rccl_init" and "launch-timeout" in d["error"]
+    # nothing of the tree is left behind
+    ps = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert "_bench_worker.py" not in ps, ps
+
+
+def test_self_launched_cpu_ranks_forward_one_json_line():
+    """The same launcher on the happy path (CPU stand-in, gloo world 2): rank 0's line is the parent's only stdout line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "4000", "--steps", "8",
+                        "--warmup", "2", "--rebalance-interval", "4", "--overlap-steps", "2", "--launch-timeout", "600",
+                        "--child-script", os.path.join(ROOT, "tests", "_bench_worker.py")],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = _check(lines[0], need_cpu_baseline=False, scaling="strong")
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2
+    assert "[bench stage] timed_region" in r.stderr
+
+
 def test_plain_gpus_n_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment must get as far as the ranks themselves (here:
     their refusal to run without a GPU), i.e. fail inside the child ranks and not in the argument handling -- and hand
@@ -91,7 +131,11 @@ def test_plain_gpus_n_starts_its_own_ranks(tmp_path):
     assert "must be launched with" not in r.stderr
     # both ranks came up under torch.distributed.run and stopped where the product path needs its GPU
     assert "bench.py needs a GPU" in r.stderr or "invalid device ordinal" in r.stderr or "NCCL" in r.stderr or "HIP" in r.stderr, r.stderr[-3000:]
-    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # the one stdout line is an error record (no metric), naming the stage the ranks died in
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "error" in d and "metric" not in d and d["n_gpus"] == 2 and d["stage"] in ("launch", "rccl_init")
 
 
 @pytest.mark.gpu
@@ -101,7 +145,8 @@ def test_bench_runs_and_prints_one_json_line(extra):
     --force-dist drives the N>1 host path (RCCL group of one rank) through the same script."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e5", "--steps", "6", "--warmup", "2",
            "--no-cpu-baseline", "--rebalance-interval", "3", "--overlap-steps", "1", "--anchor-particles", "4e5",
-           "--anchor-steps", "3"] + extra
+           "--anchor-steps", "3", "--brownian-steady-steps", "30", "--analytic-extra", "4", "--tjunction-steps", "30",
+           "--tjunction-particles", "3e5"] + extra
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -123,5 +168,13 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert st["steps"] == 100 and st["sorts_inside"] == 1 and st["ms_per_step"] > 0
         f = d["config"]["extra_fused_cycles"]
         assert f["cycles_per_launch"] == 8 and f["launches"] == 10 and f["Mparticle_steps_per_s"] > 0
+        # what the tutorials actually run: sustained diffusion (sorts inside), the frozen analytic field, TJunction as its dictionary runs it
+        bs, af, tj = d["config"]["brownian_steady"], d["config"]["analytic_field"], d["config"]["tjunction_as_run"]
+        assert bs["D"] == 1.5e-5 and bs["sort_interval"] == 25 and bs["sorts_inside"] == 1 and bs["steps"] == 30 and 0 < bs["frac"] < 1
+        assert bs["kernel"] == b["kernel"] and bs["frac"] <= bs["kernel_frac"] * 1.02
+        assert af["steps"] == 4 and af["kernel"] == d["roofline"]["kernel"] and 0 < af["frac"] < 1 and af["cells_visited_per_particle_step"] > 1
+        assert tj["particles"] == 300_000 and tj["cells"] == 248_000 and tj["D"] == 1.5e-5 and tj["records_bytes_once"] == 256 * 248_000
+        assert tj["kernel"].startswith("cpf::step_kernel_stream<true, true, false, false,") and 0 < tj["frac"] < 1
+        assert tj["mesh_flags"]["all_hex"] == 1 and tj["mesh_flags"]["z_thin"] == 0
         a = d["config"]["strong_anchor_1e8"]               # the N = 1 point of the strong-scaling curve (here: 4e5)
         assert a["particles"] == 400_000 and a["particles_after"] == 400_000 and a["steps"] == 3 and a["Mparticle_steps_per_s"] > 0

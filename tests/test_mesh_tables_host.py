@@ -74,3 +74,20 @@ def test_rounding_noise_in_face_normals_is_zero_and_pitzdaily_is_z_layered(pitz)
     assert (h["nbr"].reshape(-1, 6)[:, 4:] < 0).all()                            # front / back: boundary faces, one cell thick
     zw = pl[:, 4:, 3] * pl[:, 4:, 2]                                             # the planes' z positions agree to rounding
     assert np.ptp(zw.min(1)) < 1e-15 and np.ptp(zw.max(1)) < 1e-15
+
+
+def test_one_cell_thick_mesh_with_slanted_side_faces_is_not_z_thin(pitz):
+    """fold_z (csrc/cpf_walk.h) mirrors a kicked end point about the front / back plane BEFORE the walk and may then leave
+    both z faces out of the rounds; its argument needs the four side faces of every cell to have nz == 0 exactly.  A block
+    that is one cell thick in z but whose back plane is shifted in x (slanted side faces, planar z faces with normals exactly
+    along z) must keep its z faces in the walk: z_layered stays, z_thin does not."""
+    from cudaparticlesfoam_amd.api import mesh_flags_host
+    from cudaparticlesfoam_amd.cases import block_mesh, box_mesh
+    f = mesh_flags_host(pitz["mesh"])
+    assert f == dict(all_hex=1, z_layered=1, z_thin=1, mixed=0)
+    assert mesh_flags_host(box_mesh(6, 5, 1))["z_thin"] == 1                     # straight side faces
+    assert mesh_flags_host(box_mesh(6, 5, 2))["z_thin"] == 0                     # two cells thick: z faces are not all walls
+    v = np.array([[0, 0, 0], [6, 0, 0], [6, 5, 0], [0, 5, 0], [0.5, 0, 1], [6.5, 0, 1], [6.5, 5, 1], [0.5, 5, 1]], float)
+    sheared = block_mesh(v, [dict(hex=range(8), n=(6, 5, 1), simple=(1, 1, 1))])
+    f = mesh_flags_host(sheared)
+    assert f["all_hex"] == 1 and f["z_layered"] == 1 and f["z_thin"] == 0

@@ -1,12 +1,18 @@
 #!/usr/bin/env bash
-# GPU box: how many waves of the streaming kernel are really resident?  Timeline build (build_ab/lib_onetl.so,
-# -DCPF_STREAM_TIMELINE), grid sized for 24 / 28 / 32 single-wave workgroups per CU: a wave slot the hardware does not
-# admit starts only when another wave has exited (start time >> 0).
+# GPU box: census of the streaming kernel's rounds (timeline build build_ab/lib_onetl.so, -DCPF_STREAM_TIMELINE): busy lanes
+# per round index, sit-outs, rounds per tile against the largest visit count -> gpurun_out/<label>_census.jsonl
 cd "$(dirname "$0")/.." || exit 1
+LABEL="${1:-r04}"
+OUT=gpurun_out/${LABEL}_census.jsonl; : > $OUT
 LIB=cudaparticlesfoam_amd/lib/libcudaParticleAdvection.so
 cp $LIB /tmp/lib_orig.so
 cp build_ab/lib_onetl.so $LIB
-for w in 24 28 32; do
-  python tools/stream_timeline.py --label "waves_per_cu=$w" --opt stream_waves_per_cu=$w "$@" 2>&1 | grep kernel_ms
-done
+run() { timeout -s KILL 300 python tools/stream_timeline.py --census "$@" > /tmp/census_run.log 2>&1; grep kernel_ms /tmp/census_run.log >> $OUT || tail -5 /tmp/census_run.log; }
+run --label pitz
+run --label pitz_brown --D 1.5e-5
+run --label box3d --mesh3d
+run --label box3d_brown --mesh3d --D 1.5e-5
+run --label tjunction --tjunction
+run --label tjunction_brown_4e6 --tjunction --D 1.5e-5 --particles 4e6
 cp /tmp/lib_orig.so $LIB
+cut -c1-300 $OUT

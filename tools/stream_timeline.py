@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--D", type=float, default=0.0, help="diffusion coefficient of the measured launches")
     ap.add_argument("--groups", action="store_true", help="also per-group (= per-CU) and per-XCD end times")
     ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh of tools/bench_3d.py, swirl field")
+    ap.add_argument("--tjunction", action="store_true", help="the reference's TJunction tutorial mesh (248 000 cells), split flow u0 = 3")
+    ap.add_argument("--census", action="store_true", help="busy lanes per round index, sit-outs, rounds against the largest visit count of a tile")
     args = ap.parse_args()
     import torch
     import bench
@@ -32,7 +34,23 @@ def main():
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     n = int(args.particles)
-    if args.mesh3d:
+    if args.tjunction:
+        from cudaparticlesfoam_amd.cases import tjunction as tj
+        mesh = tj.tjunction_mesh()
+        cc, _ = mesh.cell_centres_volumes()
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(tj.split_flow_u(mesh, cc, 0.5))
+        torch.manual_seed(7)
+        na = int(n * 80.0 / 248.0)
+        u = torch.rand((3, n), dtype=torch.float64, device=dev)
+        ar = torch.arange(n, device=dev)
+        x = torch.where(ar < na, u[0] * 0.2, 0.2 + u[0] * 0.02).contiguous()
+        y = torch.where(ar < na, -0.01 + u[1] * 0.02, -0.21 + u[1] * 0.42).contiguous()
+        z = (u[2] * 0.02).contiguous()
+        del u, ar
+        c = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), n)
+    elif args.mesh3d:
         from cudaparticlesfoam_amd.cases import block_mesh
         v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
                       [0, 0.05, 0.05]], float)
@@ -56,7 +74,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("="); ctx.set_option(k, float(v))
     ctx.sort_by_cell_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), g.data_ptr(), n)
-    tl = torch.zeros(8 * 16384, dtype=torch.int64, device=dev)
+    NCEN = 16 * 65 + 16 + 256 + 16
+    tl = torch.zeros(8 * 16384 + NCEN, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
     for _ in range(args.pre_steps):
         ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, 1e-4, args.D, 0, 1, 0)
@@ -65,7 +84,8 @@ def main():
     ctx.timing_enable(True)
     ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, 1e-4, args.D, 5, 1, 0)
     launches, ms = ctx.timing_read()
-    raw = tl.cpu().numpy()
+    raw_all = tl.cpu().numpy()
+    raw, cen = raw_all[:8 * 16384], raw_all[8 * 16384:].astype(np.float64)
     stride = 8 if args.variant == 4 else 4          # variant 4 builds also report waits: see below
     t = raw[: (raw.size // stride) * stride].reshape(-1, stride)
     idx = np.nonzero(t[:, 1] > 0)[0]
@@ -91,6 +111,31 @@ def main():
         out["miss_rounds_per_tile"] = round(float(miss_rounds.sum() / max(1, t[:, 2].sum())), 3)
         out["us_per_record_wait"] = round(wrec / max(1.0, float(miss_rounds.sum())), 3)
         out["us_per_tile_end_wait"] = round(wend / max(1.0, float(t[:, 2].sum())), 3)
+    if args.census and cen.any():
+        H = cen[:16 * 65].reshape(16, 65)
+        sat = cen[16 * 65:16 * 65 + 16]
+        J = cen[16 * 65 + 16:16 * 65 + 16 + 256].reshape(16, 16)        # [rounds of the tile][largest visit count of a lane]
+        jobs = cen[16 * 65 + 16 + 256:]
+        tiles = J.sum()
+        rounds_r = H.sum(1)                                             # tiles that ran a round with index r
+        busy_r = (H * np.arange(65)[None, :]).sum(1)                    # busy lanes entering round r
+        out["census"] = dict(
+            tiles=int(tiles),
+            rounds_per_tile=round(float(rounds_r.sum() / tiles), 3),
+            ideal_rounds_per_tile=round(float((J.sum(0) * np.arange(16)).sum() / tiles), 3),
+            tiles_running_round=[round(float(v / tiles), 4) for v in rounds_r[:10]],
+            busy_lanes_per_tile_entering_round=[round(float(v / tiles), 3) for v in busy_r[:10]],
+            sitout_lanes_per_tile_in_round=[round(float(v / tiles), 3) for v in sat[:10]],
+            record_requests_per_tile_in_round=[round(float(v / tiles), 3) for v in jobs[:10]],
+            rounds_hist=[round(float(v / tiles), 4) for v in J.sum(1)[:12]],
+            ideal_hist=[round(float(v / tiles), 4) for v in J.sum(0)[:12]],
+            # had the tile stopped after R rounds: lanes still busy (to be parked), per tile
+            parked_lanes_per_tile_if_capped_at=[round(float(busy_r[R] / tiles), 3) for R in range(1, 7)],
+            rounds_per_tile_if_capped_at=[round(float(rounds_r[:R].sum() / tiles), 3) for R in range(1, 7)],
+            # rounds with <= 8 / 16 busy lanes entering, per tile
+            rounds_with_le8_busy=round(float(H[:, 1:9].sum() / tiles), 3), rounds_with_le16_busy=round(float(H[:, 1:17].sum() / tiles), 3),
+            rounds_with_le8_busy_by_round=[round(float(v / tiles), 3) for v in H[:10, 1:9].sum(1)],
+        )
     if args.groups:
         # per chunk-counter group (block id mod 256 = one CU: blocks go round-robin over 8 XCDs x 32 CUs) and per XCD
         grp = idx % 256
