@@ -47,13 +47,14 @@ def parse(argv=None):
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
     ap.add_argument("--exchange-interval", type=int, default=0,
                     help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
-    ap.add_argument("--rebalance-interval", type=int, default=16,
+    ap.add_argument("--rebalance-interval", type=int, default=32,
                     help="N>1: re-cut the cell ranges to equal particle counts + hand-off every that many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", choices=["time", "count"], default="time",
                     help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
-    ap.add_argument("--overlap-steps", type=int, default=4,
-                    help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight")
+    ap.add_argument("--overlap-steps", type=int, default=-1,
+                    help="N>1: cycles the step loop runs on while a hand-off's counts and payload are in flight; -1 = derived "
+                         "per rank from the measured host time of a hand-off: ceil(host_ms / step_ms) + 1 (parallel.py, _overlap)")
     ap.add_argument("--fused-extra", type=int, default=10,
                     help="after the timed region, also time this many launches of 8 fused cycles -- what the replacement "
                          "advect.H does between two output points (extra field config.extra_fused_cycles, never `value`; "
@@ -692,6 +693,7 @@ def run(args, M):
     ctx.timing_read()                              # drop the warm-up launches' events
     handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
     hhost0, ncomm0, ex0 = cloud.handoff_host_ms, len(cloud._comm_events), cloud.exchanges
+    hwait0 = getattr(cloud, "handoff_wait_ms", 0.0)
     cloud.profile_comm = True                      # keep the (start, end) events of the hand-offs' collectives
     M.sync(); barrier()
     stage("timed_region")
@@ -762,7 +764,8 @@ def run(args, M):
                        "mesh_flags": ctx.mesh_flags() if hasattr(ctx, "mesh_flags") else None,
                        "exchange_interval": args.exchange_interval if world > 1 else None,
                        "rebalance_interval": args.rebalance_interval if world > 1 else None,
-                       "overlap_steps": args.overlap_steps if dist_on else None,
+                       "overlap_steps": (cloud._overlap() if args.overlap_steps < 0 else args.overlap_steps) if dist_on else None,
+                       "overlap_steps_auto": (args.overlap_steps < 0) if dist_on else None,
                        "balance": (("measured step time" if args.balance == "time" else "particle count")
                                    if dist_on else None),
                        "particles_per_rank_at_end": per_rank if world > 1 else None,
@@ -771,6 +774,8 @@ def run(args, M):
                        "rccl_ranks": rccl_ranks,
                        "ms_in_handoff": ({"host_ms_total": round(handoff_host_ms, 3), "collectives_device_ms_total": round(handoff_comm_ms, 3),
                                           "handoffs": handoffs,
+                                          "host_wait_ms_total": round(getattr(cloud, "handoff_wait_ms", 0.0) - hwait0, 3),
+                                          "host_work_ms_per_handoff": round((handoff_host_ms - (getattr(cloud, "handoff_wait_ms", 0.0) - hwait0)) / max(1, handoffs), 4),
                                           "host_ms_per_step": round(handoff_host_ms / max(1, args.steps), 4)}
                                          if dist_on else None),
                        "ms_per_step_steady": steady, "brownian": brown, "device_spinup": spinup,

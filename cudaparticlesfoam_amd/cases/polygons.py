@@ -64,3 +64,62 @@ def cut_corner_box(nx: int, ny: int, nz: int, every: int = 3, cut: float = 0.4) 
             kinds["squares_with_hanging_node" if len(loop) > 4 else "squares"] += 1
             loops.append(loop)
     return extrude_polygons(np.asarray(pts), loops, np.arange(nz + 1, dtype=np.float64)), kinds
+
+
+def chamfered_box(nx: int, ny: int, nz: int, cuts_per_corner: int = 1, period: int = 3, cut: float = 0.3) -> Tuple[PolyMesh, Dict[str, int]]:
+    """An nx x ny grid of unit squares in which every square with i % period == 1 and j % period == 1 has ALL FOUR corners
+    chamfered -- with one cut an octagon (prism: TEN distinct planes: a two-record cell, cpf_walk.h), with two cuts per
+    corner a dodecagon (FOURTEEN: beyond two records, header record + CSR walk) -- extruded nz layers in z.  The corner
+    pieces are triangular prisms (five planes); the four edge neighbours of a chamfered square get two hanging nodes on the
+    shared edge, i.e. a face group of three coplanar pieces.  Returns the mesh over [0, nx] x [0, ny] x [0, nz] and the number
+    of 2-D cells of each kind."""
+    assert cuts_per_corner in (1, 2) and period >= 3 and 0.0 < cut < 0.5
+    vid = lambda i, j: j * (nx + 1) + i                                    # noqa: E731
+    pts: List[Tuple[float, float]] = [(float(i), float(j)) for j in range(ny + 1) for i in range(nx + 1)]
+    hanging_h: Dict[Tuple[int, int], List[Tuple[float, int]]] = {}         # on the edge (i, j) -> (i + 1, j): (x, vertex)
+    hanging_v: Dict[Tuple[int, int], List[Tuple[float, int]]] = {}         # on the edge (i, j) -> (i, j + 1): (y, vertex)
+
+    def new_point(x, y):
+        pts.append((x, y)); return len(pts) - 1
+
+    chosen = [(i, j) for j in range(ny) for i in range(nx) if i % period == 1 and j % period == 1]
+    chosen_set = set(chosen)
+    loops: List[List[int]] = []
+    kinds = {"polygons": 0, "triangles": 0, "squares_with_hanging_nodes": 0, "squares": 0}
+    e = cut / 6.0
+    for i, j in chosen:
+        x0, y0, x1, y1 = float(i), float(j), i + 1.0, j + 1.0
+        # chamfer end points on the four edges, in the polygon's counter-clockwise order
+        pL0, pB0 = new_point(x0, y0 + cut), new_point(x0 + cut, y0)        # bottom-left corner
+        pB1, pR0 = new_point(x1 - cut, y0), new_point(x1, y0 + cut)        # bottom-right
+        pR1, pT1 = new_point(x1, y1 - cut), new_point(x1 - cut, y1)        # top-right
+        pT0, pL1 = new_point(x0 + cut, y1), new_point(x0, y1 - cut)        # top-left
+        hanging_h[(i, j)] = [(x0 + cut, pB0), (x1 - cut, pB1)]
+        hanging_h[(i, j + 1)] = [(x0 + cut, pT0), (x1 - cut, pT1)]
+        hanging_v[(i, j)] = [(y0 + cut, pL0), (y1 - cut, pL1)]
+        hanging_v[(i + 1, j)] = [(y0 + cut, pR0), (y1 - cut, pR1)]
+        corners = [(vid(i, j), pL0, pB0, (x0 + cut / 2 - e, y0 + cut / 2 - e)),
+                   (vid(i + 1, j), pB1, pR0, (x1 - cut / 2 + e, y0 + cut / 2 - e)),
+                   (vid(i + 1, j + 1), pR1, pT1, (x1 - cut / 2 + e, y1 - cut / 2 + e)),
+                   (vid(i, j + 1), pT0, pL1, (x0 + cut / 2 - e, y1 - cut / 2 + e))]
+        poly: List[int] = []
+        for V, first, last, mid in corners:
+            if cuts_per_corner == 1:
+                poly += [first, last]
+                loops.append([V, last, first]); kinds["triangles"] += 1
+            else:
+                m = new_point(*mid)
+                poly += [first, m, last]
+                loops.append([V, m, first]); loops.append([V, last, m]); kinds["triangles"] += 2
+        loops.append(poly); kinds["polygons"] += 1
+    for j in range(ny):
+        for i in range(nx):
+            if (i, j) in chosen_set:
+                continue
+            loop = [vid(i, j)] + [v for _, v in sorted(hanging_h.get((i, j), []))]                     # bottom edge, left to right
+            loop += [vid(i + 1, j)] + [v for _, v in sorted(hanging_v.get((i + 1, j), []))]            # right edge, upwards
+            loop += [vid(i + 1, j + 1)] + [v for _, v in sorted(hanging_h.get((i, j + 1), []), reverse=True)]   # top edge, right to left
+            loop += [vid(i, j + 1)] + [v for _, v in sorted(hanging_v.get((i, j), []), reverse=True)]  # left edge, downwards
+            kinds["squares_with_hanging_nodes" if len(loop) > 4 else "squares"] += 1
+            loops.append(loop)
+    return extrude_polygons(np.asarray(pts), loops, np.arange(nz + 1, dtype=np.float64)), kinds

@@ -30,7 +30,8 @@ struct cpf_context {
     bool zFold = true;               // "z_fold": mirror the kicked end point about the planes of a one-cell-thick mesh before the walk
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
-    double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes)
+    double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes; mixed meshes: cpf_walk.h "cell records")
+    int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;
@@ -121,7 +122,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
     m.zThin = (c->host.zThin && c->zFold) ? 1 : 0;
-    m.mixed = (c->d_cellRec && !m.allHex) ? (c->host.nBigCells > 0 ? 2 : 1) : 0;
+    m.mixed = (c->d_cellRec && !m.allHex) ? (c->host.nBigCells > 0 ? 2 : 1) : 0;      // 2: two-record and / or header cells
     return m;
 }
 cpf::GridView gridView(const cpf_context* c) {
@@ -199,16 +200,28 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
         CPF_HIP(ctx, cpf::launch_build_cell_records(ctx->stream, ctx->d_planes, ctx->d_nbr, ctx->d_U, ctx->d_cellRec, nCells));
         CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->meshBytes += (size_t)nCells * 256;
-    } else if (ctx->host.nBigCells * 4 <= nCells && ctx->mixedRecords) {
-        // not all-hex, but at most a quarter of the cells have more than six slots (a hex-dominant mesh with refinement
-        // interfaces -- whose split faces are face groups, one slot each --, prism layers, a few polyhedra ...): records
-        // for the streaming kernel, padded / header-only where a cell has not exactly six slots (cpf_walk.h "cell
-        // records").  Meshes of mostly polyhedral cells keep the generic CSR walk.
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_cellRec, (size_t)nCells * 8 * sizeof(double4)));
-        CPF_HIP(ctx, cpf::launch_build_cell_records_mixed(ctx->stream, ctx->d_cellOff, ctx->d_planes, ctx->d_nbr, ctx->d_U,
-                                                          ctx->d_cellRec, nCells));
-        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->meshBytes += (size_t)nCells * 256;
+    } else if (ctx->host.nHugeCells * 4 <= nCells && ctx->mixedRecords) {
+        // not all-hex, but at most a quarter of the cells have more than TWELVE slots: records for the streaming kernel --
+        // padded where a cell has fewer than six slots, a second record for slots 6..11 of a cell with 7..12 (true polyhedra
+        // keep the LDS face test: two rounds per visit), a header record + CSR walk only beyond that (cpf_walk.h "cell
+        // records").  Refinement interfaces need none of it: their split faces are face groups, one slot each.
+        std::vector<int32_t> recB((size_t)nCells, -1);
+        int64_t nSecond = 0;
+        for (int64_t c = 0; c < nCells; ++c) {
+            const int nf = ctx->host.cellOff[(size_t)c + 1] - ctx->host.cellOff[(size_t)c];
+            if (nf > 6 && nf <= 12) recB[(size_t)c] = (int32_t)(nCells + nSecond++);
+        }
+        CPF_REQUIRE(ctx, nCells + nSecond < ((int64_t)1 << 31), CPF_ERR_MESH, "cpf_set_mesh: too many cell records");
+        int32_t* d_recB = nullptr;
+        if (nSecond > 0) CPF_HIP(ctx, up(d_recB, recB.data(), recB.size() * 4));
+        hipError_t e = hipMalloc((void**)&ctx->d_cellRec, (size_t)(nCells + nSecond) * 8 * sizeof(double4));
+        if (e == hipSuccess) e = cpf::launch_build_cell_records_mixed(ctx->stream, ctx->d_cellOff, ctx->d_planes, ctx->d_nbr, ctx->d_U, d_recB,
+                                                                      ctx->d_cellRec, nCells);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        freeDev(d_recB);
+        CPF_HIP(ctx, e);
+        ctx->nSecondRecords = nSecond;
+        ctx->meshBytes += (size_t)(nCells + nSecond) * 256;
     }
     ctx->meshBytes += (size_t)nCells * (sizeof(double4) + 24);
     ctx->haveMesh = true;
@@ -364,7 +377,7 @@ int cpf_mesh_flags_host(const double* points, int64_t nPoints, const int32_t* fa
     if (allHex) *allHex = hex ? 1 : 0;
     if (zLayered) *zLayered = t.zPairLast ? 1 : 0;
     if (zThin) *zThin = t.zThin ? 1 : 0;
-    if (mixed) *mixed = hex ? 0 : (t.nBigCells * 4 <= nCells ? (t.nBigCells > 0 ? 2 : 1) : 0);
+    if (mixed) *mixed = hex ? 0 : (t.nHugeCells * 4 <= nCells ? (t.nBigCells > 0 ? 2 : 1) : 0);
     return CPF_OK;
 }
 

@@ -87,7 +87,7 @@ hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n,
 hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,
                                      double4* rec, int64_t nCells);
 hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
-                                           const double4* U, double4* rec, int64_t nCells);
+                                           const double4* U, const int32_t* recB, double4* rec, int64_t nCells);
 hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells);
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
 

@@ -28,6 +28,7 @@ struct HostTables {
     std::vector<int32_t> binCells;  // candidate cells per bin, ascending cell id
     int32_t maxCellFaces = 0, minCellFaces = 0;   // slots per cell
     int64_t nBigCells = 0;          // cells with more than 6 slots
+    int64_t nHugeCells = 0;         // ... of which: more than 12 (header record + CSR walk; 7..12: two records, cpf_walk.h)
     int64_t nGroups() const { return (int64_t)groupOff.size() - 1; }
     bool zThin = false;             // zPairLast and the two z faces of every cell are boundary faces (one cell thick in z)
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5

@@ -832,24 +832,39 @@ __global__ void build_cell_records_kernel(const double4* __restrict__ planes, co
     for (int s = 0; s < 6; ++s) nb[s] = nbr[6 * c + s];
     nb[6] = 0; nb[7] = 0;
 }
-// records of a mesh that is not all-hex (layout: cpf_walk.h "cell records")
+// records of a mesh that is not all-hex (layout: cpf_walk.h "cell records").  recB[c] (may be null): index of the cell's
+// SECOND record (slots 6..11 of a cell with 7..12 slots), behind the nCells first ones; -1 = none
 __global__ void build_cell_records_mixed_kernel(const int32_t* __restrict__ cellOff, const double4* __restrict__ planes,
                                                 const int32_t* __restrict__ nbr, const double4* __restrict__ U,
-                                                double4* __restrict__ rec, int64_t nCells) {
+                                                const int32_t* __restrict__ recB, double4* __restrict__ rec, int64_t nCells) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nCells) return;
     const int s0 = cellOff[c], nf = cellOff[c + 1] - s0;
+    const int second = recB ? recB[c] : -1;
     double4* r = rec + 8 * c;
     int32_t* nb = reinterpret_cast<int32_t*>(r + 7);
     const double4 nullPlane = make_double4(0.0, 0.0, 0.0, -1.0);
+    const bool header = nf > 6 && second < 0;
     for (int s = 0; s < 6; ++s) {
-        const bool real = nf <= 6 && s < nf;
+        const bool real = !header && s < nf;
         r[s] = real ? planes[s0 + s] : nullPlane;
         nb[s] = real ? nbr[s0 + s] : kNullNbr;
     }
     r[6] = U[c];
     nb[6] = 0; nb[7] = 0;
-    if (nf > 6) { nb[0] = kBigCellMark; nb[1] = s0; nb[2] = nf; }
+    if (header) { nb[0] = kBigCellMark; nb[1] = s0; nb[2] = nf; }
+    if (second >= 0) {
+        nb[6] = kTwoRecMark; nb[7] = second;
+        double4* r2 = rec + 8 * (int64_t)second;
+        int32_t* nb2 = reinterpret_cast<int32_t*>(r2 + 7);
+        for (int s = 0; s < 6; ++s) {
+            const bool real = 6 + s < nf;
+            r2[s] = real ? planes[s0 + 6 + s] : nullPlane;
+            nb2[s] = real ? nbr[s0 + 6 + s] : kNullNbr;
+        }
+        r2[6] = U[c];
+        nb2[6] = 0; nb2[7] = 0;
+    }
 }
 __global__ void update_record_velocity_kernel(const double4* __restrict__ U, double4* __restrict__ rec, int64_t nCells) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -890,8 +905,8 @@ hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, cons
     return hipGetLastError();
 }
 hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
-                                           const double4* U, double4* rec, int64_t nCells) {
-    if (nCells > 0) hipLaunchKernelGGL(build_cell_records_mixed_kernel, grid_for(nCells), dim3(kBlock), 0, st, cellOff, planes, nbr, U, rec, nCells);
+                                           const double4* U, const int32_t* recB, double4* rec, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(build_cell_records_mixed_kernel, grid_for(nCells), dim3(kBlock), 0, st, cellOff, planes, nbr, U, recB, rec, nCells);
     return hipGetLastError();
 }
 hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells) {

@@ -184,6 +184,7 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
             const int32_t k = (int32_t)(w - w0);
             out.maxCellFaces = std::max(out.maxCellFaces, k);
             if (k > 6) ++out.nBigCells;
+            if (k > 12) ++out.nHugeCells;
             out.minCellFaces = c == 0 ? k : std::min(out.minCellFaces, k);
         }
         out.cellOff[(size_t)nCells] = (int32_t)w;

@@ -86,7 +86,8 @@ template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (kMixed ? 6 : CPF_STREAM_WAVES)));
+    // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers and a spill at 6 waves, none at 5)
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (LOOKUP == 2 ? 5 : (kMixed ? 6 : CPF_STREAM_WAVES))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
     constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
+    static_assert(!(kInRound && (LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5)), "in-round reflection knows neither face groups nor two-record cells");
     constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5) ? 16 : CPF_STREAM_HIT_POOL);
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     unsigned tlWaitRec = 0, tlWaitEnd = 0, tlMissRounds = 0;
     // census of the rounds (tools/stream_timeline.py --census), behind the per-wave rows in the same array: busy lanes per
     // round index, lanes that sat a round out, rounds per tile against the tile's largest visit count
-    unsigned long long* const tlH = (!STORE_VEL && vel != nullptr) ? reinterpret_cast<unsigned long long*>(vel) + 8 * 16384 : nullptr;
+    unsigned long long* const tlH = (!STORE_VEL && vel != nullptr && (sa.debug & 4)) ? reinterpret_cast<unsigned long long*>(vel) + 8 * 16384 : nullptr;
     unsigned tlVis = 0, tlRoundIdx = 0;
 #endif
 
@@ -259,6 +261,11 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             if (ul > plim || pc < 0) pc = CPF_CELL_FROZEN;
 
             int cur = pc;
+            // (meshes with two-record cells, LOOKUP 2) a lane between the two halves of a visit: `second` = the first record has
+            // been tested, the second one (record index key2) is what the lane looks up next; (carDT, carNext, carBest) carry over
+            bool second = false;
+            int key2 = 0, carNext = 0, carBest = -1;
+            double carDT = 2.0;
             // the particle's position IS the walk's running start point S_: between two cycles (and for a lane without an
             // active particle, always) S_ holds the position; a cycle's walk advances it from crossing to crossing and the
             // move at the cycle's end overwrites it (one register triple, not two)
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 if (cur < 0) cur = CPF_CELL_FROZEN;                                  // lost in the previous cycle: w = 0
                 busy = cur >= 0;
                 token = INT32_MIN; h = 0; j = 0;
+                if (bigCells) second = false;
                 if (!HIT_IN_REGS && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
                 zUnclear = false;
                 if (STATS && busy) ++st.steps;
@@ -350,14 +358,16 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 const unsigned long long busyMask = ballot64(busy);
                 // the lane's parked end point, requested before the lookup: its LDS round trip hides behind it (1 %)
                 const D3 Epre = {sE[0][lane], sE[1][lane], sE[2][lane]};
+                // what the lane looks up: its cell -- or, between the two halves of a visit of a two-record cell, the second record
+                const int lk = (bigCells && second) ? key2 : cur;
                 int myslot = -1;
                 unsigned used = 0;
                 unsigned long long missLanes = busyMask;
                 if (LOOKUP_FIXED) {
                     // (one cell for the whole wave -- nine first rounds of ten on a mesh with hundreds of particles per cell
                     // -- needs one compare against the tag vector, not six against the cells)
-                    const int cell0 = __builtin_amdgcn_readlane(cur, __ffsll((long long)busyMask) - 1);
-                    const unsigned long long in0 = __builtin_amdgcn_uicmp((unsigned)cur, (unsigned)cell0, 32 /* eq */) & busyMask;
+                    const int cell0 = __builtin_amdgcn_readlane(lk, __ffsll((long long)busyMask) - 1);
+                    const unsigned long long in0 = __builtin_amdgcn_uicmp((unsigned)lk, (unsigned)cell0, 32 /* eq */) & busyMask;
                     if (in0 == busyMask) {
                         const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)cell0, 32 /* eq */) & ALL;
                         if (hitTag != 0ull) {
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
                             const int tk = __builtin_amdgcn_readlane(tagv, k);
-                            const unsigned long long eqK = __builtin_amdgcn_uicmp((unsigned)cur, (unsigned)tk, 32 /* eq */);
+                            const unsigned long long eqK = __builtin_amdgcn_uicmp((unsigned)lk, (unsigned)tk, 32 /* eq */);
                             const unsigned long long inK = eqK & busyMask;
                             // (one select per tag on the compare's own mask; left alone, hipcc issues a second, inverted
                             // compare per tag to get the constant into the operand slot it prefers)
@@ -383,8 +393,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     missLanes = 0ull;
                     while (todo != 0ull) {
                         const int leader = __ffsll((long long)todo) - 1;
-                        const int ck = __builtin_amdgcn_readlane(cur, leader);
-                        const bool mine = cur == ck;
+                        const int ck = __builtin_amdgcn_readlane(lk, leader);
+                        const bool mine = lk == ck;
                         const unsigned long long same = ballot64(mine) & busyMask;
                         const unsigned long long hitTag = __builtin_amdgcn_uicmp((unsigned)tagv, (unsigned)ck, 32 /* eq */);
                         if (hitTag != 0ull) {
@@ -404,14 +414,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #define CPF_JOB(J)                                                                                          \
                     if (missLanes != 0ull && used != ALL) {                                                 \
                         const int leader = __ffsll((long long)missLanes) - 1;                               \
-                        const int ck = __builtin_amdgcn_readlane(cur, leader);                              \
+                        const int ck = __builtin_amdgcn_readlane(lk, leader);                               \
                         const unsigned cand = ~used & ALL;                                                  \
                         const unsigned hi = cand & (ALL << fifo) & ALL;                                     \
                         const int victim = __ffs((int)(hi ? hi : cand)) - 1;                                \
                         fifo = (unsigned)(victim + 1) == (unsigned)NS ? 0u : (unsigned)(victim + 1);          \
                         used |= 1u << victim;                                                               \
                         if (lane == victim) tagv = ck;                                                      \
-                        const bool mine = cur == ck;                                                        \
+                        const bool mine = lk == ck;                                                         \
                         if (mine) myslot = victim;                                                          \
                         missLanes &= ~ballot64(mine);                                                       \
                         if (ul < 16u)                                                                       \
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane;                             // (assigned on every path that reads it: wherever a boundary face is met)
-                    const bool needAdvect = token == INT32_MIN;
+                    const bool needAdvect = token == INT32_MIN && !(bigCells && second);      // (second half of a first visit: advected in the first)
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
                     if (myslot >= 0) {
@@ -493,15 +503,36 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // (mixed meshes) the slot may hold the HEADER record of a cell with more than six slots: that lane
                         // walks the cell's CSR slots, per lane from global memory -- same test, same order
                         int bigS0 = 0, bigNf = 0;
-                        bool bigCell = false;
+                        bool bigCell = false, twoRec = false;
                         if (bigCells) {
                             const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
+                            const int2 cont = reinterpret_cast<const int2*>(rec + 7)[3];
                             bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
+                            twoRec = !second && cont.x == kTwoRecMark;       // (a second record never carries the mark)
+                            if (twoRec) key2 = cont.y;
                         }
                         bool again;
                         do {
                             again = false;
-                            if (bigCells && bigCell) {
+                            if (bigCells && (twoRec || second)) {
+                                // a cell with 7 ... 12 slots: this round tests one of its two records, both from LDS (cpf_walk.h)
+                                const D3 P0 = S_;
+                                const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+                                double dTm = second ? carDT : 2.0;
+                                int nx = second ? carNext : cur, bs = second ? carBest : -1;
+                                if (second) trace_lds6_half<!BROWNIAN, mixed, 6>(P0, Pd, rec, token, dTm, nx, bs);
+                                else trace_lds6_half<!BROWNIAN, mixed, 0>(P0, Pd, rec, token, dTm, nx, bs);
+                                if (twoRec) {                                  // first half: nothing happens to the particle yet
+                                    carDT = dTm; carNext = nx; carBest = bs;
+                                    second = true;
+                                    next = kSitOut;
+                                } else {                                       // second half: the visit's outcome
+                                    second = false;
+                                    if (bs >= 0) { S_ = axpy(dTm, Pd, P0); outSlot = bs; }
+                                    next = nx;
+                                    if (STATS) ++st.hops;
+                                }
+                            } else if (bigCells && bigCell) {
                                 next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
                                 if (STATS) ++st.hops;
                             } else {
@@ -512,12 +543,19 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                                                 : trace_lds6<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
                             if (STATS) ++st.hops;
                             }
-                            if (REFLECT && next < 0) {
+                            if (REFLECT && next < 0 && !(mixed && is_group(next))) {       // (is_group: face-group codes and kSitOut)
                                 // The wall's plane is read HERE, where the record's address space is known (one expression
                                 // choosing between the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0).
                                 if (bigCells && bigCell) {
                                     wallPlane = m.planes[bigS0 + outSlot];
                                     asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));   // arrives HERE
+                                } else if (bigCells && lk != cur) {
+                                    // concluded on a second record: slots 6..11 are in this slot, slots 0..5 only in global memory now
+                                    if (outSlot >= 6) wallPlane = rec[outSlot - 6];
+                                    else {
+                                        wallPlane = m.planes[m.cellOff[cur] + outSlot];
+                                        asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
+                                    }
                                 } else wallPlane = rec[outSlot];
                                 // E comes from its parking slot again -- it is there, from this round's advect or an earlier
                                 // round -- so that it need not stay in registers across the face tests
@@ -550,9 +588,17 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             int gS0 = 0;
                             bool gBig = false;
                             if (LOOKUP_FIXED && bigCells) {
+                                // header cells and two-record cells alike walk their CSR slots here (a lane between the two halves
+                                // of a visit starts the visit over: same tests, same result)
                                 const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
-                                gBig = hdr.x == kBigCellMark; gS0 = hdr.y;
-                                if (gBig) { next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, hdr.z, token, outSlot); rec = m.planes + gS0; }
+                                const int2 cont = reinterpret_cast<const int2*>(rec + 7)[3];
+                                gBig = hdr.x == kBigCellMark || cont.x == kTwoRecMark;
+                                if (gBig) {
+                                    gS0 = m.cellOff[cur];
+                                    next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, m.cellOff[cur + 1] - gS0, token, outSlot);
+                                    rec = m.planes + gS0;
+                                    second = false;
+                                }
                             }
                             if (!gBig)
                             next = trace_fixed<6, false, mixed, kGatherAhead>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);

@@ -276,6 +276,35 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     return next;
 }
 
+// HALF a visit of a two-record cell (7 ... 12 slots, see "cell records" below): the six face tests of ONE record -- slots
+// BASE .. BASE + 5 of the cell -- continuing from (dTmin, next, best) and leaving the exit point to the caller, which
+// concludes after the second record.  Same tests, same order, same strict "<" as one pass over the twelve slots.
+template <bool ZERO_SKIP, bool GROUPS, int BASE>
+__device__ __forceinline__ void trace_lds6_half(const D3& P0, const D3& Pd, const double4* rec, int token, double& dTmin, int& next, int& best) {
+    const int2* nb = reinterpret_cast<const int2*>(rec + 7);
+    {
+        double4 p0 = rec[0], p1 = rec[1];
+        const int2 b = nb[0];
+        CPF_PIN_W(p0, p1)
+        face_test<ZERO_SKIP, GROUPS>(p0, b.x, P0, Pd, token, BASE + 0, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p1, b.y, P0, Pd, token, BASE + 1, dTmin, next, best);
+    }
+    {
+        double4 p2 = rec[2], p3 = rec[3];
+        const int2 b = nb[1];
+        CPF_PIN_W(p2, p3)
+        face_test<ZERO_SKIP, GROUPS>(p2, b.x, P0, Pd, token, BASE + 2, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p3, b.y, P0, Pd, token, BASE + 3, dTmin, next, best);
+    }
+    {
+        double4 p4 = rec[4], p5 = rec[5];
+        const int2 b = nb[2];
+        CPF_PIN_W(p4, p5)
+        face_test<ZERO_SKIP, GROUPS>(p4, b.x, P0, Pd, token, BASE + 4, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p5, b.y, P0, Pd, token, BASE + 5, dTmin, next, best);
+    }
+}
+
 // The same six face tests, two faces per wave-uniform decision: both denominators and both plane distances are computed
 // up front (four independent FMA chains instead of two short ones between branches), then ONE test decides whether either
 // face has a candidate lane.  No zero-denominator skip: a lane with den == 0 is a candidate only with fd >= 0, and is then
@@ -328,8 +357,15 @@ __device__ __forceinline__ int trace_lds6_paired(D3& S, const D3& E, int cur, co
 //     kBigCellMark, word 1 = its first CSR slot, word 2 = its face count, null planes, U as usual.  A lane in such a
 //     cell walks the CSR tables (planes / nbr in global memory) with trace_csr -- same arithmetic, same slot order.
 // The reference cannot run such meshes at all (src/initCuda.H:64: tetsPerCell = 12).
+//   * a cell with 7 ... 12 slots (true polyhedra: a pentagonal prism has seven planes, a polyDualMesh cell a dozen) has TWO
+//     records: the first holds slots 0..5 and U, spare word 6 = kTwoRecMark, spare word 7 = the index of the second one,
+//     which lies behind the nCells first records and holds slots 6..11 (null-padded).  A lane in such a cell tests the
+//     first record in one round and the second in the next, carrying (dTmin, next, best) across -- the same twelve tests
+//     in the same order with the same strict "<", so bit-identical to the walk over the CSR slots -- and both stay LDS
+//     tests; a cell with more than 12 slots keeps the header record.
 constexpr int kNullNbr = INT32_MIN + 5;
 constexpr int kBigCellMark = INT32_MIN + 6;
+constexpr int kTwoRecMark = INT32_MIN + 9;
 
 // trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0.  A group code may come
 // back as `next`: the caller resolves it (resolve_group), as after the six-slot tests.

@@ -180,8 +180,17 @@ class ShardedCloud:
         self.send_capacity = max(1024, int(self.capacity * send_fraction))
         self.sendbuf = torch.empty(self.send_capacity * L.HANDOFF_DOUBLES, **f64)
         self.recvbuf = torch.empty(self.send_capacity * L.HANDOFF_DOUBLES, **f64)
-        self.counts_dev = torch.zeros(16, dtype=torch.int64, device=device)
-        self.nstay_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        # per-destination leaver counts (the split kernels write up to kMaxRanks = 16 of them) and nStay sit in ONE device
+        # tensor, so that a hand-off's bookkeeping is one all-gather into one table and ONE copy into one pinned host
+        # buffer: [world x (16 + 1)] counts | nStay rows, then this rank's cell_lo (world + 1)
+        if world > 16:
+            raise ValueError("ShardedCloud: at most 16 ranks (the split kernels' count vector)")
+        self.meta_dev = torch.zeros(17, dtype=torch.int64, device=device)
+        self.counts_dev = self.meta_dev[:16]
+        self.nstay_dev = self.meta_dev[16:17]
+        self._table_dev = torch.zeros(world * 17 + world + 1, dtype=torch.int64, device=device)
+        self._table_host = torch.zeros(world * 17 + world + 1, dtype=torch.int64,
+                                       pin_memory=(device.type == "cuda"))
         # overlapped hand-off: after the split the step loop runs on for ``overlap_steps`` cycles while counts and
         # payload travel on a side stream; the arrivals then catch up on the cycles they missed (see step())
         self.overlap_steps = 0
@@ -204,6 +213,8 @@ class ShardedCloud:
         self.rebalances = 0
         self.grown = 0               # times the arrays had to be enlarged for arrivals
         self.handoff_host_ms = 0.0   # host wall time spent in the re-cut / split / exchange calls (incl. their one sync)
+        self._host_work_ms = 0.5     # running mean of the host's own work per hand-off, without the wait (see _overlap)
+        self.handoff_wait_ms = 0.0   # ... of which: blocked in that one sync (the device catching up with the queued steps + the counts' all-gather)
         self.profile_comm = False    # keep timing-enabled (start, end) device events around every hand-off's collectives
         self._comm_events = []       # ... here (bench.py reads them); off: one plain event per hand-off, nothing kept
         self.send_grown = 0          # times the send buffer had to be enlarged and the split repeated (see _finish_exchange)
@@ -247,7 +258,7 @@ class ShardedCloud:
         self._step_args = (dt, D, flags)
         dist_on = self.world > 1 or self.force_collectives
         for _ in range(n_cycles):
-            if self._pending is not None and self.step_index - self._pending["step"] >= self.overlap_steps:
+            if self._pending is not None and self.step_index - self._pending["step"] >= self._overlap():
                 self._finish_exchange()
             self.ops.step(self, dt, D, self.step_index, 1, flags)
             self.step_index += 1
@@ -267,6 +278,20 @@ class ShardedCloud:
                     self._begin_exchange()
         if self.overlap_steps == 0:
             self._finish_exchange()
+
+    def _overlap(self) -> int:
+        """Steps the loop runs on between a split and its exchange.  ``overlap_steps >= 0``: that many.  ``overlap_steps < 0``
+        (auto): enough queued steps to cover the host's own work per hand-off -- everything it does after the one wait:
+        reading the table, enqueueing the all-to-all, the unpack, the catch-up launch -- measured as a running mean, against
+        this rank's step time (measured when the balancer times the launches, else the nominal rate): ceil(host / step) + 1,
+        at least 2, at most half the hand-off interval.  Ranks may choose differently: every rank issues the same sequence
+        of collectives whatever its depth, and the catch-up replays what each rank itself missed."""
+        if self.overlap_steps >= 0:
+            return self.overlap_steps
+        step_ms = (self.cost_per_particle or 1.0) * COST_UNIT_MS * max(self.n, 1)
+        interval = self.rebalance_interval or self.exchange_interval or 16
+        want = int(np.ceil(self._host_work_ms / max(step_ms, 1e-3))) + 1
+        return int(min(max(want, 2), max(1, interval // 2)))
 
     def _grow(self, needed: int, n_keep: int):
         """More arrivals than slack: move the shard into larger arrays (HBM is plentiful; on the compute stream,
@@ -324,6 +349,7 @@ class ShardedCloud:
         if p is None:
             return
         t_host = time.perf_counter()
+        wait0 = self.handoff_wait_ms
         self._pending = None
         W = self.world
         D = L.HANDOFF_DOUBLES
@@ -335,33 +361,51 @@ class ShardedCloud:
             if cuda:
                 self._side.wait_event(p["event"])
                 ev0 = torch.cuda.Event(enable_timing=self.profile_comm); ev0.record(self._side)
+            attempts = 0
             while True:
-                meta = torch.cat([self.counts_dev[:W], self.nstay_dev])
-                rows = [torch.empty_like(meta) for _ in range(W)]
-                self.comm.all_gather(rows, meta, group=self.group)
-                host = torch.cat(rows + [self.cell_lo_dev.to(torch.int64)]).cpu().numpy()
-                table = host[: W * (W + 1)].reshape(W, W + 1)
-                over = [r for r in range(W) if table[r, W] < 0]
+                # ONE all-gather into the device table, the rank's cuts behind it, ONE copy into the pinned host buffer
+                gathered = self._table_dev[: W * 17]
+                if hasattr(self.comm, "all_gather_into_tensor"):
+                    self.comm.all_gather_into_tensor(gathered, self.meta_dev, group=self.group)
+                else:
+                    self.comm.all_gather(list(gathered.view(W, 17).unbind(0)), self.meta_dev, group=self.group)
+                self._table_dev[W * 17:].copy_(self.cell_lo_dev)
+                self._table_host.copy_(self._table_dev, non_blocking=True)
+                if cuda:
+                    got = torch.cuda.Event(); got.record(self._side)
+                    t_wait = time.perf_counter()
+                    got.synchronize()                                    # the hand-off's one host wait (side stream only)
+                    self.handoff_wait_ms += (time.perf_counter() - t_wait) * 1e3
+                host = self._table_host.numpy()
+                table = host[: W * 17].reshape(W, 17)
+                over = [r for r in range(W) if table[r, 16] < 0]
                 if not over:
                     break
-                if repacked & set(over):
-                    raise RuntimeError("hand-off: rank(s) %s still overflow after their send buffer was enlarged"
-                                       % sorted(repacked & set(over)))     # same table, same exception on every rank
+                attempts += 1
+                if attempts > 8:
+                    raise RuntimeError("hand-off: rank(s) %s still overflow after %d enlargements of their send buffers"
+                                       % (over, attempts - 1))             # same table, same exception on every rank
                 if self.rank in over:
+                    # The repeated split runs at the CURRENT step: the leavers have kept accumulating since the aborted one
+                    # (this rank moved nothing in between), so size for that -- and if it still does not fit, the loop
+                    # simply grows again: every rank sees the same table and takes the same branch.
                     need = int(table[self.rank, :W].sum())
-                    self.send_capacity = need + need // 8 + 1024
-                    self.sendbuf = torch.empty(self.send_capacity * D, dtype=torch.float64, device=self.device)
+                    missed = max(0, self.step_index - p["step"])
+                    grow = need * (1 + missed) if attempts == 1 else max(need, self.send_capacity) * 2
+                    self.send_capacity = min(max(grow + grow // 8 + 1024, self.send_capacity), self.capacity)
+                    with torch.cuda.stream(compute) if cuda else contextlib.nullcontext():
+                        self.sendbuf = torch.empty(self.send_capacity * D, dtype=torch.float64, device=self.device)
                     self.send_grown += 1
                     self.ops.pack(self)                                  # compute stream: after the steps queued so far
                     if cuda:
-                        self.sendbuf.record_stream(self._side)
+                        self.sendbuf.record_stream(self._side)           # allocated on the compute stream, read by the side stream
                         ev = torch.cuda.Event(); ev.record(compute)
                         self._side.wait_event(ev)
                 repacked |= set(over)
-            self.cell_lo = host[W * (W + 1):].astype(np.int32)
+            self.cell_lo = host[W * 17:].astype(np.int32)
             send_counts = [int(v) for v in table[self.rank, :W]]
             recv_counts = [int(v) for v in table[:, self.rank]]
-            n_stay = int(table[self.rank, W])
+            n_stay = int(table[self.rank, 16])
             n_send, n_recv = sum(send_counts), sum(recv_counts)
             assert n_send <= self.send_capacity
             if n_recv * D > self.recvbuf.numel():
@@ -408,7 +452,9 @@ class ShardedCloud:
         if self._sort_due:
             self._sort_due = False
             self.sort()
-        self.handoff_host_ms += (time.perf_counter() - t_host) * 1e3
+        total = (time.perf_counter() - t_host) * 1e3
+        self.handoff_host_ms += total
+        self._host_work_ms = 0.5 * self._host_work_ms + 0.5 * max(0.0, total - (self.handoff_wait_ms - wait0))
 
     def rebalance(self, n_cells: Optional[int] = None):
         """Re-cut the ranges (see ``_recut``) and hand particles to their new owners, synchronously."""

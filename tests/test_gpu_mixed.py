@@ -3,8 +3,9 @@
 The reference cannot run them at all (``src/initCuda.H:64``: ``tetsPerCell = 12``); the bar is this repo's own: the HIP
 path is bit-identical to the CPU statement ``oracle/cellwalk.c`` on them -- mesh tables (slots = distinct planes, face
 groups for the coplanar pieces of a split face), cells, positions, visit and reflection counters -- whichever kernel runs:
-the streaming kernel with mixed cell records (padded records for cells with fewer than six slots, header records + CSR walk
-for cells with more, face groups resolved at the exit point), or the generic CSR walk.
+the streaming kernel with mixed cell records (padded records for cells with fewer than six slots, two records for cells with
+seven to twelve -- two rounds per visit, both LDS tests --, header records + CSR walk beyond that, face groups resolved at the
+exit point), or the generic CSR walk.
 """
 import numpy as np
 import pytest
@@ -73,7 +74,7 @@ def _kernel_for(opts):
 def _kernel_for_big(opts):
     if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
         return "cpf::step_kernel<0,"
-    return ", 2>"                                   # ... 2>: header records of cells with more than six slots as well
+    return ", 2>"                                   # ... 2>: two-record cells (7..12 slots) and header records (more) as well
 
 
 @pytest.mark.parametrize("seed", [1, 2])
@@ -128,10 +129,10 @@ def test_refined_pitzdaily_1e6(oracle_libs, gpu_ctx_factory, pitz):
 
 
 @pytest.mark.parametrize("every", [4, 5])
-def test_pentagonal_prisms_use_header_records(every, oracle_libs, gpu_ctx_factory):
+def test_pentagonal_prisms_are_two_record_cells(every, oracle_libs, gpu_ctx_factory):
     """Cells with SEVEN distinct planes (pentagonal prisms: squares of an extruded grid with a corner cut off) among
-    triangular prisms (five: padded records), hexes, and hexes with a hanging node (a face group of two pieces): the
-    streaming kernel walks the seven-slot cells from their header record over the CSR tables."""
+    triangular prisms (five: padded records), hexes, and hexes with a hanging node (a face group of two pieces): a lane in a
+    seven-slot cell tests the cell's first record in one round and its second (slot 6 + five null planes) in the next."""
     from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
     mesh, kinds = cut_corner_box(11, 8, 3, every=every)
     assert min(kinds.values()) > 0
@@ -146,17 +147,49 @@ def test_pentagonal_prisms_use_header_records(every, oracle_libs, gpu_ctx_factor
     assert (c >= 0).all() and (slots[c] == 7).sum() > 1000 and (slots[c] == 5).sum() > 300
 
 
-def test_mostly_polyhedral_mesh_keeps_the_generic_walk(oracle_libs, gpu_ctx_factory):
+def test_mostly_polyhedral_mesh_keeps_the_streaming_kernel(oracle_libs, gpu_ctx_factory):
     """EVERY square of the grid cut: half of the cells are pentagonal prisms with seven (and, with their own hanging nodes,
-    face-grouped) slots -- more than a quarter of the cells have more than six slots, so no records are built and the
-    generic CSR walk runs."""
+    face-grouped) slots.  Round 3 sent such a mesh to the generic CSR walk (more than a quarter of the cells had header
+    records); with two records per such cell every lane stays on the LDS face test."""
     from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
     mesh, kinds = cut_corner_box(7, 5, 2, every=1)
     assert kinds["pentagons"] == 35 and kinds["triangles"] == 35
     rng = np.random.default_rng(3)
     U = rng.normal(size=(mesh.n_cells, 3)) * 0.8
     xyz = rng.uniform([0, 0, 0], [7, 5, 2], size=(20000, 3))
-    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict()], lambda o: "cpf::step_kernel<0,")
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict(), dict(step_variant=0)], _kernel_for_big)
+
+
+@pytest.mark.parametrize("cuts,want_slots", [(1, 10), (2, 14)])
+def test_octagonal_and_dodecagonal_prisms(cuts, want_slots, oracle_libs, gpu_ctx_factory):
+    """Squares with all four corners chamfered (cases/polygons.py, chamfered_box): octagonal prisms have TEN distinct planes
+    -- two records, four real planes in the second --, dodecagonal ones FOURTEEN: beyond two records, so a header record and
+    the walk over the CSR slots.  Around them triangular prisms (padded records) and squares whose shared edge carries two
+    hanging nodes (face groups of three pieces).  Unsorted as well: then most lanes of a tile are without a record slot and
+    the round walks by per-lane gathers (two-record cells take their CSR slots there)."""
+    from cudaparticlesfoam_amd.cases.polygons import chamfered_box
+    mesh, kinds = chamfered_box(12, 9, 3, cuts)
+    assert kinds["polygons"] == 12 and min(kinds.values()) > 0
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    slots = np.diff(t.cell_off)
+    assert set(slots) == {5, 6, want_slots} and (slots == want_slots).sum() == 36
+    assert 3 in set(np.diff(t.group_off))
+    rng = np.random.default_rng(70 + cuts)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 1.2
+    xyz = rng.uniform([0, 0, 0], [12, 9, 3], size=(60000, 3))
+    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for_big)
+    assert (c >= 0).all() and (slots[c] == want_slots).sum() > 3000
+    # the same cloud stepped WITHOUT the sort: gather rounds
+    x, y, z, cc = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t)
+    cw.step(x, y, z, cc, 0.2, 10, t, U, nthreads=cw.max_threads)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
+    ctx.locate_initial()
+    ctx.step(0.2, 0.0, 10)
+    assert ", 2>" in ctx.step_kernel_name(0.0, 0)
+    xyzw, cell = ctx.get_particles()
+    assert np.array_equal(cell, cc) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
 
 
 def test_glued_hexes_are_six_slot_cells(oracle_libs, gpu_ctx_factory):
@@ -216,20 +249,24 @@ def test_every_lane_of_a_tile_reflects_hit_pool_overflows(oracle_libs, gpu_ctx_f
             assert after["lost"] - before["lost"] == int(stats[2])
 
 
-@pytest.mark.parametrize("which", ["refined_box", "cut_corners"])
+@pytest.mark.parametrize("which", ["refined_box", "cut_corners", "octagons"])
 def test_diffusion_on_a_mixed_mesh_loses_nobody(which, oracle_libs, gpu_ctx_factory):
     """The Brownian kick on the refined box (LOOKUP = 3 with the kick: face groups, hit points in the per-wave pool) and
-    on the cut-corner grid (LOOKUP = 2: header records as well).  Parity with the CPU statement is statistical there, so
+    on the cut-corner grid and the chamfered grid (LOOKUP = 2: two-record cells as well).  Parity with the CPU statement is statistical there, so
     the check is the domain's own -- every boundary reflects, so after 60 kicked cycles nobody is lost and every particle
     lies inside the cell it claims (all plane distances <= 0), many-faced cells included."""
     if which == "refined_box":
         from cudaparticlesfoam_amd.cases import refined_box
         mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
         hi, want = [8, 6, 5], ", 5>"                                  # 360 particles per cell: the loop lookup
-    else:
+    elif which == "cut_corners":
         from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
         mesh, _ = cut_corner_box(11, 8, 3, every=4)
         hi, want = [11, 8, 3], ", 2>"
+    else:
+        from cudaparticlesfoam_amd.cases.polygons import chamfered_box
+        mesh, _ = chamfered_box(12, 9, 3, 1)                          # ten-slot cells: both records hold real planes
+        hi, want = [12, 9, 3], ", 2>"
     cw = oracle_libs.CellWalk()
     t = cw.build(mesh)
     rng = np.random.default_rng(23)

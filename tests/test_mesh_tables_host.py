@@ -91,3 +91,19 @@ def test_one_cell_thick_mesh_with_slanted_side_faces_is_not_z_thin(pitz):
     sheared = block_mesh(v, [dict(hex=range(8), n=(6, 5, 1), simple=(1, 1, 1))])
     f = mesh_flags_host(sheared)
     assert f["all_hex"] == 1 and f["z_layered"] == 1 and f["z_thin"] == 0
+
+
+@pytest.mark.parametrize("cuts,want", [(1, 10), (2, 14)])
+def test_chamfered_grid_has_ten_and_fourteen_slot_cells(cuts, want, oracle_libs):
+    """Octagonal prisms: ten distinct planes (two cell records in the streaming kernel); dodecagonal prisms: fourteen (header
+    record).  Their edge neighbours carry two hanging nodes on the shared edge: a face group of three coplanar pieces."""
+    from cudaparticlesfoam_amd.api import mesh_flags_host
+    from cudaparticlesfoam_amd.cases.polygons import chamfered_box
+    mesh, kinds = chamfered_box(9, 6, 2, cuts)
+    t = _same(mesh, oracle_libs)
+    slots = np.diff(t.cell_off)
+    assert set(slots) == {5, 6, want} and (slots == want).sum() == 2 * kinds["polygons"]
+    assert set(np.diff(t.group_off)) == {3} and t.n_groups == 2 * 4 * kinds["polygons"]
+    assert mesh_flags_host(mesh)["mixed"] == 2
+    _, vol = mesh.cell_centres_volumes()
+    assert abs(vol.sum() - 9 * 6 * 2) < 1e-9 and vol.min() > 0

@@ -114,6 +114,7 @@ def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_lib
 
 @pytest.mark.parametrize("world,interval,rebalance,overlap", [(2, 1, 0, 0), (2, 4, 0, 0), (3, 1, 0, 0), (2, 4, 10, 0),
                                                              (3, 0, 5, 0), (2, 0, 5, 3), (3, 4, 0, 4), (2, 0, 6, 10),
+                                                             (2, 0, 6, -1),      # overlap depth derived per rank (parallel.py, _overlap)
                                                              (8, 0, 15, 4)])     # eight ranks, overlapped hand-offs like the bench (the run is 30 steps: 15 divides it)
 def test_sharded_equals_single_process(world, interval, rebalance, overlap, tmp_path, oracle_libs):
     """overlap > 0: the step loop keeps running for that many cycles after the split while counts and payload

@@ -1,0 +1,55 @@
+"""Developer tools (GPU box): the synthetic cases the tools share -- one place for mesh, field and cloud set-up.
+  pitz       pitzDaily 12 225 cells (x-slab numbering), uniform (10,0,0) or the analytic step flow
+  box3d      graded 64 x 64 x 60 box = 245 760 hex cells (records 63 MB: beyond L2), diagonal / swirl fields; CPF_BOX_N=a,b,c resizes
+  tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5)"""
+import os
+
+import numpy as np
+
+BOX = ((0.0, 0.0, 0.0), (0.3, 0.05, 0.05))
+
+
+def make_case(name, ctx, torch, n, dev, field=None, seed=7):
+    """Sets mesh and field on ctx; returns (mesh, x, y, z, cell, fields) with the cloud located (not sorted);
+    fields = {label: U} of the case (the first one, or `field`, is the one set)."""
+    if name == "pitz":
+        import bench
+        from cudaparticlesfoam_amd.cases import pitzdaily as pz
+        from cudaparticlesfoam_amd.parallel import x_slab_renumbering
+        mesh0 = pz.pitzdaily_mesh(); c0, _ = mesh0.cell_centres_volumes()
+        mesh = mesh0.renumber_cells(x_slab_renumbering(c0)); cc, _ = mesh.cell_centres_volumes()
+        fields = {"uniform": pz.uniform_u(mesh), "analytic": pz.analytic_step_u(mesh, cc)}
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(fields[field or "uniform"])
+        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+        return mesh, x, y, z, c, fields
+    torch.manual_seed(seed)
+    if name == "tjunction":
+        from cudaparticlesfoam_amd.cases import tjunction as tj
+        mesh = tj.tjunction_mesh(); cc, _ = mesh.cell_centres_volumes()
+        fields = {"u0=3": tj.split_flow_u(mesh, cc, 0.5), "u0=5": tj.split_flow_u(mesh, cc, 0.5, u0=5.0)}
+        na = int(n * 80.0 / 248.0)                          # uniform over the T: the duct (80 cm^3) and the cross bar (168)
+        u = torch.rand((3, n), dtype=torch.float64, device=dev)
+        ar = torch.arange(n, device=dev)
+        x = torch.where(ar < na, u[0] * 0.2, 0.2 + u[0] * 0.02).contiguous()
+        y = torch.where(ar < na, -0.01 + u[1] * 0.02, -0.21 + u[1] * 0.42).contiguous()
+        z = (u[2] * 0.02).contiguous()
+        del u, ar
+    elif name == "box3d":
+        from cudaparticlesfoam_amd.cases import block_mesh
+        v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
+                      [0, 0.05, 0.05]], float)
+        nbox = tuple(int(k) for k in os.environ.get("CPF_BOX_N", "64,64,60").split(","))
+        mesh = block_mesh(v, [dict(hex=range(8), n=nbox, simple=(2.0, 1.0, 0.5))]); cc, _ = mesh.cell_centres_volumes()
+        fields = {"diagonal": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
+                  "swirl": np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1)}
+        x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
+        y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+        z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+    else:
+        raise ValueError(name)
+    ctx.set_mesh(mesh)
+    ctx.set_velocity(fields[field or next(iter(fields))])
+    c = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), n)
+    return mesh, x, y, z, c, fields

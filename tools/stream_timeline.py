@@ -81,6 +81,8 @@ def main():
         ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, 1e-4, args.D, 0, 1, 0)
     torch.cuda.synchronize()
     tl.zero_()
+    if args.census:
+        ctx.set_option("stream_debug", 4)        # the census' global atomics distort the timeline: only on request
     ctx.timing_enable(True)
     ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, 1e-4, args.D, 5, 1, 0)
     launches, ms = ctx.timing_read()
