@@ -123,3 +123,40 @@ def chamfered_box(nx: int, ny: int, nz: int, cuts_per_corner: int = 1, period: i
             kinds["squares_with_hanging_nodes" if len(loop) > 4 else "squares"] += 1
             loops.append(loop)
     return extrude_polygons(np.asarray(pts), loops, np.arange(nz + 1, dtype=np.float64)), kinds
+
+
+def diamond_box(nx: int, ny: int, nz: int, period: int = 6, cut: float = 0.3) -> Tuple[PolyMesh, Dict[str, int]]:
+    """A CONFORMAL mesh with a minority of true polyhedra and no hanging nodes (what a surface-snapped hex-dominant mesh
+    looks like away from its refinement interfaces): an nx x ny grid of unit squares in which, at every interior grid vertex
+    with i % period == 0 and j % period == 0, the four squares around the vertex lose that corner and a diamond (a square on
+    its tip) fills the hole.  The four squares become pentagonal prisms (SEVEN planes: two-record cells), the diamond is a
+    six-plane cell with slanted side faces; period 6: 11 % of the cells have seven planes, period 1: every square loses all
+    four corners (octagonal prisms, TEN planes, half of the cells).  Extruded nz layers in z."""
+    assert period >= 1 and 0.0 < cut < 0.5
+    vid = lambda i, j: j * (nx + 1) + i                                    # noqa: E731
+    pts: List[Tuple[float, float]] = [(float(i), float(j)) for j in range(ny + 1) for i in range(nx + 1)]
+    chosen = {(i, j) for j in range(1, ny) for i in range(1, nx) if i % period == 0 and j % period == 0}
+    arms: Dict[Tuple[int, int], Tuple[int, int, int, int]] = {}            # vertex -> its diamond's points towards +x, +y, -x, -y
+    for i, j in sorted(chosen):
+        e = []
+        for dx, dy in ((cut, 0.0), (0.0, cut), (-cut, 0.0), (0.0, -cut)):
+            pts.append((i + dx, j + dy)); e.append(len(pts) - 1)
+        arms[(i, j)] = tuple(e)
+    loops: List[List[int]] = []
+    kinds = {"diamonds": 0, "polygons": 0, "squares": 0}
+    for (i, j), (px, py, mx, my) in sorted(arms.items()):
+        loops.append([px, py, mx, my]); kinds["diamonds"] += 1
+    for j in range(ny):
+        for i in range(nx):
+            loop: List[int] = []
+            # counter-clockwise: bottom-left, bottom-right, top-right, top-left corner; a chosen corner is replaced by the two
+            # diamond points on this square's edges (in traversal order)
+            for (ci, cj), (first, last) in (((i, j), (1, 0)), ((i + 1, j), (2, 1)), ((i + 1, j + 1), (3, 2)), ((i, j + 1), (0, 3))):
+                if (ci, cj) in arms:
+                    a = arms[(ci, cj)]
+                    loop += [a[first], a[last]]
+                else:
+                    loop.append(vid(ci, cj))
+            kinds["polygons" if len(loop) > 4 else "squares"] += 1
+            loops.append(loop)
+    return extrude_polygons(np.asarray(pts), loops, np.arange(nz + 1, dtype=np.float64)), kinds

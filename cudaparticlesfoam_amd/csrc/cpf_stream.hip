@@ -82,12 +82,15 @@ struct StreamKernArgs {
 static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
+#ifndef CPF_STREAM_WAVES_L2
+#define CPF_STREAM_WAVES_L2 6
+#endif
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
-    // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers and a spill at 6 waves, none at 5)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (LOOKUP == 2 ? 5 : (kMixed ? 6 : CPF_STREAM_WAVES))));
+    // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : CPF_STREAM_WAVES))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -115,7 +118,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //     and entries beyond the pool go to the wave's own 1.5 KB of global memory (sa.hitSpill).  (A pool of 10 for
     //     every instantiation, tried first, cost bench.py's window 3 %: there the cloud drifts into the outlet wall
     //     and whole tiles reflect, 54 of 64 lanes through the spill path.)
-    constexpr bool HIT_IN_REGS = !BROWNIAN && LOOKUP != 2;
+#ifndef CPF_STREAM_HIT_REGS_L2
+#define CPF_STREAM_HIT_REGS_L2 0
+#endif
+    constexpr bool HIT_IN_REGS = !BROWNIAN && (LOOKUP != 2 || CPF_STREAM_HIT_REGS_L2);
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
     static_assert(!(kInRound && (LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5)), "in-round reflection knows neither face groups nor two-record cells");
     constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5) ? 16 : CPF_STREAM_HIT_POOL);
@@ -261,9 +267,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             if (ul > plim || pc < 0) pc = CPF_CELL_FROZEN;
 
             int cur = pc;
-            // (meshes with two-record cells, LOOKUP 2) a lane between the two halves of a visit: `second` = the first record has
-            // been tested, the second one (record index key2) is what the lane looks up next; (carDT, carNext, carBest) carry over
-            bool second = false;
+            // (meshes with two-record cells, LOOKUP 2) a lane between the two halves of a visit -- key2 != 0: the first record has
+            // been tested, the second one (record index key2 >= nCells > 0) is what the lane looks up next -- carries
+            // (carDT, carNext, carBest) over
             int key2 = 0, carNext = 0, carBest = -1;
             double carDT = 2.0;
             // the particle's position IS the walk's running start point S_: between two cycles (and for a lane without an
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 if (cur < 0) cur = CPF_CELL_FROZEN;                                  // lost in the previous cycle: w = 0
                 busy = cur >= 0;
                 token = INT32_MIN; h = 0; j = 0;
-                if (bigCells) second = false;
+                if (bigCells) key2 = 0;
                 if (!HIT_IN_REGS && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
                 zUnclear = false;
                 if (STATS && busy) ++st.steps;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 // the lane's parked end point, requested before the lookup: its LDS round trip hides behind it (1 %)
                 const D3 Epre = {sE[0][lane], sE[1][lane], sE[2][lane]};
                 // what the lane looks up: its cell -- or, between the two halves of a visit of a two-record cell, the second record
-                const int lk = (bigCells && second) ? key2 : cur;
+                const int lk = (bigCells && key2 != 0) ? key2 : cur;
                 int myslot = -1;
                 unsigned used = 0;
                 unsigned long long missLanes = busyMask;
@@ -487,10 +493,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 if (busy) {
                     int next, outSlot = 0;
                     double4 wallPlane;                             // (assigned on every path that reads it: wherever a boundary face is met)
-                    const bool needAdvect = token == INT32_MIN && !(bigCells && second);      // (second half of a first visit: advected in the first)
+                    const bool needAdvect = token == INT32_MIN && !(bigCells && key2 != 0);      // (second half of a first visit: advected in the first)
                     D3 E = S_;
                     if (!needAdvect) E = Epre;
-                    if (myslot >= 0) {
+                    // (mixed meshes with big cells) the slot may hold the HEADER record of a cell with more than twelve slots: that
+                    // lane walks the cell's CSR slots per lane from global memory, in the gather branch below
+                    bool hdrCell = false;
+                    if (bigCells && myslot >= 0) hdrCell = *reinterpret_cast<const int*>(&slots[0][0] + myslot * kSlotStride + 7) == kBigCellMark;
+                    if (myslot >= 0 && !(bigCells && hdrCell)) {
                         const double4* rec = &slots[0][0] + myslot * kSlotStride;
                         if (needAdvect) E = advect(rec);
                         // ---- the visit, and -- in the same round -- the visits after a wall.  A wall hit never changes the
@@ -500,41 +510,35 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // it.  ONE instance of the face tests inside a per-lane loop: from its second trip on only the
                         // reflecting lanes are active and most faces drop out wave-uniformly.  Same arithmetic in the same
                         // order as a round per reflection: bit-identical.
-                        // (mixed meshes) the slot may hold the HEADER record of a cell with more than six slots: that lane
-                        // walks the cell's CSR slots, per lane from global memory -- same test, same order
-                        int bigS0 = 0, bigNf = 0;
-                        bool bigCell = false, twoRec = false;
+                        bool twoRec = false;
+                        int recB = 0;
+                        const bool second0 = key2 != 0;                         // which record of its cell this round tests
                         if (bigCells) {
-                            const int4 hdr = *reinterpret_cast<const int4*>(rec + 7);
                             const int2 cont = reinterpret_cast<const int2*>(rec + 7)[3];
-                            bigCell = hdr.x == kBigCellMark; bigS0 = hdr.y; bigNf = hdr.z;
-                            twoRec = !second && cont.x == kTwoRecMark;       // (a second record never carries the mark)
-                            if (twoRec) key2 = cont.y;
+                            twoRec = !second0 && cont.x == kTwoRecMark;      // (a second record never carries the mark)
+                            recB = cont.y;
                         }
                         bool again;
                         do {
                             again = false;
-                            if (bigCells && (twoRec || second)) {
-                                // a cell with 7 ... 12 slots: this round tests one of its two records, both from LDS (cpf_walk.h)
+                            if (bigCells) {
+                                // ONE record of the cell per round, from LDS: an ordinary cell's only one, or one of the two of a
+                                // cell with 7 ... 12 slots (cpf_walk.h)
                                 const D3 P0 = S_;
                                 const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
-                                double dTm = second ? carDT : 2.0;
-                                int nx = second ? carNext : cur, bs = second ? carBest : -1;
-                                if (second) trace_lds6_half<!BROWNIAN, mixed, 6>(P0, Pd, rec, token, dTm, nx, bs);
-                                else trace_lds6_half<!BROWNIAN, mixed, 0>(P0, Pd, rec, token, dTm, nx, bs);
-                                if (twoRec) {                                  // first half: nothing happens to the particle yet
+                                double dTm = second0 ? carDT : 2.0;
+                                int nx = second0 ? carNext : cur, bs = second0 ? carBest : -1;
+                                trace_lds6_record<!BROWNIAN, mixed>(P0, Pd, rec, token, second0 ? 6 : 0, dTm, nx, bs);
+                                if (twoRec) {                                  // first of two: nothing happens to the particle yet
                                     carDT = dTm; carNext = nx; carBest = bs;
-                                    second = true;
+                                    key2 = recB;
                                     next = kSitOut;
-                                } else {                                       // second half: the visit's outcome
-                                    second = false;
+                                } else {                                       // the cell's last record: the visit's outcome
+                                    key2 = 0;
                                     if (bs >= 0) { S_ = axpy(dTm, Pd, P0); outSlot = bs; }
                                     next = nx;
                                     if (STATS) ++st.hops;
                                 }
-                            } else if (bigCells && bigCell) {
-                                next = trace_csr(S_, E, cur, m.planes, m.nbr, bigS0, bigNf, token, outSlot);
-                                if (STATS) ++st.hops;
                             } else {
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
@@ -546,10 +550,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             if (REFLECT && next < 0 && !(mixed && is_group(next))) {       // (is_group: face-group codes and kSitOut)
                                 // The wall's plane is read HERE, where the record's address space is known (one expression
                                 // choosing between the LDS slot and the global record becomes a flat load: vmcnt + lgkmcnt 0).
-                                if (bigCells && bigCell) {
-                                    wallPlane = m.planes[bigS0 + outSlot];
-                                    asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));   // arrives HERE
-                                } else if (bigCells && lk != cur) {
+                                if (bigCells && lk != cur) {
                                     // concluded on a second record: slots 6..11 are in this slot, slots 0..5 only in global memory now
                                     if (outSlot >= 6) wallPlane = rec[outSlot - 6];
                                     else {
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // no slot: more distinct new cells in the wave than the round can place (a cloud that is not
                         // kept sorted).  Per-lane gathers keep such a wave moving.
                         next = kSitOut;
-                        if (gatherRound) {
+                        if (gatherRound || (bigCells && hdrCell)) {
                             const double4* rec = m.cellRec + 8 * (int64_t)cur;
                             if (needAdvect) E = advect(rec);
                             int gS0 = 0;
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                     gS0 = m.cellOff[cur];
                                     next = trace_csr(S_, E, cur, m.planes, m.nbr, gS0, m.cellOff[cur + 1] - gS0, token, outSlot);
                                     rec = m.planes + gS0;
-                                    second = false;
+                                    key2 = 0;
                                 }
                             }
                             if (!gBig)

@@ -276,32 +276,35 @@ __device__ __forceinline__ int trace_lds6(D3& S, const D3& E, int cur, const dou
     return next;
 }
 
-// HALF a visit of a two-record cell (7 ... 12 slots, see "cell records" below): the six face tests of ONE record -- slots
-// BASE .. BASE + 5 of the cell -- continuing from (dTmin, next, best) and leaving the exit point to the caller, which
-// concludes after the second record.  Same tests, same order, same strict "<" as one pass over the twelve slots.
-template <bool ZERO_SKIP, bool GROUPS, int BASE>
-__device__ __forceinline__ void trace_lds6_half(const D3& P0, const D3& Pd, const double4* rec, int token, double& dTmin, int& next, int& best) {
+// ONE RECORD of a visit on a mesh with two-record cells (7 ... 12 slots, see "cell records" below): the six face tests of the
+// record -- slots base .. base + 5 of the cell, base = 0 or 6 -- continuing from (dTmin, next, best) and leaving the exit
+// point to the caller, which concludes after the cell's last record.  Same tests, same order, same strict "<" as one pass
+// over the cell's slots.  (The LOOKUP 2 instantiation runs EVERY visit through this one instance -- an ordinary cell is a
+// first record that is also the last --: three inlined copies of the six tests cost the instantiation 25 % on a mesh without
+// a single big cell.)
+template <bool ZERO_SKIP, bool GROUPS>
+__device__ __forceinline__ void trace_lds6_record(const D3& P0, const D3& Pd, const double4* rec, int token, int base, double& dTmin, int& next, int& best) {
     const int2* nb = reinterpret_cast<const int2*>(rec + 7);
     {
         double4 p0 = rec[0], p1 = rec[1];
         const int2 b = nb[0];
         CPF_PIN_W(p0, p1)
-        face_test<ZERO_SKIP, GROUPS>(p0, b.x, P0, Pd, token, BASE + 0, dTmin, next, best);
-        face_test<ZERO_SKIP, GROUPS>(p1, b.y, P0, Pd, token, BASE + 1, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p0, b.x, P0, Pd, token, base + 0, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p1, b.y, P0, Pd, token, base + 1, dTmin, next, best);
     }
     {
         double4 p2 = rec[2], p3 = rec[3];
         const int2 b = nb[1];
         CPF_PIN_W(p2, p3)
-        face_test<ZERO_SKIP, GROUPS>(p2, b.x, P0, Pd, token, BASE + 2, dTmin, next, best);
-        face_test<ZERO_SKIP, GROUPS>(p3, b.y, P0, Pd, token, BASE + 3, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p2, b.x, P0, Pd, token, base + 2, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p3, b.y, P0, Pd, token, base + 3, dTmin, next, best);
     }
     {
         double4 p4 = rec[4], p5 = rec[5];
         const int2 b = nb[2];
         CPF_PIN_W(p4, p5)
-        face_test<ZERO_SKIP, GROUPS>(p4, b.x, P0, Pd, token, BASE + 4, dTmin, next, best);
-        face_test<ZERO_SKIP, GROUPS>(p5, b.y, P0, Pd, token, BASE + 5, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p4, b.x, P0, Pd, token, base + 4, dTmin, next, best);
+        face_test<ZERO_SKIP, GROUPS>(p5, b.y, P0, Pd, token, base + 5, dTmin, next, best);
     }
 }
 

@@ -160,6 +160,24 @@ def test_mostly_polyhedral_mesh_keeps_the_streaming_kernel(oracle_libs, gpu_ctx_
     _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 20, [dict(), dict(step_variant=0)], _kernel_for_big)
 
 
+@pytest.mark.parametrize("period", [3, 1])
+def test_conformal_polyhedra_without_face_groups(period, oracle_libs, gpu_ctx_factory):
+    """cases/polygons.py, diamond_box: pentagonal (period 3) and octagonal (period 1: the truncated square tiling, cells with 7, 8
+    and 10 planes at the rim and inside) prisms around diamonds with slanted side faces -- conformal, no hanging nodes: only
+    two-record cells and ordinary six-slot ones."""
+    from cudaparticlesfoam_amd.cases.polygons import diamond_box
+    mesh, kinds = diamond_box(12, 9, 3, period)
+    cw = oracle_libs.CellWalk()
+    t = cw.build(mesh)
+    slots = np.diff(t.cell_off)
+    assert t.n_groups == 0 and slots.max() == (7 if period == 3 else 10) and (slots > 6).sum() > 30
+    rng = np.random.default_rng(90 + period)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 1.2
+    xyz = rng.uniform([0, 0, 0], [12, 9, 3], size=(60000, 3))
+    c = _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.2, 25, [dict(), dict(step_variant=0)], _kernel_for_big)
+    assert (c >= 0).all() and (slots[c] > 6).sum() > 3000
+
+
 @pytest.mark.parametrize("cuts,want_slots", [(1, 10), (2, 14)])
 def test_octagonal_and_dodecagonal_prisms(cuts, want_slots, oracle_libs, gpu_ctx_factory):
     """Squares with all four corners chamfered (cases/polygons.py, chamfered_box): octagonal prisms have TEN distinct planes

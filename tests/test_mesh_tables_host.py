@@ -107,3 +107,15 @@ def test_chamfered_grid_has_ten_and_fourteen_slot_cells(cuts, want, oracle_libs)
     assert mesh_flags_host(mesh)["mixed"] == 2
     _, vol = mesh.cell_centres_volumes()
     assert abs(vol.sum() - 9 * 6 * 2) < 1e-9 and vol.min() > 0
+
+
+@pytest.mark.parametrize("period,slot_set", [(6, {6, 7}), (1, {6, 7, 8, 10})])
+def test_conformal_diamond_meshes_have_no_groups(period, slot_set, oracle_libs):
+    """cases/polygons.py, diamond_box: true polyhedra without hanging nodes (no face groups): pentagonal prisms around a
+    diamond (period 6), the truncated square tiling of octagonal prisms and diamonds (period 1)."""
+    from cudaparticlesfoam_amd.cases.polygons import diamond_box
+    mesh, kinds = diamond_box(12, 12, 2, period)
+    t = _same(mesh, oracle_libs)
+    assert t.n_groups == 0 and set(np.diff(t.cell_off)) == slot_set
+    _, vol = mesh.cell_centres_volumes()
+    assert abs(vol.sum() - 288.0) < 1e-9 and vol.min() > 0

@@ -1,12 +1,20 @@
 """Developer tools (GPU box): the synthetic cases the tools share -- one place for mesh, field and cloud set-up.
   pitz       pitzDaily 12 225 cells (x-slab numbering), uniform (10,0,0) or the analytic step flow
   box3d      graded 64 x 64 x 60 box = 245 760 hex cells (records 63 MB: beyond L2), diagonal / swirl fields; CPF_BOX_N=a,b,c resizes
-  tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5)"""
+  tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5)
+  octagons / pentagons / dodecagons / hexgrid   300 x 200 x 4 unit cells (cases/polygons.py): every ninth square an octagonal prism
+             (10 planes: two-record cells) / every square with a cut corner (half the cells 7 planes) / every ninth a dodecagonal
+             prism (14 planes: header records) / the all-hex box of about the same cell count; dt = 0.1 (POLY_DT)
+  diamonds6 / diamonds1 / hexgrid6   CONFORMAL polyhedra (no hanging nodes): a diamond at every 6th grid vertex (10.5 % of the cells
+             pentagonal prisms, 7 planes) / at every vertex (truncated square tiling: half the cells octagonal prisms, 10 planes)
+             / the all-hex box with diamonds6's cell count"""
 import os
 
 import numpy as np
 
 BOX = ((0.0, 0.0, 0.0), (0.3, 0.05, 0.05))
+POLY_DT = 0.1
+POLY_CASES = ("octagons", "pentagons", "dodecagons", "hexgrid", "diamonds6", "diamonds1", "hexgrid6")
 
 
 def make_case(name, ctx, torch, n, dev, field=None, seed=7):
@@ -22,6 +30,22 @@ def make_case(name, ctx, torch, n, dev, field=None, seed=7):
         ctx.set_mesh(mesh)
         ctx.set_velocity(fields[field or "uniform"])
         x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+        return mesh, x, y, z, c, fields
+    if name in POLY_CASES:
+        import bench
+        from cudaparticlesfoam_amd.cases import box_mesh
+        from cudaparticlesfoam_amd.cases.polygons import chamfered_box, cut_corner_box, diamond_box
+        lo3, hi3 = (0.0, 0.0, 0.0), (300.0, 200.0, 4.0)
+        mesh = {"octagons": lambda: chamfered_box(300, 200, 4, 1)[0], "pentagons": lambda: cut_corner_box(300, 200, 4, every=1)[0],
+                "dodecagons": lambda: chamfered_box(300, 200, 4, 2)[0],
+                "diamonds6": lambda: diamond_box(300, 200, 4, 6)[0], "diamonds1": lambda: diamond_box(300, 200, 4, 1)[0],
+                "hexgrid6": lambda: box_mesh(320, 193, 4, lower=lo3, upper=hi3),
+                "hexgrid": lambda: box_mesh(380, 228, 4, lower=lo3, upper=hi3)}[name]()
+        cc, _ = mesh.cell_centres_volumes()
+        fields = {"drift": np.stack([3.0 + 0 * cc[:, 0], 1.0 * np.sin(0.3 * cc[:, 0]), 0.3 * np.cos(0.2 * cc[:, 1])], 1)}
+        ctx.set_mesh(mesh)
+        ctx.set_velocity(fields["drift"])
+        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, (lo3, hi3), 1000, dev)
         return mesh, x, y, z, c, fields
     torch.manual_seed(seed)
     if name == "tjunction":

@@ -58,6 +58,15 @@ def main():
         p3, _ = cut_corner_box(300, 200, 4, every=1)
         d3, _ = chamfered_box(300, 200, 4, 2)
         hex3 = box_mesh(380, 228, 4, lower=lo3, upper=hi3)
+        from cudaparticlesfoam_amd.cases.polygons import diamond_box
+        c6, _ = diamond_box(300, 200, 4, 6)
+        c1, _ = diamond_box(300, 200, 4, 1)
+        hex2 = box_mesh(320, 193, 4, lower=lo3, upper=hi3)                                  # the cell count of the conformal 10 % mesh
+        cases += [("CONFORMAL 300x200x4 grid, a diamond at every 6th vertex: 10.5 % of the cells pentagonal prisms (7 planes), no face groups", c6, {}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
+                  ("same mesh, generic CSR walk", c6, {"mixed_records": 0}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
+                  ("all-hex box of that cell count (320 x 193 x 4)", hex2, {}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
+                  ("CONFORMAL truncated-square tiling: half the cells octagonal prisms (10 planes), half diamonds", c1, {}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
+                  ("same mesh, generic CSR walk", c1, {"mixed_records": 0}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1))]
         cases += [("300x200x4 grid, every 9th square an octagon (10 planes): two-record cells", o3, {}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
                   ("same mesh, generic CSR walk", o3, {"mixed_records": 0}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),
                   ("every square with a cut corner: half the cells pentagonal prisms (7 planes)", p3, {}, (lo3, hi3), (3.0, 1.0, 0.3, 0.1)),

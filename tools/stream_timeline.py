@@ -23,52 +23,20 @@ def main():
     ap.add_argument("--groups", action="store_true", help="also per-group (= per-CU) and per-XCD end times")
     ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh of tools/bench_3d.py, swirl field")
     ap.add_argument("--tjunction", action="store_true", help="the reference's TJunction tutorial mesh (248 000 cells), split flow u0 = 3")
+    ap.add_argument("--case", default=None, help="tools/_cases.py: pitz | box3d | tjunction | octagons | pentagons | dodecagons | hexgrid")
     ap.add_argument("--census", action="store_true", help="busy lanes per round index, sit-outs, rounds against the largest visit count of a tile")
     args = ap.parse_args()
     import torch
-    import bench
     from cudaparticlesfoam_amd.api import Context
-    from cudaparticlesfoam_amd.cases import pitzdaily as pz
-    from cudaparticlesfoam_amd.parallel import x_slab_renumbering
     dev = torch.device("cuda", 0)
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     n = int(args.particles)
-    if args.tjunction:
-        from cudaparticlesfoam_amd.cases import tjunction as tj
-        mesh = tj.tjunction_mesh()
-        cc, _ = mesh.cell_centres_volumes()
-        ctx.set_mesh(mesh)
-        ctx.set_velocity(tj.split_flow_u(mesh, cc, 0.5))
-        torch.manual_seed(7)
-        na = int(n * 80.0 / 248.0)
-        u = torch.rand((3, n), dtype=torch.float64, device=dev)
-        ar = torch.arange(n, device=dev)
-        x = torch.where(ar < na, u[0] * 0.2, 0.2 + u[0] * 0.02).contiguous()
-        y = torch.where(ar < na, -0.01 + u[1] * 0.02, -0.21 + u[1] * 0.42).contiguous()
-        z = (u[2] * 0.02).contiguous()
-        del u, ar
-        c = torch.empty(n, dtype=torch.int32, device=dev)
-        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), n)
-    elif args.mesh3d:
-        from cudaparticlesfoam_amd.cases import block_mesh
-        v = np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0.05, 0], [0, 0.05, 0], [0, 0, 0.05], [0.3, 0, 0.05], [0.3, 0.05, 0.05],
-                      [0, 0.05, 0.05]], float)
-        mesh = block_mesh(v, [dict(hex=range(8), n=(64, 64, 60), simple=(2.0, 1.0, 0.5))])
-        cc, _ = mesh.cell_centres_volumes()
-        ctx.set_mesh(mesh)
-        ctx.set_velocity(np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1))
-        torch.manual_seed(7)
-        x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
-        y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
-        z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
-        c = torch.empty(n, dtype=torch.int32, device=dev)
-        ctx.locate_initial_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), n)
-    else:
-        mesh0 = pz.pitzdaily_mesh(); c0, _ = mesh0.cell_centres_volumes()
-        mesh = mesh0.renumber_cells(x_slab_renumbering(c0))
-        ctx.set_mesh(mesh); ctx.set_velocity(pz.uniform_u(mesh))
-        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, pz.DOMAIN_BOX, 1000, dev)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _cases import POLY_CASES, POLY_DT, make_case
+    case = args.case or ("tjunction" if args.tjunction else ("box3d" if args.mesh3d else "pitz"))
+    mesh, x, y, z, c, fields = make_case(case, ctx, torch, n, dev, "swirl" if case == "box3d" else None)
+    dt = POLY_DT if case in POLY_CASES else 1e-4
     g = torch.arange(n, dtype=torch.int64, device=dev)
     ctx.set_option("stats", 0); ctx.set_option("step_variant", args.variant)
     for kv in args.opt:
@@ -78,13 +46,13 @@ def main():
     tl = torch.zeros(8 * 16384 + NCEN, dtype=torch.int64, device=dev)
     p = lambda t: t.data_ptr()   # noqa: E731
     for _ in range(args.pre_steps):
-        ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, 1e-4, args.D, 0, 1, 0)
+        ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, None, n, dt, args.D, 0, 1, 0)
     torch.cuda.synchronize()
     tl.zero_()
     if args.census:
         ctx.set_option("stream_debug", 4)        # the census' global atomics distort the timeline: only on request
     ctx.timing_enable(True)
-    ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, 1e-4, args.D, 5, 1, 0)
+    ctx.step_dev(p(x), p(y), p(z), p(c), p(g) if args.D > 0 else None, p(tl), n, dt, args.D, 5, 1, 0)
     launches, ms = ctx.timing_read()
     raw_all = tl.cpu().numpy()
     raw, cen = raw_all[:8 * 16384], raw_all[8 * 16384:].astype(np.float64)
