@@ -31,6 +31,8 @@ struct cpf_context {
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes; mixed meshes: cpf_walk.h "cell records")
+    unsigned long long* d_occupied = nullptr;   // [0] occupied cells, [1] live particles of the last sort (device) ...
+    unsigned long long* h_occupied = nullptr;   // ... and their pinned host copy (StreamState::occupiedHost)
     int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_binOff = nullptr;
@@ -226,6 +228,7 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     ctx->meshBytes += (size_t)nCells * (sizeof(double4) + 24);
     ctx->haveMesh = true;
     ctx->located = false;
+    if (ctx->h_occupied) ctx->h_occupied[0] = ctx->h_occupied[1] = 0;      // (what the last sort counted belonged to the old mesh)
     return CPF_OK;
 }
 
@@ -259,6 +262,9 @@ int cpf_create(int device, cpf_context** out) {
     e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_occupied, 16);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_occupied, 16, hipHostMallocDefault);
+    if (e == hipSuccess) { ctx->h_occupied[0] = ctx->h_occupied[1] = 0; ctx->streamState.occupiedHost = ctx->h_occupied; }
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->streamState.d_grab, cpf::kStreamGrabBytes);
     if (e == hipSuccess) e = hipMemset(ctx->streamState.d_grab, 0, cpf::kStreamGrabBytes);
     if (e == hipSuccess) {
@@ -290,6 +296,8 @@ int cpf_destroy(cpf_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     freeMesh(ctx); freeCloud(ctx);
     freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab); freeDev(ctx->streamState.d_hitSpill);
+    freeDev(ctx->d_occupied);
+    if (ctx->h_occupied) { (void)hipHostFree(ctx->h_occupied); ctx->h_occupied = nullptr; ctx->streamState.occupiedHost = nullptr; }
     freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);
@@ -612,7 +620,10 @@ int sortImpl(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, i
     int r = ensureScratch(ctx, cpf::sort_scratch_bytes(n, endBit));
     if (r) return r;
     CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, vel3, n, endBit, ctx->d_cellBox, ctx->host.subBits,
-                                   ctx->host.subOrder, ctx->scratch, ctx->scratchBytes, ox, oy, oz, ocell, ogid));
+                                   ctx->host.subOrder, ctx->scratch, ctx->scratchBytes, ox, oy, oz, ocell, ogid, ctx->d_occupied));
+    // how many cells hold particles: what the streaming kernel's lookup method goes by (StreamState::occupiedHost)
+    if (ctx->d_occupied && ctx->h_occupied)
+        CPF_HIP(ctx, hipMemcpyAsync(ctx->h_occupied, ctx->d_occupied, 16, hipMemcpyDeviceToHost, ctx->stream));
     return CPF_OK;
 }
 }  // namespace
@@ -770,6 +781,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         // (2, 3, 5 on an all-hex mesh: diagnostics -- what the mixed-mesh instantiations cost by themselves; same results)
         CPF_REQUIRE(ctx, value == -1 || (value >= 0 && value <= 5 && value == (int)value), CPF_ERR_ARG, "stream_lookup must be -1 (auto) or 0 ... 5");
         ctx->streamState.lookup = (int)value;
+        return CPF_OK;
+    }
+    if (k == "stream_lookup_by_density") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "stream_lookup_by_density must be 0 or 1");
+        ctx->streamState.densityLookup = (int)value;
         return CPF_OK;
     }
     if (k == "stream_debug") {

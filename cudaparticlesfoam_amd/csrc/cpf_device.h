@@ -56,6 +56,12 @@ struct StreamState {
     int lookup = -1;          // "stream_lookup": 0 loop over distinct cells, 1 fixed tag compare, -1 = by particles per cell
     double tailFraction = -1.0; // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch; < 0 = by lookup method: 0.1 / 0.2
     int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
+    // What the last sort found: [0] cells that hold particles, [1] live particles (pinned host memory, written by an async copy
+    // behind every sort; null / zeros = not known).  The lookup method goes by particles per OCCUPIED cell: the tutorials seed
+    // their clouds in a small box (TJunction: 4e6 particles in 20 000 of 248 000 cells -- 200 per cell, not 16).  Read
+    // without synchronisation: an old value only costs a launch or two on the other -- bit-identical -- instantiation.
+    const volatile unsigned long long* occupiedHost = nullptr;
+    int densityLookup = 1;    // "stream_lookup_by_density": 0 = go by particles / cells of the whole mesh (rounds 2-3)
 };
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
@@ -113,7 +119,7 @@ size_t sort_scratch_bytes(int64_t n, int endBit);
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox = nullptr, double* oy = nullptr, double* oz = nullptr,
-                        int32_t* ocell = nullptr, int64_t* ogid = nullptr);
+                        int32_t* ocell = nullptr, int64_t* ogid = nullptr, unsigned long long* occupied = nullptr);
 
 // multi-GPU hand-off (cpf_handoff.hip)
 size_t handoff_scratch_bytes(int64_t n, int nRanks);

@@ -958,10 +958,30 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
 
 // Out arrays (ox ... ogid) given: the sorted cloud is written there and the input arrays are left alone -- no staging,
 // no copy back (a fifth of the sort's time); the caller swaps its buffers.  All null: in place.
+// how many cells hold particles: the runs of equal cell ids in the sorted keys (lost / frozen particles -- the all-ones key --
+// do not count).  out[0] += runs, out[1] += live particles
+__global__ __launch_bounds__(kBlock) void count_cell_runs_kernel(const uint32_t* __restrict__ keys, int64_t n, int nSub, uint32_t lostKey,
+                                                                 unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool live = false, start = false;
+    if (i < n) {
+        const uint32_t k = keys[i];
+        live = k != lostKey;
+        start = live && (i == 0 || (keys[i - 1] >> nSub) != (k >> nSub));
+    }
+    const unsigned runs = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(start)), alive = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live));
+    __shared__ unsigned sR, sA;
+    if (threadIdx.x == 0) { sR = 0; sA = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sR, runs); atomicAdd(&sA, alive); }
+    __syncthreads();
+    if (threadIdx.x == 0 && (sR | sA)) { atomicAdd(&out[0], (unsigned long long)sR); atomicAdd(&out[1], (unsigned long long)sA); }
+}
+
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox, double* oy, double* oz, int32_t* ocell,
-                        int64_t* ogid) {
+                        int64_t* ogid, unsigned long long* occupied) {
     if (n <= 1) return hipSuccess;
     SubKey sk;
     for (int k = 0; k < 3; ++k) { sk.bits[k] = subBits[k]; sk.order[k] = subOrder[k]; }
@@ -983,6 +1003,11 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     // endBit covers the cell bits + sub-cell bits; the all-ones key of lost/frozen particles sorts last
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keysIn, keysOut, idx, perm, (int)n, 0, endBit, st);
     if (e != hipSuccess) return e;
+    if (occupied != nullptr) {
+        e = hipMemsetAsync(occupied, 0, 16, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(count_cell_runs_kernel, grid_for(n), dim3(kBlock), 0, st, keysOut, n, nSub, 0xFFFFFFFFu, occupied);    // (sort_keys_kernel's lost key)
+    }
     if (ox != nullptr) {
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, ox, oy, oz, perm, n);
         hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, ocell, ogid, perm, n);

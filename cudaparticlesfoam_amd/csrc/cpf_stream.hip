@@ -807,12 +807,17 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
 int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
-    // not all-hex: with / without header records (cells with more than six slots); without them and with many particles per
-    // cell, the loop lookup
-    if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * (int64_t)m.nCells) ? 5 : 3);
-    if (ss.lookup >= 0) return ss.lookup;      // "stream_lookup": 0, 1 or 4
-    if (n < kStreamSparsePerCell * (int64_t)m.nCells) return 4;
-    return n < 128 * (int64_t)m.nCells ? 1 : 0;
+    // particles per cell that HOLDS particles, if the last sort counted them for a cloud of about this size (StreamState)
+    int64_t cells = m.nCells;
+    if (ss.densityLookup && ss.occupiedHost != nullptr) {
+        const int64_t occ = (int64_t)ss.occupiedHost[0], live = (int64_t)ss.occupiedHost[1];
+        if (occ > 0 && occ <= cells && live > 0 && live <= 2 * n && n <= 2 * live) cells = occ;
+    }
+    // not all-hex: with / without big cells (more than six slots); without them and with many particles per cell, the loop lookup
+    if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * cells) ? 5 : 3);
+    if (ss.lookup >= 0) return ss.lookup;      // "stream_lookup": 0, 1 or 4 (2, 3, 5: diagnostics)
+    if (n < kStreamSparsePerCell * cells) return 4;
+    return n < 128 * cells ? 1 : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,

@@ -115,7 +115,14 @@ int cpf_set_mesh_parts(cpf_context* ctx, const cpf_mesh_part* parts, int nParts)
  * One slot per distinct PLANE of a cell: coplanar faces of a cell (the pieces of a face split by a 2:1
  * refinement next door) share a slot; where they lead to different cells the slot's neighbour id names
  * a face group (cpf_get_mesh_groups) and the walk picks the piece at the exit point.  Hex meshes -- all
- * the reference can run (src/initCuda.H:64) -- have no coplanar faces: slots == faces there. */
+ * the reference can run (src/initCuda.H:64) -- have no coplanar faces: slots == faces there.
+ * NO REFERENCE COUNTERPART: trajectories on meshes with face groups (2:1 refinement interfaces) or with cells that are
+ * not hexes follow this library's own rule for such cells -- leave a group slot only outward, enter the piece whose cell
+ * holds the exit point best (csrc/cpf_walk.h) -- stated twice, here and in oracle/cellwalk.c, and checked by the property
+ * "every particle lies inside the cell it claims"; the reference cannot run such meshes, so no reference fixture pins them.
+ * The same holds for two conventions that are exact on the reference's meshes: components of a unit face normal <= 1e-12
+ * are stored as zero, and with the Brownian kick on a one-cell-thick mesh the end point is mirrored about the front / back
+ * plane before the walk (option "z_fold"). */
 int cpf_set_mesh(cpf_context* ctx, const double* points, int64_t nPoints, const int32_t* faceOffsets,
                  const int32_t* faceVerts, int64_t nFaces, const int32_t* owner, const int32_t* neighbour,
                  int64_t nInternal, int64_t nCells);
@@ -216,14 +223,17 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   back plane before the walk instead of at the hit (same trajectory, fewer cell visits; 0 = the reference's
  *                   order of operations, what the staged entry points always use)
  *   "mixed_records" (1; set BEFORE cpf_set_mesh) on a mesh that is not all-hex, build cell records anyway if at most a
- *                   quarter of the cells have more than six faces: cells with fewer than six faces get padded records,
- *                   cells with more a header record and are walked through the CSR tables inside kernel 4.  0 = such
- *                   meshes run the generic walk (kernel 0)
+ *                   quarter of the cells have more than TWELVE distinct planes: cells with fewer than six get padded records,
+ *                   cells with seven to twelve a second record (a visit there takes two rounds of kernel 4, both tests from
+ *                   LDS), cells beyond that a header record and are walked through the CSR tables inside kernel 4.
+ *                   0 = such meshes run the generic walk (kernel 0)
  *   "stream_tiles_per_chunk" (4; 3 on meshes with few particles per cell), "stream_tail_fraction" (0.1; 0.2), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare, 4 the same for sparse clouds -- fewer than 8 particles
  *                   per cell --: pipelined per-lane record gathers; on meshes that are not all-hex only 0 / 1 apply): how a wave finds its cells
- *                   in its record cache;
+ *                   in its record cache; "particles per cell" means per cell that HOLDS particles, as counted by the last
+ *                   sort ("stream_lookup_by_density" 1, default; 0 = per cell of the whole mesh): the tutorials seed 4e6
+ *                   particles into 20 000 of TJunction's 248 000 cells;
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
