@@ -57,11 +57,15 @@ struct StreamState {
     double tailFraction = -1.0; // "stream_tail_fraction": share of the cloud dealt tile by tile at the end of a launch; < 0 = by lookup method: 0.1 / 0.2
     int debug = 0;            // "stream_debug": diagnostics only (1 = no stores, 2 = no loads; results are wrong)
     // What the last sort found: [0] cells that hold particles, [1] live particles (pinned host memory, written by an async copy
-    // behind every sort; null / zeros = not known).  The lookup method goes by particles per OCCUPIED cell: the tutorials seed
-    // their clouds in a small box (TJunction: 4e6 particles in 20 000 of 248 000 cells -- 200 per cell, not 16).  Read
-    // without synchronisation: an old value only costs a launch or two on the other -- bit-identical -- instantiation.
+    // behind every sort; null / zeros = not known).  With "stream_lookup_by_density" 1 the lookup method goes by particles per
+    // OCCUPIED cell instead of per cell of the whole mesh: the tutorials seed their clouds in a small box (TJunction: 4e6
+    // particles in 20 000 of 248 000 cells -- 200 per cell, not 16).  Read without synchronisation: an old value only costs
+    // a launch or two on the other -- bit-identical -- instantiation.  OFF by default, measured (round 4, one box): TJunction
+    // as its dictionary runs it, D = 1.5e-5, takes 0.150 ms per step with the fixed compare the whole-mesh figure picks and
+    // 0.177 ms with the loop lookup the density picks -- on a 3-D mesh with the kick a tile's lanes spread over more cells
+    // per round than the 128-per-cell threshold, tuned on pitzDaily, assumes.
     const volatile unsigned long long* occupiedHost = nullptr;
-    int densityLookup = 1;    // "stream_lookup_by_density": 0 = go by particles / cells of the whole mesh (rounds 2-3)
+    int densityLookup = 0;    // "stream_lookup_by_density"
 };
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,

@@ -231,9 +231,9 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare, 4 the same for sparse clouds -- fewer than 8 particles
  *                   per cell --: pipelined per-lane record gathers; on meshes that are not all-hex only 0 / 1 apply): how a wave finds its cells
- *                   in its record cache; "particles per cell" means per cell that HOLDS particles, as counted by the last
- *                   sort ("stream_lookup_by_density" 1, default; 0 = per cell of the whole mesh): the tutorials seed 4e6
- *                   particles into 20 000 of TJunction's 248 000 cells;
+ *                   in its record cache; with "stream_lookup_by_density" 1 (default 0) "particles per cell" means per cell that
+ *                   HOLDS particles, as counted by the last sort (the tutorials seed 4e6 particles into 20 000 of TJunction's
+ *                   248 000 cells; measured slower there, hence off);
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
