@@ -82,6 +82,9 @@ struct StreamKernArgs {
 static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
+#ifndef CPF_STREAM_WAVES_B1
+#define CPF_STREAM_WAVES_B1 5
+#endif
 #ifndef CPF_STREAM_WAVES_L2
 #define CPF_STREAM_WAVES_L2 6
 #endif
@@ -90,7 +93,7 @@ template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : 6) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : CPF_STREAM_WAVES))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6)) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : CPF_STREAM_WAVES))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -99,7 +102,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
     int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
     // (with the kick the landing zone and the hit pool are larger: 7 slots keep the sixth wave, 6600 of 6826 bytes)
-    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? 7 : kStreamSlotsFixed);
+#ifndef CPF_STREAM_SLOTS_BROWN
+#define CPF_STREAM_SLOTS_BROWN 10
+#endif
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed);
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
     // the wave's record cache.  (256 bytes per slot is one full turn of the 64 LDS banks, so lanes reading the same plane
     // of different slots conflict: 50 conflict cycles per tile on pitzDaily, 351 on the 3-D bench mesh.  Padding the

@@ -3,10 +3,12 @@
 statement, bit for bit.  Random graded/sheared hex blocks (tests/test_oracle_random._case), random cell-constant U,
 time steps that cross several cells and bounce off several walls; every case runs with the statistics on and off
 (two instantiations), plain and fused launches, sorted and unsorted clouds, and with exactly axis-aligned flow
-(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed]
+(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed|poly]
 "mixed": a random subset of the block's cells is split 2 x 2 x 2 (2 x 2 x 1 for every third seed) first -- coarse cells
 with one to six split faces, i.e. face groups in every combination -- and the CPU statement's result is also checked
-against the domain's own invariant (nobody lost, everybody inside the cell they claim)."""
+against the domain's own invariant (nobody lost, everybody inside the cell they claim).
+"poly": extruded polygon grids of random size with true polyhedra (cases/polygons.py: pentagonal, octagonal and dodecagonal
+prisms -- 7, 10 and 14 planes: two-record cells and header records --, conformal or with hanging nodes), same invariant."""
 import os
 import sys
 import time
@@ -20,7 +22,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"
+    mixed = len(sys.argv) > 3 and sys.argv[3] in ("mixed", "poly")
+    poly = len(sys.argv) > 3 and sys.argv[3] == "poly"
     import torch  # noqa: F401  (its HIP runtime first)
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -32,7 +35,17 @@ def main():
     t0 = time.time()
     for seed in range(first, first + count):
         rng, mesh, U, dt = _case(seed)
-        if mixed:
+        if poly:
+            from cudaparticlesfoam_amd.cases import polygons as pg
+            nx, ny, nz = int(rng.integers(4, 14)), int(rng.integers(4, 11)), int(rng.integers(1, 4))
+            kind = seed % 5
+            if kind == 0: mesh, _ = pg.cut_corner_box(nx, ny, nz, every=int(rng.integers(1, 6)), cut=float(rng.uniform(0.2, 0.45)))     # noqa: E701
+            elif kind == 1: mesh, _ = pg.chamfered_box(nx, ny, nz, 1, cut=float(rng.uniform(0.15, 0.4)))                              # noqa: E701
+            elif kind == 2: mesh, _ = pg.chamfered_box(nx, ny, nz, 2, cut=float(rng.uniform(0.15, 0.4)))                              # noqa: E701
+            else: mesh, _ = pg.diamond_box(nx, ny, nz, period=int(rng.integers(1, 4)), cut=float(rng.uniform(0.15, 0.45)))            # noqa: E701
+            U = rng.normal(size=(mesh.n_cells, 3)) * float(rng.choice([0.5, 1.5, 4.0])) + rng.normal(size=3)
+            dt = float(rng.choice([0.05, 0.2, 0.5]))
+        elif mixed:
             from cudaparticlesfoam_amd.cases.refine import refine_hexes
             mask = rng.random(mesh.n_cells) < rng.choice([0.1, 0.3, 0.5])
             mask[int(rng.integers(mesh.n_cells))] = True
@@ -44,7 +57,7 @@ def main():
             amp = float(np.abs(U).max()) or 1.0
             U = np.zeros_like(U); U[:, seed % 3] = rng.normal(size=U.shape[0]) * amp
         if mode == 2:
-            dt = dt * 4                                  # many cells and walls per step
+            dt = dt * (2 if poly else 4)                 # many cells and walls per step
         t = cw.build(mesh)
         lo, hi = mesh.bounds()
         n = int(rng.integers(1000, 60000))
@@ -57,10 +70,11 @@ def main():
         if mixed:
             from test_oracle_mixed import worst_outside
             alive = c >= 0
-            w = worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive])
+            w = worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive]) if alive.any() else np.zeros(1)
             # (mode 2 sends particles across the whole block several times per step: more than five reflections, i.e. lost by
             # the reference's own cap -- the plain block loses them too)
-            if (mode != 2 and (c[ref0 >= 0] < 0).any()) or w.max() > 1e-9 * float((hi - lo).max()):
+            # (poly: steps of up to two unit cells in a grid 1-3 cells thick -- the five-reflection cap takes particles there too)
+            if (mode != 2 and not poly and (c[ref0 >= 0] < 0).any()) or w.max() > 1e-9 * float((hi - lo).max()):
                 bad += 1
                 print("INVARIANT seed %d: %d lost, %d outside their cell (worst %.3e)" %
                       (seed, int((c[ref0 >= 0] < 0).sum()), int((w > 1e-9 * float((hi - lo).max())).sum()), float(w.max())), flush=True)
