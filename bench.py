@@ -740,7 +740,7 @@ def run(args, M):
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc))              # PMC passes are separate rocprofv3 runs (tools/profile_run.sh)
+                rec = json.load(open(pmc))              # PMC passes are separate rocprofv3 runs (tools/pmc.sh)
                 if rec.get("particles_per_launch") == n_local and world == 1:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
@@ -789,7 +789,7 @@ def run(args, M):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": ("profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                            "this command, tools/profile_run.sh; not collected in this run)" if traffic is not None
+                                            "this command, tools/pmc.sh; not collected in this run)" if traffic is not None
                                             else None),
                          "kernel": ctx.step_kernel_name(0.0, 0), "kernel_avg_ms": round(avg_kernel_s * 1e3, 4),
                          "launches": launches, "launches_sampled_every": args.timing_stride, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PARTICLE_STEP * per_launch)},

@@ -82,6 +82,11 @@ struct StreamKernArgs {
 static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
 
+// the zero-denominator skip of a face (cpf_walk.h) in the fixed-lookup instantiation: few particles per cell = a 3-D mesh, where no
+// face is parallel to everybody's displacement (the z pair of a layered mesh is dropped by its own test either way)
+#ifndef CPF_STREAM_L1_ZERO_SKIP
+#define CPF_STREAM_L1_ZERO_SKIP 1
+#endif
 #ifndef CPF_STREAM_WAVES_B1
 #define CPF_STREAM_WAVES_B1 5
 #endif
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
-                                                                : trace_lds6<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
+                                                                : trace_lds6<(!BROWNIAN && (CPF_STREAM_L1_ZERO_SKIP || LOOKUP != 1)), mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
                             if (STATS) ++st.hops;
                             }
                             if (REFLECT && next < 0 && !(mixed && is_group(next))) {       // (is_group: face-group codes and kSitOut)

@@ -52,9 +52,44 @@ def counter_per_kernel(d, counter):
     return {k: dict(dispatches=v[0], mean=v[1] / v[0]) for k, v in agg.items()}
 
 
+FETCH_CORR, WRITE_CORR = 1.9975, 0.9934      # gfx950: calibrated on the zero-cycle launch (profiles/r03_pmc_hbm.json, tools/calib.py)
+
+
+def sq_table(out_dir):
+    """Per step-kernel instantiation: every SQ / GRBM counter of the sq* passes, mean per launch and per 64-particle tile
+    (tiles from the kernel's grid are not in the CSV: the caller divides by its own tile count; 1e7 particles = 156 250)."""
+    import collections
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for f in glob.glob(os.path.join(out_dir, "sq*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            if "step_kernel" not in kn:
+                continue
+            a = agg[kn.split("(")[0][-48:]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    for key, d in agg.items():
+        print("==", key)
+        for c, (n, tot) in sorted(d.items()):
+            print("  %-34s launches %4d  mean/launch %16.1f   per tile of a 1e7-particle launch %10.2f" % (c, n, tot / n, tot / n / 156250.0))
+
+
 def main():
+    if sys.argv[1] == "--sq":
+        return sq_table(sys.argv[2])
     label, stats_dir = sys.argv[1], sys.argv[2]
     out = dict(label=label, kernels=kernel_stats(stats_dir)[:12])
+    if len(sys.argv) >= 5:
+        f = counter_per_kernel(sys.argv[3], "FETCH_SIZE"); w = counter_per_kernel(sys.argv[4], "WRITE_SIZE")
+        steps = []
+        for k in out["kernels"]:
+            full = [n for n in f if n[:140] == k["kernel"]]
+            if "step_kernel" not in k["kernel"] or not full:
+                continue
+            fk, wk = f[full[0]]["mean"], (w.get(full[0]) or {}).get("mean") or 0.0
+            steps.append(dict(kernel=k["kernel"].split("(")[0], calls=k["calls"], avg_us=k["avg_us"], min_us=k["min_us"], max_us=k["max_us"],
+                              FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
+                              hbm_bytes_per_launch=int(fk * 1024 * FETCH_CORR + wk * 1024 * WRITE_CORR),
+                              corrections="FETCH x %.4f, WRITE x %.4f" % (FETCH_CORR, WRITE_CORR)))
+        out["step_kernels"] = steps
     if len(sys.argv) >= 5:
         f = counter_per_kernel(sys.argv[3], "FETCH_SIZE"); w = counter_per_kernel(sys.argv[4], "WRITE_SIZE")
         out["pmc"] = {k[:140]: dict(FETCH_SIZE_KB=f[k]["mean"], WRITE_SIZE_KB=w.get(k, {}).get("mean"), dispatches=f[k]["dispatches"])

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--variant", type=int, default=4)
     ap.add_argument("--D", type=float, default=0.0, help="diffusion coefficient of the measured launches")
     ap.add_argument("--groups", action="store_true", help="also per-group (= per-CU) and per-XCD end times")
-    ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh of tools/bench_3d.py, swirl field")
+    ap.add_argument("--mesh3d", action="store_true", help="the 245 760-cell 3-D mesh (tools/_cases.py: box3d), swirl field")
     ap.add_argument("--tjunction", action="store_true", help="the reference's TJunction tutorial mesh (248 000 cells), split flow u0 = 3")
     ap.add_argument("--case", default=None, help="tools/_cases.py: pitz | box3d | tjunction | octagons | pentagons | dodecagons | hexgrid")
     ap.add_argument("--census", action="store_true", help="busy lanes per round index, sit-outs, rounds against the largest visit count of a tile")
