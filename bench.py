@@ -545,7 +545,7 @@ class GpuMachine:
         Db, interval = 1.5e-5, 25
         cl = self._fresh_cloud(cloud.n, box, 2025, sort_interval=interval)
         cl.step(dt, 10, D=Db)
-        cl.step_index = 0                                       # (the sort cadence restarts with the clock)
+        cl.sort(); cl.step_index = 0         # steady state: every interval of the clock starts on a fresh sort and pays for the next one
         r = self._timed_steps(torch, ctx, cl, dt, args.brownian_steady_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
         r.update({"D": Db, "sort_interval": interval, "sorts_inside": args.brownian_steady_steps // interval,
                   "kernel": ctx.step_kernel_name(Db, 0), "particles": cl.n,
@@ -597,7 +597,7 @@ class GpuMachine:
             ctx2.set_option("stats", 1); c0 = ctx2.counters()
             cl.step(dt, 10, D=Db)
             torch.cuda.synchronize(); c1 = ctx2.counters(); ctx2.set_option("stats", 0)
-            cl.step_index = 0
+            cl.sort(); cl.step_index = 0     # (as in _brownian_steady)
             r = self._timed_steps(torch, ctx2, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
             rec_once = 256 * mesh.n_cells
             r.update({"D": Db, "particles": n, "cells": mesh.n_cells, "sort_interval": interval,

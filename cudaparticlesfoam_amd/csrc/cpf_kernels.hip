@@ -784,6 +784,24 @@ __global__ void gather_ids_kernel(const int32_t* __restrict__ cell, const int64_
         if (gid) sg[i] = gid[j];
     }
 }
+// the sort's gathers in one pass (into a second set of arrays): one read of the permutation, five independent gathers in
+// flight per thread; a live particle's cell comes out of its sorted key (no gather), a lost / frozen one's is fetched
+__global__ __launch_bounds__(kBlock) void gather_all_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                                            const int32_t* __restrict__ cell, const int64_t* __restrict__ gid,
+                                                            double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
+                                                            int32_t* __restrict__ ocell, int64_t* __restrict__ ogid,
+                                                            const int32_t* __restrict__ perm, const uint32_t* __restrict__ keys, int nSub, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = perm[i];
+    const uint32_t k = keys[i];
+    const double a = x[j], b = y[j], c = z[j];
+    const int64_t g = gid ? gid[j] : 0;
+    const int32_t cc = k != 0xFFFFFFFFu ? (int32_t)(k >> nSub) : cell[j];
+    ox[i] = a; oy[i] = b; oz[i] = c;
+    ocell[i] = cc;
+    if (gid) ogid[i] = g;
+}
 __global__ void copy_ids_kernel(int32_t* __restrict__ cell, int64_t* __restrict__ gid, const int32_t* __restrict__ sc,
                                 const int64_t* __restrict__ sg, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1009,8 +1027,12 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
         hipLaunchKernelGGL(count_cell_runs_kernel, grid_for(n), dim3(kBlock), 0, st, keysOut, n, nSub, 0xFFFFFFFFu, occupied);    // (sort_keys_kernel's lost key)
     }
     if (ox != nullptr) {
+#ifdef CPF_SORT_SPLIT_GATHERS
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, ox, oy, oz, perm, n);
         hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, ocell, ogid, perm, n);
+#else
+        hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n);
+#endif
     } else {
         double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;          // the 24n-byte staging area
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, perm, n);
