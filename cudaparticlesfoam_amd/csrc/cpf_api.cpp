@@ -564,9 +564,17 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             else CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         ctx->lastStepN = n; ctx->lastStepCycles = cycPerLaunch;
-        CPF_HIP(ctx, cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                      reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
-                                      &ctx->streamState));
+        const hipError_t le = cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
+                                               reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
+                                               &ctx->streamState);
+        if (le != hipSuccess) {
+            // a launch that did not go out (occupancy query, tile count, missing spill area): its time stamps must not be
+            // left for the next, unrelated launch to take, and the two events go back to the pool instead of leaking
+            ctx->streamState.evStart = ctx->streamState.evStop = nullptr;
+            if (e0) ctx->eventPool.push_back(e0);
+            if (e1) ctx->eventPool.push_back(e1);
+        }
+        CPF_HIP(ctx, le);
         if (timed) {
             if (!stamped) CPF_HIP(ctx, hipEventRecord(e1, ctx->stream));
             else if (ctx->streamState.evStart != nullptr) {  // (cannot happen: the streaming launcher always takes them)
