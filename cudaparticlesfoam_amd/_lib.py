@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "cpf.h")
 
 CPF_OK, CPF_ERR_ARG, CPF_ERR_STATE, CPF_ERR_MESH, CPF_ERR_HIP, CPF_ERR_NOMEM = range(6)
 CELL_LOST, CELL_FROZEN = -1, -2
-STEP_DEFAULT, STEP_NO_REFLECT, STEP_STORE_VEL, STEP_FUSE_CYCLES = 0, 1, 2, 4
+STEP_DEFAULT, STEP_NO_REFLECT, STEP_STORE_VEL, STEP_FUSE_CYCLES, STEP_VERTEX_VELOCITY = 0, 1, 2, 4, 8
 HANDOFF_DOUBLES = 5
 
 

@@ -543,6 +543,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     CPF_REQUIRE(ctx, !storeVel || vel, CPF_ERR_ARG, "cpf_step: CPF_STEP_STORE_VEL needs a vel array");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     const bool reflect = (flags & CPF_STEP_NO_REFLECT) == 0;
+    const bool vertexU = (flags & CPF_STEP_VERTEX_VELOCITY) != 0;
+    CPF_REQUIRE(ctx, !vertexU || ctx->haveVertVel, CPF_ERR_STATE, "cpf_step: CPF_STEP_VERTEX_VELOCITY needs cpf_set_tets and cpf_set_vertex_velocity");
     const cpf::MeshView m = meshView(ctx);
     const bool fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
     const int nLaunch = fuse ? 1 : nCycles;   // fused with nCycles == 0: load+store only (bandwidth calibration)
@@ -559,14 +561,18 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             // the streaming launcher stamps the events with the dispatch's own begin / end (cpf_device.h, StreamState);
             // any other kernel is bracketed by two event records
-            stamped = cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
+            stamped = !vertexU && cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
             if (stamped) { ctx->streamState.evStart = e0; ctx->streamState.evStop = e1; }
             else CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
         ctx->lastStepN = n; ctx->lastStepCycles = cycPerLaunch;
-        const hipError_t le = cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
-                                               reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
-                                               &ctx->streamState);
+        const hipError_t le = vertexU
+            ? cpf::launch_step_vertex(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed, reflect,
+                                      storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->d_tetPos, ctx->d_tets, ctx->tetsPerCell,
+                                      ctx->d_vertVel)
+            : cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
+                               reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
+                               &ctx->streamState);
         if (le != hipSuccess) {
             // a launch that did not go out (occupancy query, tile count, missing spill area): its time stamps must not be
             // left for the next, unrelated launch to take, and the two events go back to the pool instead of leaking
@@ -843,7 +849,8 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     const char* b[2] = {"false", "true"};
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
     char tmp[160];
-    if (v == 5 && !brown && !sv && !(flags & CPF_STEP_FUSE_CYCLES))
+    if (flags & CPF_STEP_VERTEX_VELOCITY) snprintf(tmp, sizeof tmp, "cpf::step_kernel_vertex<%s, %s, %s>", b[brown], b[reflect], b[sv]);
+    else if (v == 5 && !brown && !sv && !(flags & CPF_STEP_FUSE_CYCLES))
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
     else if (v == 4 || v == 5) {
         // (the record lookup is picked per launch from the particle count: the most recent launch's, else the owned cloud's)

@@ -80,6 +80,11 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                        bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters, int variant,
                        StreamState* ss);
+// the fused cycle with the "VertexVelocity" advect mode (generic walk; CPF_STEP_VERTEX_VELOCITY)
+hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                              double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
+                              bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel);
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
                               bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,

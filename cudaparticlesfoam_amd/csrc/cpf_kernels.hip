@@ -23,17 +23,56 @@ namespace cpf {
 // structure; >1 keeps the particle in registers between cycles)
 // ------------------------------------------------------------------------------------------------
 
-template <class TRACER, bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+// "VertexVelocity" advect mode (cuda/particles.cu:244-313, 428-437): the velocity at P is the barycentric interpolation of
+// VERTEX velocities in a tet of the particle's cell -- the tet whose smallest barycentric weight of P is largest (the product
+// tracks cells, and the interpolant is continuous across the tets of a cell), then weighed exactly like the reference
+// (w_X = det(tet with X := P) * (1 / det(tet))).  Shared by the staged advect and the fused cycle: same bits.
+struct VertexField { const double* pos; const int32_t* tets; const double* vel; int tetsPerCell; };
+__device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
+    const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
+    const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+    return d.x * c.x + d.y * c.y + d.z * c.z;
+}
+__device__ __forceinline__ bool vertex_velocity(const VertexField& f, const D3& Pp, int c, D3& v) {
+    auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
+    int best = -1;
+    double bestMin = 0.0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (int k = 0; k < f.tetsPerCell; ++k) {
+        const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + k);
+        const D3 A = ld(f.pos, ix[0]), B = ld(f.pos, ix[1]), C = ld(f.pos, ix[2]), D = ld(f.pos, ix[3]);
+        const double den = det4(A, B, C, D);
+        if (den == 0.0) continue;                                 // a bad tet (particles.cu:275-278) cannot hold P
+        const double a = det4(Pp, B, C, D) * (1. / den), b = det4(A, Pp, C, D) * (1. / den);
+        const double cc = det4(A, B, Pp, D) * (1. / den), d = det4(A, B, C, Pp) * (1. / den);
+        const double m = fmin(fmin(a, b), fmin(cc, d));
+        if (best < 0 || m > bestMin) { best = k; bestMin = m; w0 = a; w1 = b; w2 = cc; w3 = d; }
+    }
+    if (best < 0) return false;
+    const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + best);
+    const D3 vA = ld(f.vel, ix[0]), vB = ld(f.vel, ix[1]), vC = ld(f.vel, ix[2]), vD = ld(f.vel, ix[3]);
+    v = {((w0 * vA.x + w1 * vB.x) + w2 * vC.x) + w3 * vD.x, ((w0 * vA.y + w1 * vB.y) + w2 * vC.y) + w3 * vD.y,
+         ((w0 * vA.z + w1 * vB.z) + w2 * vC.z) + w3 * vD.z};
+    return true;
+}
+
+template <class TRACER, bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool VERTEX = false>
 __device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView& m, D3& P, int& cur, D3& v,
                                                 uint64_t id, double dt, double sigma, uint32_t step0, int nCyc,
-                                                uint32_t seed, StepStats& st) {
+                                                uint32_t seed, StepStats& st, const VertexField* vf = nullptr) {
     for (int c = 0; c < nCyc; ++c) {
         if (cur < 0) { cur = CPF_CELL_FROZEN; break; }           // lost in the previous cycle: w = 0
-        ++st.steps;
         // ---- advect (cuda/particles.cu:355-362): disp = (P + dt*U[cell]) - P
-        const double4 u = tr.velocity(cur);
-        v = {u.x, u.y, u.z};
-        const D3 Pn = axpy(dt, v, P);
+        D3 Pn;
+        if (VERTEX) {
+            // (no tet of the cell holds P -- degenerate decomposition: the reference switches the particle off, :262-266)
+            if (!vertex_velocity(*vf, P, cur, v)) { cur = CPF_CELL_FROZEN; break; }
+            Pn = {P.x + dt * v.x, P.y + dt * v.y, P.z + dt * v.z};       // multiply, round, add: what the staged advect does
+        } else {
+            const double4 u = tr.velocity(cur);
+            v = {u.x, u.y, u.z};
+            Pn = axpy(dt, v, P);
+        }
+        ++st.steps;
         D3 disp = {Pn.x - P.x, Pn.y - P.y, Pn.z - P.z};
         if (BROWNIAN) {                                          // particles.cu:560-569
             const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
@@ -97,6 +136,38 @@ __global__ __launch_bounds__(kBlock) void step_kernel(double* __restrict__ x, do
             const GlobalTracer<VARIANT> tr{m};
             particle_cycles<GlobalTracer<VARIANT>, BROWNIAN, REFLECT, STORE_VEL>(tr, m, P, cur, v, id, dt, sigma, step0,
                                                                                  nCyc, seed, st);
+            x[i] = P.x; y[i] = P.y; z[i] = P.z;
+            cell[i] = cur;
+            if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
+        } else if (cur == CPF_CELL_LOST) {
+            cell[i] = CPF_CELL_FROZEN;
+        }
+    }
+    __shared__ unsigned sCnt[4];
+    flush_stats(st, counters, sCnt);
+}
+
+// The fused cycle with the "VertexVelocity" advect (cuda/particles.cu:428-437; CPF_STEP_VERTEX_VELOCITY): the generic walk
+// with the velocity interpolated at the particle's position.  Same stages in the same order as the reference's five calls with
+// that mode, one launch; the advect shares its arithmetic with cpf_stage_advect_vertex (tests assert equality).
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL>
+__global__ __launch_bounds__(kBlock) void step_kernel_vertex(double* __restrict__ x, double* __restrict__ y,
+                                                             double* __restrict__ z, int32_t* __restrict__ cell,
+                                                             const int64_t* __restrict__ gid, double* __restrict__ vel,
+                                                             int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
+                                                             uint32_t seed, MeshView m, VertexField vf,
+                                                             unsigned long long* __restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    StepStats st = {0, 0, 0, 0};
+    if (i < n) {
+        int cur = cell[i];
+        if (cur >= 0) {
+            D3 P = {x[i], y[i], z[i]};
+            D3 v = {0, 0, 0};
+            const uint64_t id = gid ? (uint64_t)gid[i] : (uint64_t)i;
+            const GlobalTracer<kVariantGeneric> tr{m};
+            particle_cycles<GlobalTracer<kVariantGeneric>, BROWNIAN, REFLECT, STORE_VEL, true>(tr, m, P, cur, v, id, dt, sigma, step0,
+                                                                                               nCyc, seed, st, &vf);
             x[i] = P.x; y[i] = P.y; z[i] = P.z;
             cell[i] = cur;
             if (STORE_VEL) { vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z; }
@@ -425,6 +496,27 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     return hipGetLastError();
 }
 
+hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                              double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
+                              bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    const bool brown = D > 0.0;
+    const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
+    const VertexField vf{pos, tets, vertVel, tetsPerCell};
+#define CPF_VTX(B, R, SV) hipLaunchKernelGGL((step_kernel_vertex<B, R, SV>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, vf, counters)
+    if (brown) {
+        if (reflect) { if (storeVel) CPF_VTX(true, true, true); else CPF_VTX(true, true, false); }
+        else { if (storeVel) CPF_VTX(true, false, true); else CPF_VTX(true, false, false); }
+    } else {
+        if (reflect) { if (storeVel) CPF_VTX(false, true, true); else CPF_VTX(false, true, false); }
+        else { if (storeVel) CPF_VTX(false, false, true); else CPF_VTX(false, false, false); }
+    }
+#undef CPF_VTX
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stage-by-stage kernels on the REFERENCE's own array layouts (Particle = double4 AoS, vec4d
 // disps / vels, int ids), one per wrapper of third_party/RTXAdvect/cuda/common.h and
@@ -452,41 +544,17 @@ __global__ __launch_bounds__(kBlock) void stage_advect_kernel(double4* __restric
 // "VertexVelocity" advect (cuda/particles.cu:244-313) on cell ids; see cpf_stage_advect_vertex in include/cpf.h.
 // Plain products and sums in the reference's order (no fma: the file is built with -ffp-contract=off), so that
 // oracle/cellwalk.c's cw_advect_vertex is reproduced bit for bit.
-__device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
-    const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
-    const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
-    return d.x * c.x + d.y * c.y + d.z * c.z;
-}
 __global__ __launch_bounds__(kBlock) void stage_advect_vertex_kernel(double4* __restrict__ P, const int32_t* __restrict__ ids,
                                                                      double4* __restrict__ vels, double4* __restrict__ disps,
-                                                                     double dt, int64_t n, const double* __restrict__ pos,
-                                                                     const int32_t* __restrict__ tets, int tetsPerCell,
-                                                                     const double* __restrict__ vertVel) {
+                                                                     double dt, int64_t n, VertexField f) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     double4 p = P[i];
     if (!p.w) return;
     const int c = ids[i];
     if (c < 0) { p.w = 0.0; P[i] = p; return; }                  // particles.cu:262-266
-    const D3 Pp = {p.x, p.y, p.z};
-    auto ld = [](const double* a, int v) { return D3{a[3 * (int64_t)v], a[3 * (int64_t)v + 1], a[3 * (int64_t)v + 2]}; };
-    int best = -1;
-    double bestMin = 0.0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    for (int k = 0; k < tetsPerCell; ++k) {
-        const int32_t* ix = tets + 4 * ((int64_t)c * tetsPerCell + k);
-        const D3 A = ld(pos, ix[0]), B = ld(pos, ix[1]), C = ld(pos, ix[2]), D = ld(pos, ix[3]);
-        const double den = det4(A, B, C, D);
-        if (den == 0.0) continue;                                 // a bad tet (particles.cu:275-278) cannot hold P
-        const double a = det4(Pp, B, C, D) * (1. / den), b = det4(A, Pp, C, D) * (1. / den);
-        const double cc = det4(A, B, Pp, D) * (1. / den), d = det4(A, B, C, Pp) * (1. / den);
-        const double m = fmin(fmin(a, b), fmin(cc, d));
-        if (best < 0 || m > bestMin) { best = k; bestMin = m; w0 = a; w1 = b; w2 = cc; w3 = d; }
-    }
-    if (best < 0) { p.w = 0.0; P[i] = p; return; }
-    const int32_t* ix = tets + 4 * ((int64_t)c * tetsPerCell + best);
-    const D3 vA = ld(vertVel, ix[0]), vB = ld(vertVel, ix[1]), vC = ld(vertVel, ix[2]), vD = ld(vertVel, ix[3]);
-    const D3 v = {((w0 * vA.x + w1 * vB.x) + w2 * vC.x) + w3 * vD.x, ((w0 * vA.y + w1 * vB.y) + w2 * vC.y) + w3 * vD.y,
-                  ((w0 * vA.z + w1 * vB.z) + w2 * vC.z) + w3 * vD.z};
+    D3 v;
+    if (!vertex_velocity(f, D3{p.x, p.y, p.z}, c, v)) { p.w = 0.0; P[i] = p; return; }
     const D3 Pn = {p.x + dt * v.x, p.y + dt * v.y, p.z + dt * v.z};
     vels[i] = make_double4(v.x, v.y, v.z, -1.0);
     disps[i] = make_double4(Pn.x - p.x, Pn.y - p.y, Pn.z - p.z, -1.0);
@@ -614,7 +682,7 @@ hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* 
                                       const double* vertVel) {
     if (n > 0)
         hipLaunchKernelGGL(stage_advect_vertex_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels,
-                           (double4*)disps, dt, n, pos, tets, tetsPerCell, vertVel);
+                           (double4*)disps, dt, n, VertexField{pos, tets, vertVel, tetsPerCell});
     return hipGetLastError();
 }
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,

@@ -52,6 +52,10 @@ typedef enum cpf_status {
 #define CPF_STEP_STORE_VEL 2u     /* also write per-particle velocity (d_particle_vels, for the VTU writer) */
 #define CPF_STEP_FUSE_CYCLES 4u   /* run all nCycles inside ONE launch, particle state kept in registers
                                      (legal because U is frozen during the loop, src/advect.H:86) */
+#define CPF_STEP_VERTEX_VELOCITY 8u /* advect with the velocity INTERPOLATED at the particle's position from vertex velocities
+                                     (cudaAdvect(..., "VertexVelocity"), cuda/particles.cu:244-313, 428-437) instead of the
+                                     cell-constant one: needs cpf_set_tets + cpf_set_vertex_velocity; the same five stages in
+                                     one launch of the generic walk, equal to the staged calls bit for bit */
 
 /* ---------------------------------------------------------------------------------------------
  * context

@@ -178,6 +178,62 @@ def test_vertex_velocity_vs_reference_golden(gpu_ctx_factory, oracle_libs):
         sc.close()
 
 
+def test_fused_vertex_velocity_cycle_equals_the_staged_calls(gpu_ctx_factory):
+    """cpf_step(..., CPF_STEP_VERTEX_VELOCITY): the reference's cycle with the "VertexVelocity" advect (cuda/particles.cu:
+    244-313, 428-437 -> ConvexQuery -> reflect -> move) as ONE launch of the generic walk.  Same stages, same arithmetic as the
+    five staged calls: cells and positions equal them bit for bit at every checkpoint of the reference golden -- single-cycle
+    launches, fused launches and a sorted cloud alike -- and therefore the reference's own output within the same 1e-5."""
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import StagedCloud
+    from cudaparticlesfoam_amd.cases import box_mesh
+    from oracle.tetmesh import poly_to_tets
+    g = np.load(os.path.join(G, "vertex_box.npz"))
+    mesh = box_mesh(10, 9, 8)
+    lo, hi = mesh.bounds(); diag = float(np.linalg.norm(hi - lo))
+    pos, tets, tcell, _ = poly_to_tets(mesh, None, np.zeros((mesh.n_cells, 3)))
+    n = g["xyz0"].shape[0]
+    cell0 = (g["tet0"] // 12).astype(np.int32)
+    dt = float(g["dt"])
+
+    def ctx_with_field():
+        c = gpu_ctx_factory()
+        c.set_mesh(mesh); c.set_velocity(np.zeros((mesh.n_cells, 3)))
+        c.set_tets(pos, tets, 12); c.set_vertex_velocity(g["vertex_U"])
+        return c
+    staged_ctx = ctx_with_field()
+    P0 = np.ones((n, 4)); P0[:, :3] = g["xyz0"]
+    sc = StagedCloud(staged_ctx, n)
+    fused = []
+    for mode in ("per cycle", "fused launches", "sorted"):
+        c = ctx_with_field()
+        c.set_particles(g["xyz0"], cell0)
+        if mode == "sorted":
+            c.sort_by_cell()
+        fused.append((mode, c))
+    assert "step_kernel_vertex<false, true, false>" in fused[0][1].step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY)
+    try:
+        sc.set(P0, cell0)
+        done = 0
+        for k in g["checkpoints"]:
+            for _ in range(int(k) - done):
+                sc.cudaAdvect(dt, "VertexVelocity"); sc.convexTetQuery(); sc.convexWallReflect(); sc.cudaMoveParticles()
+            for mode, c in fused:
+                fl = L.STEP_VERTEX_VELOCITY | (L.STEP_FUSE_CYCLES if mode == "fused launches" else 0)
+                c.step(dt, 0.0, int(k) - done, fl)
+                xyzw, cell = c.get_particles()
+                assert np.array_equal(cell, sc.ids), (mode, int(k))
+                assert np.array_equal(xyzw[:, :3], sc.particles[:, :3]), (mode, int(k))
+                assert np.array_equal(cell, g["tet_%d" % k] // 12) and _rel(np.c_[xyzw[:, :3], np.ones(n)], g["P_%d" % k], diag).max() <= REL_TOL
+            done = int(k)
+        # without the tets / vertex field the flag is refused, not ignored
+        bare = gpu_ctx_factory()
+        bare.set_mesh(mesh); bare.set_velocity(np.zeros((mesh.n_cells, 3))); bare.set_particles(g["xyz0"], cell0)
+        with pytest.raises(L.CpfError):
+            bare.step(dt, 0.0, 1, L.STEP_VERTEX_VELOCITY)
+    finally:
+        sc.close()
+
+
 # ---- the oracle .so files built ON THIS BOX, tied to the same goldens in the same run ----------------------
 @pytest.mark.parametrize("name", ["pitz_uniform", "pitz_analytic", "box_random"])
 def test_oracle_built_here_reproduces_goldens(name, pitz, oracle_libs):
