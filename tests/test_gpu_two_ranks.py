@@ -164,3 +164,13 @@ def test_two_ranks_fixed_ranges_growing_shard(pitz, oracle_libs):
     out, cell = _run_two_ranks(pitz, oracle_libs, n_total=300_000, steps=40, rebalance=0, exchange=2, overlap=1,
                                balance_by_time=False, capacity=160_000, dt=4e-4)
     assert sum(o["grown"] for o in out) >= 1 and out[1]["n"] > 160_000
+
+
+def test_two_ranks_overlap_depth_derived_per_rank(pitz, oracle_libs):
+    """`overlap_steps = -1` (bench.py's default since round 4): every rank derives how many steps it queues between a split and
+    its exchange from its own measured host work per hand-off and its own step time (parallel.py, _overlap) -- the ranks may
+    choose differently, and every particle still equals the one-process run bit for bit."""
+    out, cell = _run_two_ranks(pitz, oracle_libs, n_total=400_000, steps=32, rebalance=8, exchange=0, overlap=-1,
+                               balance_by_time=True, capacity=400_000 + 64)
+    assert all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
+    assert sum(o["n"] for o in out) == 400_000
