@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
         bool havePrev = false;
         unsigned rtile = 0;
         double rvx = 0, rvy = 0, rvz = 0;
+        bool ralive = false;                         // (stored velocity) the lane carried a live particle when the tile was LOADED
         int rc = 0;
         unsigned rlim = 63;
 
@@ -317,7 +318,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 double* const x = cp.x; double* const y = cp.y; double* const z = cp.z; int32_t* const cell = cp.cell;
                 if (havePrev && !(sa.debug & 1)) {
                     const int64_t b = (int64_t)uniform32(rtile) * 64;
-                    if (STORE_VEL && rc != CPF_CELL_FROZEN) {
+                    // (every particle that was alive when the launch began gets its velocity stored -- of its last live cycle if
+                    // it was lost on the way, like the reference's vels[] after an advect that skips it, cuda/particles.cu:333-338,
+                    // and like the other step kernels; round 4: this kernel used to skip particles lost DURING a fused launch)
+                    if (STORE_VEL && ralive) {
                         double* vv = vel + 3 * b;
                         async_store(vv, ul * 24u, rvx); async_store(vv + 1, ul * 24u, rvy); async_store(vv + 2, ul * 24u, rvz);
                     }
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             // which keeps the NUMBER of stores per tile fixed -- the counted wait above needs it
             rtile = tile; havePrev = true;
             sE[0][lane] = S_.x; sE[1][lane] = S_.y; sE[2][lane] = S_.z;
-            if (STORE_VEL) { rvx = v.x; rvy = v.y; rvz = v.z; }
+            if (STORE_VEL) { rvx = v.x; rvy = v.y; rvz = v.z; ralive = pc >= 0; }
             rc = cur;
             rlim = plim;
             if (ntilesLeft <= 0) break;
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             double* const x = cp.x; double* const y = cp.y; double* const z = cp.z; int32_t* const cell = cp.cell;
             const double rx = sE[0][lane], ry = sE[1][lane], rz = sE[2][lane];
             if (ul <= rlim) { (x + b)[ul] = rx; (y + b)[ul] = ry; (z + b)[ul] = rz; (cell + b)[ul] = rc; }
-            if (STORE_VEL && rc != CPF_CELL_FROZEN) {
+            if (STORE_VEL && ralive) {
                 double* vv = vel + 3 * b;
                 vv[3 * ul] = rvx; vv[3 * ul + 1] = rvy; vv[3 * ul + 2] = rvz;
             }

@@ -1089,3 +1089,45 @@ def test_merge_failure_is_reported_through_the_context(setup, gpu_ctx_factory):
     assert e.value.status == L.CPF_ERR_MESH
     msg = ctx.lib.cpf_last_error(ctx.h).decode()
     assert "piece 1" in msg and "owner" in msg
+
+
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_stored_velocity_of_particles_lost_during_a_fused_launch(setup, gpu_ctx_factory, variant):
+    """Walls that do not reflect (reflectWall = false, src/initCuda.H:67): a particle that reaches one is lost and frozen from the
+    next cycle on, and its stored velocity stays what its LAST live cycle gave it (the reference's advect skips it from then on,
+    cuda/particles.cu:333-338).  That must not depend on how the cycles are grouped into launches: 12 cycles as 12 launches, as
+    one fused launch and as 5 + 7 give the same velocities -- round 4 found the streaming kernel skipping the store for particles
+    lost in the middle of a fused launch (tools/stream_check.py)."""
+    import torch
+    from cudaparticlesfoam_amd import _lib as L
+    mesh, pz = setup["mesh"], setup["pz"]
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(setup["pitz"]["U_uniform"]); ctx.set_option("step_variant", variant)
+    n = 60_000
+    xyz = pz.uniform_points(5, int(n * 1.5), (0.25, -0.025, -0.0005), (0.29, 0.025, 0.0005))     # the last 40 mm before the outlet
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    x0, y0, z0 = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+    c0 = torch.empty(xyz.shape[0], dtype=torch.int32, device=dev)
+    ctx.locate_initial_dev(x0.data_ptr(), y0.data_ptr(), z0.data_ptr(), c0.data_ptr(), xyz.shape[0])
+    keep = (c0 >= 0).nonzero().flatten()[:n]
+    x0, y0, z0, c0 = x0[keep].contiguous(), y0[keep].contiguous(), z0[keep].contiguous(), c0[keep].contiguous()
+    n = int(x0.numel())
+    fl = L.STEP_NO_REFLECT | L.STEP_STORE_VEL
+    outs = []
+    for groups in ([1] * 12, [12], [5, 7]):
+        x, y, z, c = x0.clone(), y0.clone(), z0.clone(), c0.clone()
+        vel = torch.full((3 * n,), -7.0, dtype=torch.float64, device=dev)
+        step = 0
+        for k in groups:
+            ctx.step_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), c.data_ptr(), None, vel.data_ptr(), n, 2e-4, 0.0, step, k,
+                         fl | (L.STEP_FUSE_CYCLES if k > 1 else 0))
+            step += k
+        torch.cuda.synchronize()
+        outs.append((x.cpu().numpy(), c.cpu().numpy(), vel.cpu().numpy().reshape(n, 3)))
+    lost = outs[0][1] < 0
+    assert 1000 < lost.sum() < n                                  # 2 mm per cycle: those within 24 mm of the outlet reach it on the way
+    for x, c, v in outs[1:]:
+        assert np.array_equal(c < 0, lost) and np.array_equal(x, outs[0][0])
+        assert np.array_equal(v, outs[0][2])
+    assert (outs[0][2][lost][:, 0] == 10.0).all()                 # the lost ones carry the velocity of their last live cycle

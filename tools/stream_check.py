@@ -67,6 +67,9 @@ def main():
             if not same:
                 bad += 1
                 nd = int((a[3] != b[3]).sum()); nx = int((a[0] != b[0]).sum())
+                ny = int((a[1] != b[1]).sum()); nz = int((a[2] != b[2]).sum())
+                nv = int((a[4] != b[4]).sum()) if vel is not None else 0
+                print("  y_differ", ny, "z_differ", nz, "vel_differ", nv, "max|dz|", float((a[2] - b[2]).abs().max()), flush=True)
                 print("MISMATCH", dict(field=field, n=n, sort=sort, D=D, noref=noref, sv=sv, stats=stats, fused=fused,
                                        tpc=tpc, il=il, cells_differ=nd, x_differ=nx, cnt3=a[5], cnt4=b[5]), flush=True)
         print("checked", field, n, "sorted" if sort else "unsorted", "bad so far:", bad, flush=True)
