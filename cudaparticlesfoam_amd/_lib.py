@@ -109,6 +109,7 @@ SIGNATURES = {
     "cpf_write_vtu_async": (_int, [_ctx, C.c_char_p, C.POINTER(_dbl)]),
     "cpf_write_vtu_wait": (_int, [_ctx]),
     "cpf_write_vtu_arrays": (_int, [C.c_char_p, _i64, _vp, _vp, _vp, C.POINTER(_dbl)]),
+    "cpf_write_vtu_arrays_binary": (_int, [C.c_char_p, _i64, _vp, _vp, _vp, C.POINTER(_dbl)]),
     "cpf_timing_enable": (_int, [_ctx, _int]),
     "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
     "cpf_timing_poll": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),

@@ -62,6 +62,7 @@ struct cpf_context {
     uint32_t lastSortStep = 0;
     bool stats = false;                         // "stats": per-launch counters (steps, cells visited, reflections, lost)
     int stepVariant = -1;                       // cpf_set_option("step_variant"), see include/cpf.h: -1 = choose per launch
+    bool vtuBinary = false;                     // cpf_set_option("vtu_binary"): frames with raw appended arrays instead of the reference's ASCII
     bool mixedRecords = true;                   // cpf_set_option("mixed_records"): build cell records for hex-dominant meshes too (before cpf_set_mesh)
     cpf::StreamState streamState;               // chunk counter + tuning of the streaming step kernel
     int64_t lastStepN = -1;                     // particle count of the most recent step launch (cpf_step_kernel_name)
@@ -240,6 +241,8 @@ WriterRegistry::~WriterRegistry() {
         if (c->writerLive && c->writer.joinable()) { c->writer.join(); c->writerLive = false; }
 }
 }  // namespace
+
+namespace cpf { bool vtu_binary(const cpf_context* ctx) { return ctx && ctx->vtuBinary; } }
 
 extern "C" {
 
@@ -805,6 +808,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->streamState.densityLookup = (int)value;
         return CPF_OK;
     }
+    if (k == "vtu_binary") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "vtu_binary must be 0 or 1");
+        ctx->vtuBinary = value != 0;
+        return CPF_OK;
+    }
     if (k == "stream_debug") {
         ctx->streamState.debug = (int)value;
         return CPF_OK;
@@ -1118,9 +1126,10 @@ int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE) {
     const std::string file(path);
     { std::lock_guard<std::mutex> lk(g_mutex); g_writers.live.push_back(ctx); }
     ctx->writerLive = true;
-    ctx->writer = std::thread([ctx, file, n] {
-        ctx->writerStatus = cpf_write_vtu_arrays(file.c_str(), n, ctx->wXyzw.data(), ctx->wCell.data(), ctx->wVel.data(),
-                                                 nullptr);
+    const bool binary = ctx->vtuBinary;
+    ctx->writer = std::thread([ctx, file, n, binary] {
+        ctx->writerStatus = (binary ? cpf_write_vtu_arrays_binary : cpf_write_vtu_arrays)(file.c_str(), n, ctx->wXyzw.data(), ctx->wCell.data(),
+                                                                                         ctx->wVel.data(), nullptr);
     });
     return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
 }

@@ -18,6 +18,9 @@
 
 #include "cpf.h"
 
+struct cpf_context;
+namespace cpf { bool vtu_binary(const cpf_context* ctx); }     // cpf_api.cpp: the context's "vtu_binary" option
+
 namespace {
 
 // Formatting dominates the output path (printf of "%.15lf": 2.4 us per particle and frame on one core, 240 ms for
@@ -187,6 +190,76 @@ extern "C" int cpf_write_vtu_arrays(const char* path, int64_t n, const double* x
     return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
 }
 
+// ---- the same frame with the arrays RAW behind the XML ("binary-appended as an option").  Same arrays, names,
+// types and order as the ASCII file -- Position Float64 x 3, ParticleType / ParticleID / ParticleTetID / ConvexTetID Int32, vels
+// Float32 x 3 (NaN -> 0), KEs Float32, connectivity / offsets Int32, types UInt8 -- as DataArrays with format='appended' and an
+// offset into one <AppendedData encoding='raw'> section: per array a UInt64 byte count, then the bytes (little endian).  Nothing to
+// format: 1e5 particles are 6 MB instead of 9 MB of text and take a memcpy's time instead of 60-80 ms.  ParaView / VTK read both.
+extern "C" int cpf_write_vtu_arrays_binary(const char* path, int64_t n, const double* xyzw, const int32_t* cell,
+                                           const double* vel, double* totalKE) {
+    if (!path || n < 0 || n > 0x7fffffffLL || (n > 0 && (!xyzw || !cell || !vel))) return CPF_ERR_ARG;
+    FILE* fp = std::fopen(path, "wb");
+    if (!fp) return CPF_ERR_ARG;
+    const size_t N = (size_t)n;
+    struct Arr { const char* name; const char* type; int comps; size_t bytes; };
+    const Arr arrs[] = {{"Position", "Float64", 3, N * 24}, {"ParticleType", "Int32", 1, N * 4}, {"ParticleID", "Int32", 1, N * 4},
+                        {"ParticleTetID", "Int32", 1, N * 4}, {"ConvexTetID", "Int32", 1, N * 4}, {"vels", "Float32", 3, N * 12},
+                        {"KEs", "Float32", 1, N * 4}, {"connectivity", "Int32", 1, N * 4}, {"offsets", "Int32", 1, N * 4},
+                        {"types", "UInt8", 1, N}};
+    unsigned long long off[10], o = 0;
+    for (int k = 0; k < 10; ++k) { off[k] = o; o += 8 + arrs[k].bytes; }
+    auto decl = [&](int k) {
+        std::fprintf(fp, "<DataArray NumberOfComponents='%d' type='%s' Name='%s' format='appended' offset='%llu'/>\n", arrs[k].comps,
+                     arrs[k].type, arrs[k].name, off[k]);
+    };
+    std::fprintf(fp, "<VTKFile type='UnstructuredGrid' version='1.0' byte_order='LittleEndian' header_type='UInt64'>\n");
+    std::fprintf(fp, "<UnstructuredGrid>\n<Piece NumberOfCells='%lld' NumberOfPoints='%lld'>\n<Points>\n", (long long)n, (long long)n);
+    decl(0);
+    std::fprintf(fp, "</Points>\n<PointData>\n");
+    for (int k = 1; k <= 6; ++k) decl(k);
+    std::fprintf(fp, "</PointData>\n<Cells>\n");
+    for (int k = 7; k <= 9; ++k) decl(k);
+    std::fprintf(fp, "</Cells>\n</Piece>\n</UnstructuredGrid>\n<AppendedData encoding='raw'>\n_");
+    bool ok = true;
+    auto block = [&](const void* data, size_t bytes) {
+        const unsigned long long nb = bytes;
+        ok = ok && std::fwrite(&nb, 8, 1, fp) == 1 && (bytes == 0 || std::fwrite(data, 1, bytes, fp) == bytes);
+    };
+    std::vector<double> pos(N * 3);
+    std::vector<int32_t> i32(N);
+    std::vector<float> f32(N * 3);
+    for (size_t i = 0; i < N; ++i) { pos[3 * i] = xyzw[4 * i]; pos[3 * i + 1] = xyzw[4 * i + 1]; pos[3 * i + 2] = xyzw[4 * i + 2]; }
+    block(pos.data(), N * 24);
+    for (size_t i = 0; i < N; ++i) i32[i] = (int32_t)xyzw[4 * i + 3];
+    block(i32.data(), N * 4);
+    for (size_t i = 0; i < N; ++i) i32[i] = (int32_t)i;
+    block(i32.data(), N * 4);
+    block(cell, N * 4); block(cell, N * 4);
+    double total = 0.0;
+    std::vector<float> ke(N);
+    for (size_t i = 0; i < N; ++i) {
+        const bool nan = std::isnan(vel[4 * i]);
+        for (int c = 0; c < 3; ++c) f32[3 * i + c] = nan ? 0.0f : (float)vel[4 * i + c];
+        const double e = 0.5 * (vel[4 * i] * vel[4 * i] + vel[4 * i + 1] * vel[4 * i + 1] + vel[4 * i + 2] * vel[4 * i + 2]);
+        ke[i] = (float)e;
+        total += e;                                                      // in index order, like the reference's running sum
+    }
+    block(f32.data(), N * 12);
+    block(ke.data(), N * 4);
+    for (size_t i = 0; i < N; ++i) i32[i] = (int32_t)i;
+    block(i32.data(), N * 4);
+    for (size_t i = 0; i < N; ++i) i32[i] = (int32_t)(i + 1);
+    block(i32.data(), N * 4);
+    std::vector<unsigned char> types(N, 1);
+    block(types.data(), N);
+    std::fprintf(fp, "\n</AppendedData>\n</VTKFile>\n");
+    const bool bad = !ok || std::ferror(fp) != 0;
+    std::fclose(fp);
+    if (totalKE) *totalKE = total;
+    if (bad) return CPF_ERR_ARG;
+    return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
+}
+
 extern "C" int cpf_write_vtu(cpf_context* ctx, const char* path, double* totalKE) {
     if (!ctx || !path) return CPF_ERR_ARG;
     int64_t n = 0;
@@ -196,5 +269,6 @@ extern "C" int cpf_write_vtu(cpf_context* ctx, const char* path, double* totalKE
     std::vector<int32_t> cell((size_t)n);
     r = cpf_get_particles(ctx, xyzw.data(), cell.data(), vel.data());
     if (r) return r;
-    return cpf_write_vtu_arrays(path, n, xyzw.data(), cell.data(), vel.data(), totalKE);
+    const bool binary = cpf::vtu_binary(ctx);              // cpf_set_option "vtu_binary"
+    return (binary ? cpf_write_vtu_arrays_binary : cpf_write_vtu_arrays)(path, n, xyzw.data(), cell.data(), vel.data(), totalKE);
 }

@@ -241,6 +241,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
+ *   "vtu_binary"    (0) 1: cpf_write_vtu / cpf_write_vtu_async write frames with raw appended arrays (cpf_write_vtu_arrays_binary)
+ *                   instead of the reference's ASCII layout; the replacement fragments set it from the dictionary key binaryFrames
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference
  *                   has no such diagnostics, and they cost the step kernel a resident wave (0.16 -> 0.22 ms
  *                   per 1e7-particle launch)
@@ -375,6 +377,13 @@ int cpf_write_vtu_wait(cpf_context* ctx);
 /* same formatter on host arrays: xyzw [n][4], cell [n], vel [n][4] */
 int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const int32_t* cell, const double* vel,
                          double* totalKE);
+/* The same frame with its arrays RAW behind the XML ("binary-appended as an option"): the same DataArrays --
+ * names, types, components, order -- with format='appended' and offsets into one <AppendedData encoding='raw'> section (per
+ * array a UInt64 byte count, then little-endian bytes).  Not the reference's bytes (its writer is ASCII only, cuda/utils.cpp:
+ * 144-283), the same data: positions exact instead of 15 decimals.  cpf_set_option(ctx, "vtu_binary", 1) makes cpf_write_vtu /
+ * cpf_write_vtu_async write this form. */
+int cpf_write_vtu_arrays_binary(const char* path, int64_t n, const double* xyzw, const int32_t* cell, const double* vel,
+                                double* totalKE);
 
 /* ---------------------------------------------------------------------------------------------
  * measurement

@@ -1019,6 +1019,17 @@ def test_async_vtu_frame_is_a_snapshot(setup, gpu_ctx_factory, tmp_path):
     b = open(tmp_path / "async_b.vtu", "rb").read()
     assert b != a and b.endswith(b"</VTKFile>\n") and ke_b != ke_sync
     ctx.write_vtu_wait()                                             # idempotent
+    # option "vtu_binary": the same frames with raw appended arrays -- what the cloud holds, exactly
+    from test_vtu_writer import _read_appended
+    ctx.set_option("vtu_binary", 1)
+    ke_bin = ctx.write_vtu_async(tmp_path / "bin.vtu")
+    ctx.write_vtu_wait()
+    xyzw, cell = ctx.get_particles()
+    d = _read_appended(tmp_path / "bin.vtu")
+    assert ke_bin == ke_b and np.array_equal(d["Position"], xyzw[:, :3]) and np.array_equal(d["ConvexTetID"], cell)
+    assert np.array_equal(d["ParticleType"], xyzw[:, 3].astype(np.int32)) and (np.abs(d["vels"]).max(0)[:2] > 0).all()
+    ctx.write_vtu(tmp_path / "bin_sync.vtu")
+    assert open(tmp_path / "bin_sync.vtu", "rb").read() == open(tmp_path / "bin.vtu", "rb").read()
 
 
 @pytest.mark.parametrize("n_parts", [2, 5])

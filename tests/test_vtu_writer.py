@@ -102,3 +102,67 @@ def test_unwritable_path_is_an_error(tmp_path):
     x = np.zeros((1, 4)); c = np.zeros(1, np.int32)
     r, _ = _write(tmp_path / "no_such_dir" / "p.vtu", x, c, x)
     assert r == L.CPF_ERR_ARG
+
+
+def _read_appended(path):
+    """Minimal reader of a VTU with raw appended data (header_type UInt64): {array name: numpy array}."""
+    raw = open(path, "rb").read()
+    k = raw.index(b"<AppendedData encoding='raw'>")
+    head = raw[:k].decode()
+    start = raw.index(b"_", k) + 1
+    np_type = {"Float64": np.float64, "Float32": np.float32, "Int32": np.int32, "UInt8": np.uint8}
+    out = {}
+    for line in head.split("\n"):
+        if not line.startswith("<DataArray"):
+            continue
+        a = {kv.split("=")[0]: kv.split("=")[1].strip("'/>") for kv in line[len("<DataArray "):].split(" ")}
+        assert a["format"] == "appended"
+        off = start + int(a["offset"])
+        nbytes = int(np.frombuffer(raw[off:off + 8], np.uint64)[0])
+        arr = np.frombuffer(raw[off + 8:off + 8 + nbytes], np_type[a["type"]])
+        comps = int(a["NumberOfComponents"])
+        out[a["Name"]] = arr.reshape(-1, comps) if comps > 1 else arr
+    assert raw.rstrip().endswith(b"</VTKFile>") and b"NumberOfCells='%d' NumberOfPoints='%d'" % (len(out["types"]), len(out["types"])) in raw
+    return out
+
+
+def test_binary_appended_frame_holds_the_ascii_frames_data(tmp_path):
+    """"binary-appended as an option".  cpf_write_vtu_arrays_binary writes the same DataArrays -- names, types,
+    components, order -- with format='appended' and raw little-endian blocks; read back, they are the inputs exactly (positions
+    to the last bit, where the ASCII frame has 15 decimals), and what the ASCII frame of the same particles says."""
+    lib = L.load()
+    rng = np.random.default_rng(8)
+    n = 3001
+    xyzw = np.concatenate([rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-6, 3, size=(n, 1)), np.ones((n, 1))], 1)
+    xyzw[::5, 3] = 0.0
+    cell = rng.integers(-3, 12225, size=n).astype(np.int32)
+    vel = np.concatenate([rng.normal(size=(n, 3)) * 3.0, np.zeros((n, 1))], 1)
+    vel[11, 0] = np.nan                                           # "vels" prints / stores 0 0 0 there, the energy is NaN
+    ke = C.c_double()
+    b = tmp_path / "frame_bin.vtu"
+    r = lib.cpf_write_vtu_arrays_binary(str(b).encode(), n, xyzw.ctypes.data, cell.ctypes.data, vel.ctypes.data, C.byref(ke))
+    assert r == L.CPF_ERR_STATE and np.isnan(ke.value)            # like the ASCII writer: NaN energy is reported, the file is written
+    vel[11, 0] = 0.25
+    r = lib.cpf_write_vtu_arrays_binary(str(b).encode(), n, xyzw.ctypes.data, cell.ctypes.data, vel.ctypes.data, C.byref(ke))
+    assert r == 0
+    d = _read_appended(b)
+    assert list(d) == ["Position", "ParticleType", "ParticleID", "ParticleTetID", "ConvexTetID", "vels", "KEs", "connectivity",
+                       "offsets", "types"]
+    assert np.array_equal(d["Position"], xyzw[:, :3]) and np.array_equal(d["ParticleType"], xyzw[:, 3].astype(np.int32))
+    assert np.array_equal(d["ParticleID"], np.arange(n)) and np.array_equal(d["ParticleTetID"], cell) and np.array_equal(d["ConvexTetID"], cell)
+    assert np.array_equal(d["vels"], vel[:, :3].astype(np.float32))
+    e = 0.5 * (vel[:, :3] ** 2).sum(1)
+    assert np.array_equal(d["KEs"], e.astype(np.float32)) and abs(ke.value - e.sum()) < 1e-9 * e.sum()
+    assert np.array_equal(d["connectivity"], np.arange(n)) and np.array_equal(d["offsets"], np.arange(1, n + 1)) and (d["types"] == 1).all()
+    # against the ASCII frame of the same particles
+    a = tmp_path / "frame_ascii.vtu"
+    r, ke_a = _write(a, xyzw, cell, vel)
+    assert r == 0 and ke_a == ke.value
+    sec, _ = _sections(open(a).read())
+    pos_a = np.array([[float(v) for v in ln.split()] for ln in sec["Position"] if ln])
+    assert (np.abs(pos_a - d["Position"]) <= 5.01e-16 + 2.3e-16 * np.abs(d["Position"])).all()     # 15 decimals + the parse's rounding
+    assert [int(v) for v in sec["ConvexTetID"] if v] == list(d["ConvexTetID"])
+    assert os.path.getsize(b) < os.path.getsize(a)
+    # empty cloud: a valid file with empty blocks
+    r = lib.cpf_write_vtu_arrays_binary(str(b).encode(), 0, None, None, None, C.byref(ke))
+    assert r == 0 and len(_read_appended(b)["types"]) == 0
