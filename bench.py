@@ -496,10 +496,20 @@ class GpuMachine:
                       "Mparticle_steps_per_s": round(na * args.anchor_steps / ta / 1e6, 1),
                       "note": "one GPU, no sharding, no hand-off: divide the --gpus N value by this for the strong-scaling ratio"}
             del ax, ay, az, ac, ag
+        # (an extra that fails must not take the headline line with it: its key then holds the error)
         more = {}
-        more["brownian_steady"] = self._brownian_steady(cloud, dt, args, box)
-        more["analytic_field"] = self._analytic_field(cloud, dt, args, box)
-        more["tjunction_as_run"] = self._tjunction_as_run(dt, args)
+        for key, fn in (("brownian_steady", lambda: self._brownian_steady(cloud, dt, args, box)),
+                        ("analytic_field", lambda: self._analytic_field(cloud, dt, args, box)),
+                        ("tjunction_as_run", lambda: self._tjunction_as_run(dt, args))):
+            try:
+                more[key] = fn()
+            except Exception as e:                                   # noqa: BLE001
+                more[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                if key == "analytic_field":                          # the field must not stay switched
+                    try:
+                        ctx.set_velocity(self._case[1])
+                    except Exception:                                # noqa: BLE001
+                        pass
         return brown, fused, steady, anchor, more
 
     # ---- what the tutorials actually run (never `value`)
