@@ -4,7 +4,8 @@
 #   tools/ab.sh [-r REPS] [-l "name1 name2 ..."] -- <command ...>
 # runs the command REPS times (default 2, alternating) per build_ab/lib_<name>.so (all of them unless -l names some;
 # "product" = the library in place) and prefixes every JSON line of its output with the library's name.
-# Libraries come from tools/build_ab.sh.
+# Libraries come from tools/build_ab.sh.  Every run of the command is under `timeout` (AB_TIMEOUT seconds, default 300): an
+# experimental kernel that never finishes must cost its own limit, not the call's.
 cd "$(dirname "$0")/.." || exit 1
 REPS=2; NAMES=""
 while [ $# -gt 0 ]; do
@@ -16,7 +17,7 @@ cp $LIB /tmp/lib_orig.so
 for rep in $(seq 1 "$REPS"); do
   for name in $NAMES; do
     if [ "$name" = product ]; then cp /tmp/lib_orig.so $LIB; else cp "build_ab/lib_$name.so" $LIB || continue; fi
-    "$@" 2>/tmp/ab_err.log | grep '^{' | sed "s/^/$name: /" || tail -3 /tmp/ab_err.log
+    timeout -s KILL ${AB_TIMEOUT:-300} "$@" 2>/tmp/ab_err.log | grep '^{' | sed "s/^/$name: /" || tail -3 /tmp/ab_err.log
   done
 done
 cp /tmp/lib_orig.so $LIB
