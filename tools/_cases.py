@@ -1,7 +1,8 @@
 """Developer tools (GPU box): the synthetic cases the tools share -- one place for mesh, field and cloud set-up.
   pitz       pitzDaily 12 225 cells (x-slab numbering), uniform (10,0,0) or the analytic step flow
   box3d      graded 64 x 64 x 60 box = 245 760 hex cells (records 63 MB: beyond L2), diagonal / swirl fields; CPF_BOX_N=a,b,c resizes
-  tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5)
+  tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5), cloud over the whole T
+  tjunction_run   ... seeded as the tutorial's dictionary does: in the first 50 mm of the inlet duct
   octagons / pentagons / dodecagons / hexgrid   300 x 200 x 4 unit cells (cases/polygons.py): every ninth square an octagonal prism
              (10 planes: two-record cells) / every square with a cut corner (half the cells 7 planes) / every ninth a dodecagonal
              prism (14 planes: header records) / the all-hex box of about the same cell count; dt = 0.1 (POLY_DT)
@@ -48,6 +49,15 @@ def make_case(name, ctx, torch, n, dev, field=None, seed=7):
         x, y, z, c = bench.seed_in_fluid(ctx, torch, n, (lo3, hi3), 1000, dev)
         return mesh, x, y, z, c, fields
     torch.manual_seed(seed)
+    if name == "tjunction_run":
+        # the tutorial as its dictionary seeds it: all particles in the first 50 mm of the inlet duct (200 per cell at 4e6)
+        import bench
+        from cudaparticlesfoam_amd.cases import tjunction as tj
+        mesh = tj.tjunction_mesh(); cc, _ = mesh.cell_centres_volumes()
+        fields = {"u0=3": tj.split_flow_u(mesh, cc, 0.5)}
+        ctx.set_mesh(mesh); ctx.set_velocity(fields["u0=3"])
+        x, y, z, c = bench.seed_in_fluid(ctx, torch, n, tj.PARTICLE_DICT["seedingBox"], 2027, dev)
+        return mesh, x, y, z, c, fields
     if name == "tjunction":
         from cudaparticlesfoam_amd.cases import tjunction as tj
         mesh = tj.tjunction_mesh(); cc, _ = mesh.cell_centres_volumes()
