@@ -99,6 +99,8 @@ class CpuMachine:
 
 def main():
     args = bench.parse(sys.argv[1:])
+    # (like bench.main: ranks started by somebody else's launcher carry their own watchdog)
+    dog = bench.rank_watchdog(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
     bench.stage("rccl_init")
     if os.environ.get("BENCH_TEST_HANG_RANK") == os.environ.get("RANK"):
         import time
@@ -107,6 +109,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == args.gpus
     out = bench.run(args, CpuMachine(rank, world))
+    if dog is not None:
+        dog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

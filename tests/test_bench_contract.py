@@ -101,6 +101,26 @@ def test_a_rank_that_hangs_becomes_an_error_line_within_the_limit():
     assert "_bench_worker.py" not in ps, ps
 
 
+def test_ranks_under_a_foreign_launcher_watch_themselves():
+    """The driver starts N > 1 ranks with its own `torch.distributed.run`: no parent of ours watches them.  Every rank arms a timer
+    (bench.rank_watchdog); here rank 1 never reaches the rendezvous, rank 0 waits in it -- when the timers fire rank 0 prints the
+    error line (stage: rccl_init) and every rank leaves with 124, so the launcher returns non-zero instead of hanging."""
+    import socket
+    import time
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_bench_worker.py"), "--gpus", "2", "--particles", "2000",
+           "--steps", "2", "--warmup", "1", "--launch-timeout", "20"]
+    env = dict(os.environ, BENCH_TEST_HANG_RANK="1", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and 20 <= time.time() - t0 < 120
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["stage"] == "rccl_init" and d["n_gpus"] == 2 and "watchdog" in d["error"]
+
+
 def test_self_launched_cpu_ranks_forward_one_json_line():
     """The same launcher on the happy path (CPU stand-in, gloo world 2): rank 0's line is the parent's only stdout line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
