@@ -128,7 +128,8 @@ size_t sort_scratch_bytes(int64_t n, int endBit);
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox = nullptr, double* oy = nullptr, double* oz = nullptr,
-                        int32_t* ocell = nullptr, int64_t* ogid = nullptr, unsigned long long* occupied = nullptr);
+                        int32_t* ocell = nullptr, int64_t* ogid = nullptr, unsigned long long* occupied = nullptr,
+                        const int32_t* rank = nullptr);
 
 // multi-GPU hand-off (cpf_handoff.hip)
 size_t handoff_scratch_bytes(int64_t n, int nRanks);

@@ -33,6 +33,7 @@ struct HostTables {
     bool zThin = false;             // zPairLast and the two z faces of every cell are boundary faces (one cell thick in z)
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
+    std::vector<int32_t> curveRank; // [nCells]     rank of the cell along a Morton curve through the cell boxes' centres (sort key of sparse clouds)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes
     // from most to least significant (the longest domain axis first)
     int32_t subBits[3] = {2, 2, 2}, subOrder[3] = {0, 1, 2};

@@ -858,14 +858,15 @@ __global__ __launch_bounds__(kBlock) void gather_all_kernel(const double* __rest
                                                             const int32_t* __restrict__ cell, const int64_t* __restrict__ gid,
                                                             double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
                                                             int32_t* __restrict__ ocell, int64_t* __restrict__ ogid,
-                                                            const int32_t* __restrict__ perm, const uint32_t* __restrict__ keys, int nSub, int64_t n) {
+                                                            const int32_t* __restrict__ perm, const uint32_t* __restrict__ keys, int nSub, int64_t n,
+                                                            bool cellFromKey) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int64_t j = perm[i];
     const uint32_t k = keys[i];
     const double a = x[j], b = y[j], c = z[j];
     const int64_t g = gid ? gid[j] : 0;
-    const int32_t cc = k != 0xFFFFFFFFu ? (int32_t)(k >> nSub) : cell[j];
+    const int32_t cc = (cellFromKey && k != 0xFFFFFFFFu) ? (int32_t)(k >> nSub) : cell[j];
     ox[i] = a; oy[i] = b; oz[i] = c;
     ocell[i] = cc;
     if (gid) ogid[i] = g;
@@ -1015,7 +1016,7 @@ hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n,
 struct SubKey { int bits[3]; int order[3]; };
 __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                  const double* __restrict__ z, const int32_t* __restrict__ cell,
-                                 const float* __restrict__ cellBox, SubKey sk, int subBits,
+                                 const float* __restrict__ cellBox, const int32_t* __restrict__ rank, SubKey sk, int subBits,
                                  uint32_t* __restrict__ keys, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -1030,7 +1031,8 @@ __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __r
         const int q = min((1 << sk.bits[a]) - 1, max(0, (int)(a == 0 ? r[0] : (a == 1 ? r[1] : r[2]))));
         sub = (sub << sk.bits[a]) | (uint32_t)q;
     }
-    keys[i] = ((uint32_t)c << subBits) | sub;
+    // (rank: the cell's place along the mesh layer's Morton curve instead of its id -- sparse clouds, see sort_by_cell)
+    keys[i] = ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
 }
 
 size_t sort_scratch_bytes(int64_t n, int endBit) {
@@ -1067,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void count_cell_runs_kernel(const uint32_t*
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox, double* oy, double* oz, int32_t* ocell,
-                        int64_t* ogid, unsigned long long* occupied) {
+                        int64_t* ogid, unsigned long long* occupied, const int32_t* rank) {
     if (n <= 1) return hipSuccess;
     SubKey sk;
     for (int k = 0; k < 3; ++k) { sk.bits[k] = subBits[k]; sk.order[k] = subOrder[k]; }
@@ -1085,7 +1087,7 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     double* stage = (double*)p; p += al(24 * (size_t)n);
     if ((size_t)(p - (char*)scratch) > scratchBytes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(kBlock), 0, st, idx, n);
-    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, sk, nSub, keysIn, n);
+    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, rank, sk, nSub, keysIn, n);
     // endBit covers the cell bits + sub-cell bits; the all-ones key of lost/frozen particles sorts last
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keysIn, keysOut, idx, perm, (int)n, 0, endBit, st);
     if (e != hipSuccess) return e;
@@ -1099,7 +1101,8 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, ox, oy, oz, perm, n);
         hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, ocell, ogid, perm, n);
 #else
-        hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n);
+        hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n,
+                           rank == nullptr);
 #endif
     } else {
         double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;          // the 24n-byte staging area

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace cpf {
 namespace {
@@ -290,6 +291,25 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
             const int k = order[r];
             out.subOrder[r] = k;
             out.subBits[k] = thin[k] ? 0 : (nThick == 3 ? 2 : (nThick == 2 ? (r == 0 ? 2 : 5) : 7));
+        }
+        // Rank of every cell along a Morton curve through the centres of the cell boxes (10 bits per axis): the sort key of SPARSE
+        // clouds (fewer than 8 particles per cell), where the step kernel is bound by record traffic and a cloud ordered along the
+        // curve has a cell's neighbours in all three directions close by -- not just the one the mesh numbers along.
+        {
+            std::vector<std::pair<uint32_t, int32_t>> code((size_t)nCells);
+            auto spread = [](uint32_t v) { v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
+            for (int64_t c = 0; c < nCells; ++c) {
+                uint32_t q[3];
+                for (int k = 0; k < 3; ++k) {
+                    const double mid = 0.5 * (bmin[3 * c + k] + bmax[3 * c + k]);
+                    const double t = dext[k] > 0.0 ? (mid - out.lo[k]) / dext[k] : 0.0;
+                    q[k] = (uint32_t)std::min(1023.0, std::max(0.0, t * 1024.0));
+                }
+                code[(size_t)c] = {spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2), (int32_t)c};
+            }
+            std::sort(code.begin(), code.end());
+            out.curveRank.resize((size_t)nCells);
+            for (int64_t r = 0; r < nCells; ++r) out.curveRank[(size_t)code[(size_t)r].second] = (int32_t)r;
         }
         out.cellBox.resize((size_t)nCells * 6);
         for (int64_t c = 0; c < nCells; ++c)

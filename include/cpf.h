@@ -241,6 +241,10 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   "stream_debug" is a diagnostic (results are WRONG when non-zero)
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
+ *   "sort_curve"    (-1) the sort's major key: 0 = the cell id, 1 = the cell's rank along a Morton curve through the cell centres
+ *                   (built at cpf_set_mesh), -1 = the rank for sparse clouds (fewer than 8 particles per cell: the step kernel is
+ *                   bound by record traffic there and a cell's neighbours in all three directions should be close by in the
+ *                   sorted cloud), the id otherwise.  Results do not depend on the order
  *   "vtu_binary"    (0) 1: cpf_write_vtu / cpf_write_vtu_async write frames with raw appended arrays (cpf_write_vtu_arrays_binary)
  *                   instead of the reference's ASCII layout; the replacement fragments set it from the dictionary key binaryFrames
  *   "stats"         1 accumulate the cpf_get_counters statistics, 0 (default) skip that work: the reference

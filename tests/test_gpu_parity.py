@@ -1142,3 +1142,52 @@ def test_stored_velocity_of_particles_lost_during_a_fused_launch(setup, gpu_ctx_
         assert np.array_equal(c < 0, lost) and np.array_equal(x, outs[0][0])
         assert np.array_equal(v, outs[0][2])
     assert (outs[0][2][lost][:, 0] == 10.0).all()                 # the lost ones carry the velocity of their last live cycle
+
+
+def test_sparse_clouds_are_sorted_along_the_morton_curve(gpu_ctx_factory, oracle_libs):
+    """Fewer than 8 particles per cell (the regime of the streaming kernel's LOOKUP 4): the sort's major key is the cell's rank along
+    a Morton curve through the cell centres instead of its id (option "sort_curve": -1 by regime, 0 id, 1 rank).  Equal cells stay
+    contiguous, the curve keeps spatial neighbours close in all three directions, and -- the order being invisible to the walk --
+    every particle equals the CPU statement bit for bit whichever key sorted the cloud."""
+    import torch
+    from cudaparticlesfoam_amd.cases import box_mesh
+    mesh = box_mesh(24, 20, 16, upper=(2.4, 2.0, 1.6), grading=(2.0, 1.0, 0.5))
+    cc, _ = mesh.cell_centres_volumes()
+    rng = np.random.default_rng(5)
+    U = np.stack([1.0 + 0 * cc[:, 0], 0.6 * np.sin(3 * cc[:, 2]), 0.6 * np.cos(3 * cc[:, 1])], 1)
+    n = 3 * mesh.n_cells                                           # 3 particles per cell: sparse
+    xyz = rng.uniform([0, 0, 0], [2.4, 2.0, 1.6], size=(n, 3))
+    cw = oracle_libs.CellWalk(); t = cw.build(mesh)
+    x, y, z = (xyz[:, k].copy() for k in range(3))
+    c = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
+    cw.step(x, y, z, c, 0.05, 15, t, U, nthreads=cw.max_threads)
+    dev = torch.device("cuda", 0)
+    orders = {}
+    for curve in (-1, 0, 1):
+        ctx = gpu_ctx_factory()
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_option("sort_curve", curve)
+        ctx.set_mesh(mesh); ctx.set_velocity(U)
+        tx, ty, tz = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+        tc = torch.empty(n, dtype=torch.int32, device=dev); tg = torch.arange(n, dtype=torch.int64, device=dev)
+        p = lambda a: a.data_ptr()   # noqa: E731
+        ctx.locate_initial_dev(p(tx), p(ty), p(tz), p(tc), n)
+        o = [torch.empty_like(a) for a in (tx, ty, tz, tc, tg)]
+        ctx.sort_by_cell_dev_to(p(tx), p(ty), p(tz), p(tc), p(tg), *[p(a) for a in o], n)
+        tx, ty, tz, tc, tg = o
+        cells0 = tc.cpu().numpy()
+        change = np.nonzero(np.diff(cells0))[0]
+        assert len(set(cells0[np.r_[0, change + 1]])) == len(change) + 1                     # every cell is ONE contiguous run
+        orders[curve] = cells0
+        ctx.step_dev(p(tx), p(ty), p(tz), p(tc), None, None, n, 0.05, 0.0, 0, 15, 0)
+        assert ", 4>" in ctx.step_kernel_name(0.0, 0)
+        g = tg.cpu().numpy()
+        assert np.array_equal(tc.cpu().numpy(), c[g]) and np.array_equal(tx.cpu().numpy(), x[g])
+        assert np.array_equal(ty.cpu().numpy(), y[g]) and np.array_equal(tz.cpu().numpy(), z[g])
+    assert np.array_equal(orders[-1], orders[1]) and not np.array_equal(orders[0], orders[1])   # sparse: the curve is the default
+    assert (np.diff(orders[0]) >= 0).all()                                                     # key 0: ascending cell ids
+    # along the curve consecutive cells are spatial neighbours far more often than along the ids in y and z
+    def jump(cells):
+        d = np.abs(np.diff(cc[cells], axis=0))
+        return np.median(d[np.diff(cells) != 0], axis=0)
+    assert jump(orders[1])[1:].max() < 0.6 * max(jump(orders[0])[1:].max(), 1e-9) or jump(orders[1]).sum() < jump(orders[0]).sum()
