@@ -69,7 +69,7 @@ class ThreadComm:
 
 
 def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, overlap, balance_by_time, capacity,
-                   dt=1e-4):
+                   dt=1e-4, world=2):
     import torch
     from cudaparticlesfoam_amd.api import Context
     from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges, x_slab_renumbering
@@ -82,7 +82,6 @@ def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, ov
     xyz = pz.uniform_points(321, n_total, *pz.DOMAIN_BOX)
     x, y, z = (xyz[:, k].copy() for k in range(3))
     cell = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
-    world = 2
     comm = ThreadComm(world)
     cell_lo = slab_cell_ranges(vols, world)
     dev = torch.device("cuda", 0)
@@ -174,3 +173,17 @@ def test_two_ranks_overlap_depth_derived_per_rank(pitz, oracle_libs):
                                balance_by_time=True, capacity=400_000 + 64)
     assert all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
     assert sum(o["n"] for o in out) == 400_000
+
+
+def test_four_ranks_as_threads_on_one_gpu(pitz, oracle_libs):
+    """Four ranks (four contexts, streams and shards on ONE GPU, the collectives through the in-process stand-in): a four-way
+    all-to-all with real leavers out of the HIP split kernels, re-cut every 6 steps by measured time, overlap depth derived per
+    rank -- bit-identical to one process, every rank ending inside its own cut."""
+    out, cell = _run_two_ranks(pitz, oracle_libs, n_total=600_000, steps=24, rebalance=6, exchange=0, overlap=-1,
+                               balance_by_time=True, capacity=600_000 + 64, world=4)
+    assert len(out) == 4 and all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
+    assert sum(o["n"] for o in out) == 600_000 and min(o["n"] for o in out) > 50_000
+    lo = out[0]["cell_lo"]
+    assert all(np.array_equal(o["cell_lo"], lo) for o in out)
+    for r, o in enumerate(out):
+        assert ((o["c"] >= lo[r]) & (o["c"] < lo[r + 1]) | (o["c"] < 0)).all()
