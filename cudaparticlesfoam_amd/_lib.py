@@ -65,6 +65,7 @@ SIGNATURES = {
                                           C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     "cpf_mesh_flags_host": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cpf_mesh_box_records_host": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, C.POINTER(C.c_int32), _vp]),
     "cpf_set_velocity": (_int, [_ctx, _vp, _i64]),
     "cpf_set_velocity_dev": (_int, [_ctx, _vp, _i64]),
     "cpf_alloc_particles": (_int, [_ctx, _i64]),

@@ -292,6 +292,22 @@ def mesh_flags_host(mesh):
     return dict(all_hex=v[0].value, z_layered=v[1].value, z_thin=v[2].value, mixed=v[3].value)
 
 
+def mesh_box_records_host(mesh):
+    """The mesh's box records ([n_cells, 16] float64; ``cpf_mesh_box_records_host``), or None if some cell is not an axis-aligned
+    box.  Layout: csrc/cpf_walk.h "box records"."""
+    lib = L.load()
+    a = [np.ascontiguousarray(mesh.points, dtype=np.float64), np.ascontiguousarray(mesh.face_offsets, dtype=np.int32),
+         np.ascontiguousarray(mesh.face_verts, dtype=np.int32), np.ascontiguousarray(mesh.owner, dtype=np.int32),
+         np.ascontiguousarray(mesh.neighbour, dtype=np.int32)]
+    is_box = C.c_int32(0)
+    rec = np.zeros((mesh.n_cells, 16), np.float64)
+    st = lib.cpf_mesh_box_records_host(_ptr(a[0]), mesh.n_points, _ptr(a[1]), _ptr(a[2]), mesh.n_faces, _ptr(a[3]), _ptr(a[4]),
+                                       mesh.n_internal, mesh.n_cells, C.byref(is_box), _ptr(rec))
+    if st != L.CPF_OK:
+        raise L.CpfError(st, "cpf_mesh_box_records_host")
+    return rec if is_box.value else None
+
+
 def pack_mesh_parts(parts):
     """(ctypes array of cpf_mesh_part, the numpy arrays it points into)."""
     arr = (L.MeshPart * len(parts))()

@@ -30,6 +30,8 @@ struct cpf_context {
     bool zFold = true;               // "z_fold": mirror the kicked end point about the planes of a one-cell-thick mesh before the walk
     double4* d_U = nullptr;
     double* d_U3 = nullptr;     // staging for host uploads
+    double* d_boxRec = nullptr;     // 128-byte box records (meshes of axis-aligned boxes with records; cpf_walk.h "box records")
+    bool boxRecords = true;         // "box_records": 0 = never use them (diagnostics; bit-identical either way)
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes; mixed meshes: cpf_walk.h "cell records")
     unsigned long long* d_occupied = nullptr;   // [0] occupied cells, [1] live particles of the last sort (device) ...
     unsigned long long* h_occupied = nullptr;   // ... and their pinned host copy (StreamState::occupiedHost)
@@ -123,6 +125,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.cellOff = c->d_cellOff; m.planes = c->d_planes; m.nbr = c->d_nbr; m.U = c->d_U;
     m.groupOff = c->d_groupOff; m.groupNbr = c->d_groupNbr;
     m.cellRec = c->d_cellRec;
+    m.boxRec = c->boxRecords ? reinterpret_cast<const double4*>(c->d_boxRec) : nullptr;
     m.nCells = (int32_t)c->host.nCells;
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
@@ -157,7 +160,7 @@ int sortEndBit(const cpf_context* ctx) {
 }
 
 void freeMesh(cpf_context* c) {
-    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_groupOff); freeDev(c->d_groupNbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_cellBox); freeDev(c->d_curveRank);
+    freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_groupOff); freeDev(c->d_groupNbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_boxRec); freeDev(c->d_cellBox); freeDev(c->d_curveRank);
     freeDev(c->d_binOff); freeDev(c->d_binCells);
     c->haveMesh = c->haveU = false; c->meshBytes = 0;
 }
@@ -206,6 +209,7 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
         CPF_HIP(ctx, cpf::launch_build_cell_records(ctx->stream, ctx->d_planes, ctx->d_nbr, ctx->d_U, ctx->d_cellRec, nCells));
         CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->meshBytes += (size_t)nCells * 256;
+        if (!h.boxRec.empty()) CPF_HIP(ctx, up(ctx->d_boxRec, h.boxRec.data(), h.boxRec.size() * 8));
     } else if (ctx->host.nHugeCells * 4 <= nCells && ctx->mixedRecords) {
         // not all-hex, but at most a quarter of the cells have more than TWELVE slots: records for the streaming kernel --
         // padded where a cell has fewer than six slots, a second record for slots 6..11 of a cell with 7..12 (true polyhedra
@@ -395,6 +399,22 @@ int cpf_mesh_flags_host(const double* points, int64_t nPoints, const int32_t* fa
     return CPF_OK;
 }
 
+int cpf_mesh_box_records_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                              int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                              int32_t* isBox, double* boxRec) {
+    if (!points || !faceOffsets || !faceVerts || !owner || (!neighbour && nInternal != 0)) return CPF_ERR_ARG;
+    cpf::HostTables t;
+    try {
+        const std::string why = cpf::build_tables<int32_t>(points, nPoints, faceOffsets, faceVerts, nFaces, owner, neighbour, nInternal, nCells, t);
+        if (!why.empty()) return CPF_ERR_MESH;
+    } catch (const std::bad_alloc&) {
+        return CPF_ERR_NOMEM;
+    }
+    if (isBox) *isBox = t.boxRec.empty() ? 0 : 1;
+    if (boxRec && !t.boxRec.empty()) std::memcpy(boxRec, t.boxRec.data(), t.boxRec.size() * 8);
+    return CPF_OK;
+}
+
 int cpf_mesh_info(const cpf_context* ctx, int64_t* nCells, int64_t* nSlots, int64_t* deviceBytes) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_mesh_info: no mesh set");
@@ -444,7 +464,7 @@ int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_U3, U, (size_t)nCells * 24, hipMemcpyHostToDevice, ctx->stream));
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, ctx->d_U3, ctx->d_U, nCells));
-    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, nCells));
+    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // U may be pageable host memory owned by the caller
     ctx->haveU = true;
     return CPF_OK;
@@ -456,7 +476,7 @@ int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells) {
     CPF_REQUIRE(ctx, dU && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity_dev: bad arguments");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, dU, ctx->d_U, nCells));
-    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, nCells));
+    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
     ctx->haveU = true;
     return CPF_OK;
 }
@@ -774,6 +794,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->mixedRecords = value != 0;
         return CPF_OK;
     }
+    if (k == "box_records") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "box_records must be 0 or 1");
+        ctx->boxRecords = value != 0;
+        return CPF_OK;
+    }
     if (k == "stream_tiles_per_chunk") {
         CPF_REQUIRE(ctx, value >= 1 && value <= 1024 && value == (int)value, CPF_ERR_ARG, "stream_tiles_per_chunk must be 1..1024");
         ctx->streamState.tilesPerChunk = (int)value;
@@ -807,7 +832,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     }
     if (k == "stream_lookup") {
         // (2, 3, 5 on an all-hex mesh: diagnostics -- what the mixed-mesh instantiations cost by themselves; same results)
-        CPF_REQUIRE(ctx, value == -1 || (value >= 0 && value <= 5 && value == (int)value), CPF_ERR_ARG, "stream_lookup must be -1 (auto) or 0 ... 5");
+        CPF_REQUIRE(ctx, value == -1 || (value >= 0 && value <= 6 && value == (int)value), CPF_ERR_ARG, "stream_lookup must be -1 (auto) or 0 ... 6");
         ctx->streamState.lookup = (int)value;
         return CPF_OK;
     }

@@ -21,6 +21,7 @@ struct MeshView {
     const int32_t* groupNbr;
     const double4* U;         // [nCells]   cell-constant velocity, w unused (32-B aligned gathers)
     const double4* cellRec;   // [nCells][8] packed 256-B records (null: generic walk only); layout: cpf_walk.h "cell records"
+    const double4* boxRec;    // [nCells][4] 128-B box records (null: some cell is not an axis-aligned box); cpf_walk.h "box records"
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s) and there are no face groups
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
@@ -70,7 +71,7 @@ struct StreamState {
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
-int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records, 6 fixed compare + box records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 8;       // fused launches of this many cycles or more run the wave-cooperative kernel (round 3: the
@@ -103,7 +104,7 @@ hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, cons
                                      double4* rec, int64_t nCells);
 hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
                                            const double4* U, const int32_t* recB, double4* rec, int64_t nCells);
-hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells);
+hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, double* box, int64_t nCells);
 hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
 
 // stage-by-stage kernels on the reference's AoS layouts

@@ -32,6 +32,10 @@ struct HostTables {
     int64_t nGroups() const { return (int64_t)groupOff.size() - 1; }
     bool zThin = false;             // zPairLast and the two z faces of every cell are boundary faces (one cell thick in z)
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
+    // [nCells][16] BOX RECORDS, or empty: every cell is an axis-aligned box (six planes with normals exactly +-e_x, +-e_y,
+    // +-e_z, one of each: blockMesh cases such as the TJunction tutorial) -- 128 bytes per cell instead of the 256-byte
+    // record, and a face test that never touches a normal.  Layout and the exactness argument: cpf_walk.h "box records"
+    std::vector<double> boxRec;
     std::vector<float> cellBox;     // [nCells][6]  AABB lower corner and 2^subBits/extent per axis (sub-cell sort key)
     std::vector<int32_t> curveRank; // [nCells]     rank of the cell along a Morton curve through the cell boxes' centres (sort key of sparse clouds)
     // sub-cell sort key layout: bits per axis (0 for an axis in which the mesh is one cell thick) and the axes

@@ -953,9 +953,14 @@ __global__ void build_cell_records_mixed_kernel(const int32_t* __restrict__ cell
         nb2[6] = 0; nb2[7] = 0;
     }
 }
-__global__ void update_record_velocity_kernel(const double4* __restrict__ U, double4* __restrict__ rec, int64_t nCells) {
+// (box: the mesh's box records, or null -- U sits in doubles 10..12 of each, cpf_walk.h "box records")
+__global__ void update_record_velocity_kernel(const double4* __restrict__ U, double4* __restrict__ rec, double* __restrict__ box,
+                                              int64_t nCells) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (c < nCells) rec[8 * c + 6] = U[c];
+    if (c >= nCells) return;
+    const double4 u = U[c];
+    rec[8 * c + 6] = u;
+    if (box != nullptr) { box[16 * c + 10] = u.x; box[16 * c + 11] = u.y; box[16 * c + 12] = u.z; }
 }
 __global__ void count_negative_kernel(const int32_t* __restrict__ cell, int64_t n, unsigned long long* out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -996,8 +1001,8 @@ hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOf
     if (nCells > 0) hipLaunchKernelGGL(build_cell_records_mixed_kernel, grid_for(nCells), dim3(kBlock), 0, st, cellOff, planes, nbr, U, recB, rec, nCells);
     return hipGetLastError();
 }
-hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, int64_t nCells) {
-    if (nCells > 0) hipLaunchKernelGGL(update_record_velocity_kernel, grid_for(nCells), dim3(kBlock), 0, st, U, rec, nCells);
+hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, double* box, int64_t nCells) {
+    if (nCells > 0) hipLaunchKernelGGL(update_record_velocity_kernel, grid_for(nCells), dim3(kBlock), 0, st, U, rec, box, nCells);
     return hipGetLastError();
 }
 hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n, unsigned long long* out) {

@@ -260,6 +260,45 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
+    // ---- box records (cpf_walk.h "box records"): every cell an axis-aligned box.  Canonical slot k = 2 * axis + (normal
+    // component -1 ? 1 : 0); the record keeps each plane's offset d, the neighbour, the slot's place in the walk's own order
+    // (ties in dT go to the lower ORIGINAL slot) and the signs of the normal's two zero components (a mirrored -0.0
+    // coordinate keeps its sign exactly as with the full planes).  U (doubles 10..12) is filled in on the device.
+    out.boxRec.clear();
+    if (out.minCellFaces == 6 && out.maxCellFaces == 6 && out.nGroups() == 0 && nCells > 0) {
+        std::vector<double> box((size_t)nCells * 16, 0.0);
+        bool ok = true;
+        for (int64_t c = 0; c < nCells && ok; ++c) {
+            const size_t s0 = (size_t)out.cellOff[(size_t)c];
+            double* r = &box[(size_t)c * 16];
+            int32_t* nb = reinterpret_cast<int32_t*>(r + 6);
+            uint32_t code = 0, seen = 0;
+            for (int s = 0; s < 6 && ok; ++s) {
+                const double* pl = &out.planes[4 * (s0 + s)];
+                int axis = -1;
+                for (int a = 0; a < 3; ++a)
+                    if (pl[a] == 1.0 || pl[a] == -1.0) {
+                        if (axis >= 0) ok = false;
+                        axis = a;
+                    } else if (pl[a] != 0.0) ok = false;
+                if (axis < 0 || !std::isfinite(pl[3])) ok = false;
+                if (!ok) break;
+                const int k = 2 * axis + (pl[axis] < 0.0 ? 1 : 0);
+                if (seen & (1u << k)) { ok = false; break; }
+                seen |= 1u << k;
+                r[k] = pl[3];
+                nb[k] = out.nbr[s0 + s];
+                code |= (uint32_t)s << (3 * k);
+                const int o1 = axis == 0 ? 1 : 0, o2 = axis == 2 ? 1 : 2;     // the two other components, in axis order
+                code |= (std::signbit(pl[o1]) ? 1u : 0u) << (18 + 2 * k);
+                code |= (std::signbit(pl[o2]) ? 1u : 0u) << (19 + 2 * k);
+            }
+            if (ok && seen != 63u) ok = false;
+            nb[6] = (int32_t)code; nb[7] = 0;
+        }
+        if (ok) out.boxRec.swap(box);
+    }
+
     // ---- uniform bin grid (initial locate; replaces the OptiX BVH, src/initCuda.H:134-139)
     for (int k = 0; k < 3; ++k) { out.lo[k] = 1e300; out.hi[k] = -1e300; }
     for (int64_t p = 0; p < nPoints; ++p)

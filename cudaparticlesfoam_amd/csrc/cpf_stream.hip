@@ -87,6 +87,12 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 #ifndef CPF_STREAM_L1_ZERO_SKIP
 #define CPF_STREAM_L1_ZERO_SKIP 1
 #endif
+#ifndef CPF_STREAM_BOX_SPARSE
+#define CPF_STREAM_BOX_SPARSE 1
+#endif
+#ifndef CPF_STREAM_WAVES_BOX
+#define CPF_STREAM_WAVES_BOX 7
+#endif
 #ifndef CPF_STREAM_WAVES_B1
 #define CPF_STREAM_WAVES_B1 5
 #endif
@@ -98,7 +104,7 @@ template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6)) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : CPF_STREAM_WAVES))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 1 || LOOKUP == 6) ? CPF_STREAM_WAVES_B1 : 6)) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -110,13 +116,17 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #ifndef CPF_STREAM_SLOTS_BROWN
 #define CPF_STREAM_SLOTS_BROWN 10
 #endif
-    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed);
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && (LOOKUP == 1 || LOOKUP == 6) ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed);
+    // LOOKUP 6: the mesh's 128-byte BOX records instead of the 256-byte ones (cpf_walk.h "box records")
+    constexpr bool BOX = LOOKUP == 6;
+    constexpr int kStride = BOX ? 4 : kSlotStride;               // double4 per slot
+    constexpr unsigned kRecBytes = 32u * kStride;
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
     // the wave's record cache.  (256 bytes per slot is one full turn of the 64 LDS banks, so lanes reading the same plane
     // of different slots conflict: 50 conflict cycles per tile on pitzDaily, 351 on the 3-D bench mesh.  Padding the
     // slots to 288 bytes removes the conflicts and was SLOWER on every mesh, 3-4 %: the 192 bytes cost the 24th wave per
     // CU, and with 5 padded slots instead of 6 -- same LDS as now -- the extra misses cost more than the conflicts.)
-    __shared__ double4 slots[NS][kSlotStride];
+    __shared__ double4 slots[NS][kStride];
     __shared__ unsigned sCnt[4];
     // Per-lane end point E, parked between rounds (see step_kernel_coop) -- the slot also carries the three Brownian
     // deviates from the first round of a cycle to the lane's advect, and the previous tile's position from the tile's end
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
-    const bool zFold = BROWNIAN && REFLECT && m.zThin != 0;
+    const bool zFold = !BOX && BROWNIAN && REFLECT && m.zThin != 0;      // (stream_lookup_mode: no box records on a mesh one cell thick)
     const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
@@ -448,9 +458,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         const bool mine = lk == ck;                                                         \
                         if (mine) myslot = victim;                                                          \
                         missLanes &= ~ballot64(mine);                                                       \
-                        if (ul < 16u)                                                                       \
-                            glds16(reinterpret_cast<const char*>(m.cellRec) + (int64_t)ck * 256 + ul * 16u,  \
-                                   uniform32(slotBase + (unsigned)victim * (32u * kSlotStride)));                          \
+                        if (ul < kRecBytes / 16u)                                                            \
+                            glds16(reinterpret_cast<const char*>(BOX ? m.boxRec : m.cellRec) + (int64_t)ck * kRecBytes + ul * 16u,  \
+                                   uniform32(slotBase + (unsigned)victim * kRecBytes));                     \
                         nJobs = J + 1;                                                                      \
                     }
                     CPF_JOB(0) CPF_JOB(1) CPF_JOB(2) CPF_JOB(3)
@@ -489,7 +499,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 const bool gatherRound = __popcll(missLanes) >= kStreamGatherLanes;
                 // advect (particles.cu:355-362) with the record's velocity: end point E, parked in the lane's E slot
                 auto advect = [&](const double4* rec) __attribute__((always_inline)) -> D3 {
-                    const double4 u = rec[6];
+                    double4 u;
+                    if (BOX) { const double2 uxy = reinterpret_cast<const double2*>(rec)[5]; u = {uxy.x, uxy.y, reinterpret_cast<const double*>(rec)[12], 0.0}; }
+                    else u = rec[6];
                     v = {u.x, u.y, u.z};
                     const D3 Pn = axpy(dt, v, S_);
                     D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};           // not yet walked in this cycle: S_ is the position
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                     if (BROWNIAN && REFLECT && zFold) {                           // one cell thick in z: cpf_walk.h, fold_z
                         bool clear;
-                        const int nb = fold_z(E.z, rec[4], rec[5], clear);
+                        const int nb = fold_z(E.z, rec[BOX ? 0 : 4], rec[BOX ? 0 : 5], clear);      // (never with box records: zFold)
                         zUnclear |= ballot64(!clear) != 0ull;                      // (wave-uniform; the advecting lanes vote)
                         if (STATS) st.refl += nb;
                         if (STORE_VEL && (nb & 1)) v.z = -v.z;
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     bool hdrCell = false;
                     if (bigCells && myslot >= 0) hdrCell = *reinterpret_cast<const int*>(&slots[0][0] + myslot * kSlotStride + 7) == kBigCellMark;
                     if (myslot >= 0 && !(bigCells && hdrCell)) {
-                        const double4* rec = &slots[0][0] + myslot * kSlotStride;
+                        const double4* rec = &slots[0][0] + myslot * kStride;
                         if (needAdvect) E = advect(rec);
                         // ---- the visit, and -- in the same round -- the visits after a wall.  A wall hit never changes the
                         // cell and its record is in the slot already, so a lane that hits a wall mirrors its end point and
@@ -561,6 +573,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
+                            if (BOX) next = trace_box<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
+                            else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<(!BROWNIAN && (CPF_STREAM_L1_ZERO_SKIP || LOOKUP != 1)), mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
                             if (STATS) ++st.hops;
@@ -575,7 +589,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                         wallPlane = m.planes[m.cellOff[cur] + outSlot];
                                         asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
                                     }
-                                } else wallPlane = rec[outSlot];
+                                } else if (BOX) wallPlane = box_wall_plane(rec, outSlot);
+                                else wallPlane = rec[outSlot];
                                 // E comes from its parking slot again -- it is there, from this round's advect or an earlier
                                 // round -- so that it need not stay in registers across the face tests
                                 asm volatile("" ::: "memory");
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                         // kept sorted).  Per-lane gathers keep such a wave moving.
                         next = kSitOut;
                         if (gatherRound || (bigCells && hdrCell)) {
-                            const double4* rec = m.cellRec + 8 * (int64_t)cur;
+                            const double4* rec = BOX ? m.boxRec + 4 * (int64_t)cur : m.cellRec + 8 * (int64_t)cur;
                             if (needAdvect) E = advect(rec);
                             int gS0 = 0;
                             bool gBig = false;
@@ -619,13 +634,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                     key2 = 0;
                                 }
                             }
-                            if (!gBig)
+                            if (BOX) next = trace_box<false>(S_, E, cur, rec, token, outSlot);
+                            else if (!gBig)
                             next = trace_fixed<6, false, mixed, kGatherAhead>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                             if (STATS) ++st.hops;
                             // (the empty asm makes the compiler wait for this load HERE: a load of its own left pending
                             // at the loop's back edge costs every round an s_waitcnt vmcnt(0), i.e. a wait for the prefetch)
                             if (REFLECT && next < 0) {
-                                wallPlane = rec[outSlot];
+                                wallPlane = BOX ? box_wall_plane(rec, outSlot) : rec[outSlot];
                                 asm volatile("" : "+v"(wallPlane.x), "+v"(wallPlane.y), "+v"(wallPlane.z), "+v"(wallPlane.w));
                             }
                         }
@@ -833,9 +849,10 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
     }
     // not all-hex: with / without big cells (more than six slots); without them and with many particles per cell, the loop lookup
     if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * cells) ? 5 : 3);
-    if (ss.lookup >= 0) return ss.lookup;      // "stream_lookup": 0, 1 or 4 (2, 3, 5: diagnostics)
-    if (n < kStreamSparsePerCell * cells) return 4;
-    return n < 128 * cells ? 1 : 0;
+    const bool box = m.boxRec != nullptr && m.zThin == 0;
+    if (ss.lookup >= 0) return (ss.lookup == 6 && !box) ? 1 : ss.lookup;      // "stream_lookup": 0, 1, 4 or 6 (2, 3, 5: diagnostics)
+    if (n < kStreamSparsePerCell * cells) return (box && CPF_STREAM_BOX_SPARSE) ? 6 : 4;
+    return n < 128 * cells ? (box ? 6 : 1) : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
@@ -845,6 +862,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
     const int lf = stream_lookup_mode(n, m, ss);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
+        if (lf == 6) return launch_stream_inst<B, R, SV, ST, 6>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 5) return launch_stream_inst<B, R, SV, ST, 5>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 4) return launch_stream_inst<B, R, SV, ST, 4>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 3) return launch_stream_inst<B, R, SV, ST, 3>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

@@ -370,6 +370,110 @@ constexpr int kNullNbr = INT32_MIN + 5;
 constexpr int kBigCellMark = INT32_MIN + 6;
 constexpr int kTwoRecMark = INT32_MIN + 9;
 
+// BOX RECORDS (MeshView::boxRec, 128 bytes = 16 doubles per cell; built by cpf_mesh.cpp when EVERY cell of the mesh is an
+// axis-aligned box: six planes whose normals are exactly +-e_x, +-e_y, +-e_z, one of each -- blockMesh cases such as the
+// TJunction tutorial).  Canonical slot k = 2 * axis + (normal component == -1):
+//   doubles 0..5   the plane offsets d_k
+//   bytes  48..71  the six neighbour codes (int32), bytes 72..75 the ORDER CODE: bits 3k..3k+2 = the slot's place in the
+//                  walk's own slot order (HostTables), bits 18+2k, 19+2k = sign bits of the normal's two zero components
+//   doubles 10..12 U
+// What the six-face test becomes, bit for bit (the dropped terms of the reference's dot products are exact zeros, which
+// change at most the sign of a zero result -- and no comparison below sees the sign of a zero):
+//   den_k = n_a * Pd_a = +-Pd_a exactly,   fd_k = fl(d_k - n_a * P0_a)  (one rounding, as the innermost live fma of plane_dist).
+// A face can be accepted (ConvexQuery.cu:86-95: fd < tol, tol < dT <= 1, smallest dT, ties to the lower slot) only if
+// fd and den have equal signs; with den > 0 -- the face of the pair the particle moves AWAY from -- that needs fd > 0: the
+// particle outside its cell by a rounding (never beyond 1e-13: fd < tol).  Hence per axis only the face the particle moves
+// TOWARDS is tested (den = -|Pd_a|): three candidates per visit instead of six, no normal ever fetched, one LDS round trip
+// for the whole record instead of three.  The rest -- a lane with fd > 0 on any face that is not the one it came in through,
+// two axes with exactly equal dT (the ORIGINAL slot order decides, not the canonical one), a displacement that is not
+// finite (0 * inf = NaN poisons every denominator of the reference form) -- sends the WAVE through trace_box_slow, which
+// evaluates the reference's predicate on all six faces and breaks ties by original slot.  Parity: tests/test_gpu_box.py,
+// tools/fuzz_parity.py box (structured clouds that sit on faces, edges and diagonals).
+__device__ __forceinline__ double4 box_wall_plane(const double4* rec4, int k) {
+    const unsigned code = reinterpret_cast<const unsigned*>(rec4)[18];
+    const int axis = k >> 1;
+    const double one = (k & 1) ? -1.0 : 1.0;
+    const double z1 = ((code >> (18 + 2 * k)) & 1u) ? -0.0 : 0.0, z2 = ((code >> (19 + 2 * k)) & 1u) ? -0.0 : 0.0;
+    double4 p;
+    p.x = axis == 0 ? one : z1;
+    p.y = axis == 1 ? one : (axis == 0 ? z1 : z2);
+    p.z = axis == 2 ? one : z2;
+    p.w = reinterpret_cast<const double*>(rec4)[k];
+    return p;
+}
+// the reference's predicate on all six faces of a box record, ties to the lower ORIGINAL slot (rare path of trace_box)
+__device__ __forceinline__ void trace_box_slow(const D3& P0, const D3& Pd, const double4* rec4, int token, double& dTmin, int& next, int& best) {
+    const double* rd = reinterpret_cast<const double*>(rec4);
+    const int* ri = reinterpret_cast<const int*>(rec4);
+    const unsigned code = (unsigned)ri[18];
+    // (what the zero components of the normals contribute in the reference form: +-0, or NaN next to an infinity or a NaN)
+    const double nanD = Pd.x * 0.0 + Pd.y * 0.0 + Pd.z * 0.0, nanP = P0.x * 0.0 + P0.y * 0.0 + P0.z * 0.0;
+    int ordBest = 8;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const int a = k >> 1;
+        const double pa = a == 0 ? P0.x : (a == 1 ? P0.y : P0.z), da = a == 0 ? Pd.x : (a == 1 ? Pd.y : Pd.z);
+        const double w = rd[k];
+        const int nb = ri[12 + k];
+        const double fd = ((k & 1) ? w + pa : w - pa) + nanP, den = ((k & 1) ? -da : da) + nanD;
+        const int ord = (int)((code >> (3 * k)) & 7u);
+        double dT = fd / den;
+        if (__builtin_isinf(dT)) dT = -1.0;
+        if (nb == token) continue;
+        if (fd < kTol && dT > kTol && dT <= 1.0 && (dT < dTmin || (dT == dTmin && ord < ordBest))) { dTmin = dT; next = nb; best = k; ordBest = ord; }
+    }
+}
+template <bool ZERO_SKIP>
+__device__ __forceinline__ int trace_box(D3& S, const D3& E, int cur, const double4* rec4, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    const double2* rd = reinterpret_cast<const double2*>(rec4);
+    const double2 w01 = rd[0], w23 = rd[1], w45 = rd[2];
+    const int4 nA = reinterpret_cast<const int4*>(rec4)[3];
+    const int2 nB = reinterpret_cast<const int2*>(rec4)[8];
+    const double f0 = w01.x - P0.x, f1 = w01.y + P0.x, f2 = w23.x - P0.y, f3 = w23.y + P0.y, f4 = w45.x - P0.z, f5 = w45.y + P0.z;
+    int next = cur, best = -1;
+    double dTmin = 2.0;
+    // lanes the three-candidate form does not cover (see above); voted on once, after the candidates
+    const unsigned long long odd =
+        (ballot64(f0 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.x, (unsigned)token, 33 /* ne */)) |
+        (ballot64(f1 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.y, (unsigned)token, 33)) |
+        (ballot64(f2 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.z, (unsigned)token, 33)) |
+        (ballot64(f3 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.w, (unsigned)token, 33)) |
+        (ballot64(f4 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nB.x, (unsigned)token, 33)) |
+        (ballot64(f5 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nB.y, (unsigned)token, 33)) |
+        ballot64(!(fabs(Pd.x) + fabs(Pd.y) + fabs(Pd.z) < __builtin_inf()));
+    bool tie = false;
+#define CPF_BOX_AXIS(A, D, FD0, FD1, NB0, NB1)                                                                     \
+    if (!ZERO_SKIP || ballot64(D != 0.0) != 0ull) {                                                                \
+        const bool pos = D > 0.0;                                                                                  \
+        const double fdt = pos ? FD1 : FD0;                                                                        \
+        const int nbt = pos ? NB1 : NB0;                                                                           \
+        const bool c1 = fabs(fdt) <= fabs(D), c3 = fdt < kTol, c4 = nbt != token;                                  \
+        if ((ballot64(c1) & ballot64(c3) & __builtin_amdgcn_uicmp((unsigned)nbt, (unsigned)token, 33)) != 0ull) {  \
+            if (c1 && c3 && c4) {                                                                                  \
+                const double dT = fdt / -fabs(D);                                                                  \
+                const bool ok = dT > kTol;                                                                         \
+                tie |= ok && dT == dTmin;                                                                          \
+                if (ok && dT < dTmin) { dTmin = dT; next = nbt; best = 2 * A + (pos ? 1 : 0); }                    \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    CPF_BOX_AXIS(0, Pd.x, f0, f1, nA.x, nA.y)
+    CPF_BOX_AXIS(1, Pd.y, f2, f3, nA.z, nA.w)
+    CPF_BOX_AXIS(2, Pd.z, f4, f5, nB.x, nB.y)
+#undef CPF_BOX_AXIS
+    if ((odd | ballot64(tie)) != 0ull) {
+        next = cur; best = -1; dTmin = 2.0;
+        trace_box_slow(P0, Pd, rec4, token, dTmin, next, best);
+    }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        outSlot = best;
+    }
+    return next;
+}
+
 // trace_in_cell on the CSR slots [s0, s0 + nf) of one cell; outSlot is returned relative to s0.  A group code may come
 // back as `next`: the caller resolves it (resolve_group), as after the six-slot tests.
 __device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const double4* __restrict__ planes, const int32_t* __restrict__ nbr,

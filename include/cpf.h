@@ -159,6 +159,15 @@ int cpf_build_mesh_tables_host(const double* points, int64_t nPoints, const int3
 int cpf_mesh_flags_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
                         int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
                         int32_t* allHex, int32_t* zLayered, int32_t* zThin, int32_t* mixed);
+/* ... and its BOX RECORDS (NO REFERENCE COUNTERPART: the reference walks 12 tets per cell whatever the cell's shape,
+ * src/initCuda.H:64).  *isBox = 1 if every cell is an axis-aligned box -- six planes with normals exactly +-e_x, +-e_y, +-e_z,
+ * blockMesh cases such as the TJunction tutorial -- and boxRec (may be NULL) then receives [nCells][16] doubles: the 128-byte
+ * records the streaming kernel walks on such a mesh instead of the 256-byte ones (layout and the bit-exactness argument:
+ * csrc/cpf_walk.h "box records"; option "box_records" 0 turns them off -- same results, bit for bit).  U (doubles 10..12) is
+ * zero here: the device copy gets it from cpf_set_velocity. */
+int cpf_mesh_box_records_host(const double* points, int64_t nPoints, const int32_t* faceOffsets, const int32_t* faceVerts,
+                              int64_t nFaces, const int32_t* owner, const int32_t* neighbour, int64_t nInternal, int64_t nCells,
+                              int32_t* isBox, double* boxRec);
 
 /* Cell-constant velocity U[nCells][3] (host, zero-copy from U.primitiveField()).  Replaces the
  * 12x replication loop + cudaUpdateVelocity of src/advect.H:44-57 (cuda/particles.cu:718-749):

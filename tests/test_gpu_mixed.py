@@ -28,14 +28,15 @@ def _prism_box(nx, ny, nz):
     return build_polymesh_from_cells(m.points, [[tuple(int(v) for v in f) for f in c] for c in cells])
 
 
-def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, want_kernel):
+def _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, dt, cycles, options, want_kernel, check_inside=True):
     cw = oracle_libs.CellWalk()
     t = cw.build(mesh)
     ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
     x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
     stats = cw.step(x, y, z, c, dt, cycles, t, U, nthreads=cw.max_threads)
     alive = c >= 0                                  # the walk's own invariant: everybody inside the cell they claim
-    assert worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive]).max() <= 1e-9
+    # (check_inside False: clouds built to sit on vertices and edges, where the reference's walk itself loses the cell)
+    assert not check_inside or worst_outside(t, np.stack([x, y, z], 1)[alive], c[alive]).max() <= 1e-9
     for opts in options:
         ctx = gpu_ctx_factory()
         for k, v in opts.items():
