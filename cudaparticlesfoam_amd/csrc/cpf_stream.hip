@@ -87,11 +87,17 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 #ifndef CPF_STREAM_L1_ZERO_SKIP
 #define CPF_STREAM_L1_ZERO_SKIP 1
 #endif
+#ifndef CPF_STREAM_LAZY_USED
+#define CPF_STREAM_LAZY_USED 1
+#endif
 #ifndef CPF_STREAM_BOX_SPARSE
 #define CPF_STREAM_BOX_SPARSE 1
 #endif
+#ifndef CPF_STREAM_WAVES_BOX_B
+#define CPF_STREAM_WAVES_BOX_B 6
+#endif
 #ifndef CPF_STREAM_WAVES_BOX
-#define CPF_STREAM_WAVES_BOX 7
+#define CPF_STREAM_WAVES_BOX 6
 #endif
 #ifndef CPF_STREAM_WAVES_B1
 #define CPF_STREAM_WAVES_B1 5
@@ -104,7 +110,7 @@ template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 1 || LOOKUP == 6) ? CPF_STREAM_WAVES_B1 : 6)) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -410,6 +416,22 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             missLanes = 0ull;
                         }
                     } else {
+#if CPF_STREAM_LAZY_USED
+                        // the sweep itself is vector work only; which slots are in use (`used`) is scalar work -- four
+                        // operations per tag -- that only a round with a miss needs (the victims of its jobs)
+                        unsigned long long eqs[NS];
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const int tk = __builtin_amdgcn_readlane(tagv, k);
+                            eqs[k] = __builtin_amdgcn_uicmp((unsigned)lk, (unsigned)tk, 32 /* eq */);
+                            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(myslot) : "v"(myslot), "n"(k), "s"(eqs[k]));
+                        }
+                        missLanes = ballot64(myslot < 0) & busyMask;
+                        if (missLanes != 0ull) {
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) used |= ((eqs[k] & busyMask) != 0ull ? 1u : 0u) << k;
+                        }
+#else
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
                             const int tk = __builtin_amdgcn_readlane(tagv, k);
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             used |= (inK != 0ull ? 1u : 0u) << k;
                             missLanes &= ~inK;
                         }
+#endif
                     }
                 } else {
                     unsigned long long todo = busyMask;

@@ -1180,7 +1180,7 @@ def test_sparse_clouds_are_sorted_along_the_morton_curve(gpu_ctx_factory, oracle
         assert len(set(cells0[np.r_[0, change + 1]])) == len(change) + 1                     # every cell is ONE contiguous run
         orders[curve] = cells0
         ctx.step_dev(p(tx), p(ty), p(tz), p(tc), None, None, n, 0.05, 0.0, 0, 15, 0)
-        assert ", 4>" in ctx.step_kernel_name(0.0, 0)
+        assert ", 6>" in ctx.step_kernel_name(0.0, 0)                 # sparse, and every cell a box: box records (else ", 4>")
         g = tg.cpu().numpy()
         assert np.array_equal(tc.cpu().numpy(), c[g]) and np.array_equal(tx.cpu().numpy(), x[g])
         assert np.array_equal(ty.cpu().numpy(), y[g]) and np.array_equal(tz.cpu().numpy(), z[g])

@@ -3,7 +3,10 @@
 statement, bit for bit.  Random graded/sheared hex blocks (tests/test_oracle_random._case), random cell-constant U,
 time steps that cross several cells and bounce off several walls; every case runs with the statistics on and off
 (two instantiations), plain and fused launches, sorted and unsorted clouds, and with exactly axis-aligned flow
-(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed|poly]
+(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed|poly|box]
+"box": axis-aligned boxes (uniform or graded blockMesh boxes: BOX RECORDS, csrc/cpf_walk.h) with half of the cloud snapped to
+fractions of the grid spacing and velocities that are +-1 / +-1/2 cells per step per axis on every other seed -- particles on
+faces, edges and vertices, equal dT on two or three axes: the cases the three-candidate face test hands to the six-face form.
 "mixed": a random subset of the block's cells is split 2 x 2 x 2 (2 x 2 x 1 for every third seed) first -- coarse cells
 with one to six split faces, i.e. face groups in every combination -- and the CPU statement's result is also checked
 against the domain's own invariant (nobody lost, everybody inside the cell they claim).
@@ -24,6 +27,7 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     mixed = len(sys.argv) > 3 and sys.argv[3] in ("mixed", "poly")
     poly = len(sys.argv) > 3 and sys.argv[3] == "poly"
+    box = len(sys.argv) > 3 and sys.argv[3] == "box"
     import torch  # noqa: F401  (its HIP runtime first)
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -52,8 +56,22 @@ def main():
             mesh, parent = refine_hexes(mesh.points, mesh.hexes, mask, split_z=bool(seed % 3))
             U = U[parent] + rng.normal(size=(mesh.n_cells, 3)) * 0.1 * float(np.abs(U).max())
             dt = dt * 0.5
+        if box:
+            from cudaparticlesfoam_amd.cases import box_mesh
+            nb = [int(rng.integers(3, 11)) for _ in range(3)]
+            if seed % 2:                                 # unit cells, whole or half cells per step along every axis: ties galore
+                mesh = box_mesh(*nb)
+                cc, _ = mesh.cell_centres_volumes()
+                U = rng.choice([-1.0, -0.5, 0.0, 0.5, 1.0], size=(mesh.n_cells, 3)) if seed % 4 == 1 else \
+                    np.tile(rng.choice([-1.0, -0.5, 0.5, 1.0], size=3), (mesh.n_cells, 1))
+                dt = 1.0
+            else:
+                lo3 = rng.normal(size=3); ext = rng.uniform(0.3, 2.0, size=3)
+                mesh = box_mesh(*nb, lower=tuple(lo3), upper=tuple(lo3 + ext), grading=tuple(rng.choice([0.25, 1.0, 3.0], size=3)))
+                U = rng.normal(size=(mesh.n_cells, 3)) * ext * float(rng.choice([0.5, 2.0, 6.0]))
+                dt = float(rng.choice([0.05, 0.2]))
         mode = seed % 4
-        if mode == 1:                                    # axis-aligned flow: whole families of faces have den == 0
+        if mode == 1 and not box:                                    # axis-aligned flow: whole families of faces have den == 0
             amp = float(np.abs(U).max()) or 1.0
             U = np.zeros_like(U); U[:, seed % 3] = rng.normal(size=U.shape[0]) * amp
         if mode == 2:
@@ -62,6 +80,9 @@ def main():
         lo, hi = mesh.bounds()
         n = int(rng.integers(1000, 60000))
         xyz = rng.uniform(lo - 0.02 * (hi - lo), hi + 0.02 * (hi - lo), size=(n, 3))
+        if box and seed % 2:                             # half of the cloud on quarter-cell positions (strictly inside the domain)
+            k = n // 2
+            xyz[:k] = np.clip(np.round(xyz[:k] * 4.0) / 4.0, lo + 0.25, hi - 0.25)
         ref0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
         x, y, z, c = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), ref0.copy()
         steps = [1, 5, 24]
@@ -84,7 +105,10 @@ def main():
                 ctx.set_option("stats", stats)
                 if os.environ.get("CPF_FUZZ_VARIANT"):
                     ctx.set_option("step_variant", int(os.environ["CPF_FUZZ_VARIANT"]))
-                ctx.set_option("stream_lookup", (0, 1) [(seed // 2 + stats) % 2] if mixed else (0, 1, 4)[(seed // 2 + stats) % 3])      # all record-lookup methods of the streaming kernel
+                if box:
+                    ctx.set_option("stream_lookup", (6, 6, 1, 4)[(seed // 2 + stats + 2 * fused) % 4])
+                else:
+                    ctx.set_option("stream_lookup", (0, 1) [(seed // 2 + stats) % 2] if mixed else (0, 1, 4)[(seed // 2 + stats) % 3])      # all record-lookup methods of the streaming kernel
                 ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz)
                 ctx.locate_initial()
                 _, cell0 = ctx.get_particles()
