@@ -609,7 +609,7 @@ class GpuMachine:
             torch.cuda.synchronize(); c1 = ctx2.counters(); ctx2.set_option("stats", 0)
             cl.sort(); cl.step_index = 0     # (as in _brownian_steady)
             r = self._timed_steps(torch, ctx2, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
-            rec_once = 256 * mesh.n_cells
+            rec_once = (128 if ctx2.step_kernel_name(Db, 0).endswith(", 6>") else 256) * mesh.n_cells     # (box records: 128 B)
             r.update({"D": Db, "particles": n, "cells": mesh.n_cells, "sort_interval": interval,
                       "sorts_inside": args.tjunction_steps // interval, "kernel": ctx2.step_kernel_name(Db, 0),
                       "mesh_flags": ctx2.mesh_flags(), "records_bytes_once": rec_once,

@@ -240,10 +240,15 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   cells with seven to twelve a second record (a visit there takes two rounds of kernel 4, both tests from
  *                   LDS), cells beyond that a header record and are walked through the CSR tables inside kernel 4.
  *                   0 = such meshes run the generic walk (kernel 0)
+ *   "box_records"   (1) on a mesh whose cells are ALL axis-aligned boxes (cpf_mesh_box_records_host) kernel 4 walks 128-byte box
+ *                   records -- three candidate faces per visit instead of six -- whenever it would use the fixed tag compare
+ *                   ("stream_lookup" 1 or 4: fewer than 128 particles per cell); 0 = the 256-byte records everywhere.
+ *                   Bit-identical either way (tests/test_gpu_box.py)
  *   "stream_tiles_per_chunk" (4; 3 on meshes with few particles per cell), "stream_tail_fraction" (0.1; 0.2), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
  *                   distinct cells of a wave, 1 fixed tag compare, 4 the same for sparse clouds -- fewer than 8 particles
- *                   per cell --: pipelined per-lane record gathers; on meshes that are not all-hex only 0 / 1 apply): how a wave finds its cells
+ *                   per cell --: pipelined per-lane record gathers, 6 fixed tag compare + box records where the mesh has
+ *                   them (else 1); on meshes that are not all-hex only 0 / 1 apply): how a wave finds its cells
  *                   in its record cache; with "stream_lookup_by_density" 1 (default 0) "particles per cell" means per cell that
  *                   HOLDS particles, as counted by the last sort (the tutorials seed 4e6 particles into 20 000 of TJunction's
  *                   248 000 cells; measured slower there, hence off);

@@ -57,7 +57,7 @@ def main():
         launches, ms = ctx.timing_read(); ctx.timing_enable(False)
         k = ms / max(launches, 1) / (a.steps if a.fused else 1)
         per = 56 + (8 if a.D > 0 else 0)
-        rec_once = 256 * mesh.n_cells
+        rec_once = (128 if ctx.step_kernel_name(a.D, 0).endswith(", 6>") else 256) * mesh.n_cells      # (box records: 128 B)
         print(json.dumps(dict(label=a.label, case=a.case, field=name, opts=a.opt, D=a.D, cells=mesh.n_cells, particles=n,
                               kernel=ctx.step_kernel_name(a.D, 0), kernel_ms=round(k, 4),
                               Gparticle_steps_per_s=round(n / k / 1e6, 2), roofline_GBs=round(per * n / k / 1e6, 1),
