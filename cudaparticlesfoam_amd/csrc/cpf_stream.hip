@@ -93,6 +93,12 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 #ifndef CPF_STREAM_BOX_SPARSE
 #define CPF_STREAM_BOX_SPARSE 1
 #endif
+#ifndef CPF_STREAM_SLOTS_BOX
+#define CPF_STREAM_SLOTS_BOX 9
+#endif
+#ifndef CPF_STREAM_SLOTS_BOX_B
+#define CPF_STREAM_SLOTS_BOX_B 12
+#endif
 #ifndef CPF_STREAM_WAVES_BOX_B
 #define CPF_STREAM_WAVES_BOX_B 6
 #endif
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #ifndef CPF_STREAM_SLOTS_BROWN
 #define CPF_STREAM_SLOTS_BROWN 10
 #endif
-    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (BROWNIAN && (LOOKUP == 1 || LOOKUP == 6) ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed);
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (LOOKUP == 6 ? (BROWNIAN ? CPF_STREAM_SLOTS_BOX_B : CPF_STREAM_SLOTS_BOX) : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed));
     // LOOKUP 6: the mesh's 128-byte BOX records instead of the 256-byte ones (cpf_walk.h "box records")
     constexpr bool BOX = LOOKUP == 6;
     constexpr int kStride = BOX ? 4 : kSlotStride;               // double4 per slot
