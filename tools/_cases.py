@@ -1,6 +1,7 @@
 """Developer tools (GPU box): the synthetic cases the tools share -- one place for mesh, field and cloud set-up.
   pitz       pitzDaily 12 225 cells (x-slab numbering), uniform (10,0,0) or the analytic step flow
   box3d      graded 64 x 64 x 60 box = 245 760 hex cells (records 63 MB: beyond L2), diagonal / swirl fields; CPF_BOX_N=a,b,c resizes
+  refbox3d   the same box (default 40 x 40 x 40) with its central block refined 2 x 2 x 2: face groups, mixed records
   tjunction  the reference's TJunction tutorial mesh, 248 000 cells of 1 mm, closed-form split flow (u0 = 3 / 5), cloud over the whole T
   tjunction_run   ... seeded as the tutorial's dictionary does: in the first 50 mm of the inlet duct
   octagons / pentagons / dodecagons / hexgrid   300 x 200 x 4 unit cells (cases/polygons.py): every ninth square an octagonal prism
@@ -75,6 +76,19 @@ def make_case(name, ctx, torch, n, dev, field=None, seed=7):
                       [0, 0.05, 0.05]], float)
         nbox = tuple(int(k) for k in os.environ.get("CPF_BOX_N", "64,64,60").split(","))
         mesh = block_mesh(v, [dict(hex=range(8), n=nbox, simple=(2.0, 1.0, 0.5))]); cc, _ = mesh.cell_centres_volumes()
+        fields = {"diagonal": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
+                  "swirl": np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1)}
+        x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
+        y = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+        z = torch.rand(n, dtype=torch.float64, device=dev) * 0.05
+    elif name == "refbox3d":
+        # the 3-D box with its central block (half the extent per axis) refined 2 x 2 x 2: face groups around the block, the
+        # snappyHexMesh kind of mesh; CPF_BOX_N as for box3d (default 40,40,40 -> 120 000 cells)
+        from cudaparticlesfoam_amd.cases import refined_box
+        nbox = tuple(int(k) for k in os.environ.get("CPF_BOX_N", "40,40,40").split(","))
+        mesh, _ = refined_box(*nbox, (0.0, 0.0, 0.0), (0.3, 0.05, 0.05), ((0.075, 0.0125, 0.0125), (0.225, 0.0375, 0.0375)),
+                              grading=(2.0, 1.0, 0.5))
+        cc, _ = mesh.cell_centres_volumes()
         fields = {"diagonal": np.tile([10.0, 2.0, 1.0], (mesh.n_cells, 1)),
                   "swirl": np.stack([10.0 + 0 * cc[:, 0], 4 * np.sin(40 * cc[:, 2]), 4 * np.cos(40 * cc[:, 1])], 1)}
         x = torch.rand(n, dtype=torch.float64, device=dev) * 0.3
