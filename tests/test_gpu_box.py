@@ -137,3 +137,70 @@ def test_box_records_brownian_same_bits_as_full_records(gpu_ctx_factory, D):
     assert np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][0].view(np.int64), outs[1][0].view(np.int64))
     assert outs[0][2] == outs[1][2]
+
+
+def _refined_unit_box(nx, ny, nz, region):
+    from cudaparticlesfoam_amd.cases import refined_box
+    return refined_box(nx, ny, nz, (0.0, 0.0, 0.0), (float(nx), float(ny), float(nz)), region)[0]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_refined_box_random_cloud(oracle_libs, gpu_ctx_factory, seed):
+    """A 2:1-refined box (face groups around the refined block: the snappyHexMesh kind of mesh).  Its cells are all axis-aligned
+    boxes too, but a mesh with face groups walks the ordinary mixed records (box data inside them were built and measured in round
+    4: slower on dense clouds, docs/experiments.md) -- ``box_records`` must be a no-op there.  Bit-identical to the CPU statement
+    with both lookups, sparse and dense."""
+    from cudaparticlesfoam_amd.cases import refined_box
+    rng = np.random.default_rng(seed)
+    mesh, _ = refined_box(10, 9, 8, (-0.2, 0.0, 0.1), (1.0, 0.9, 0.9), ((0.1, 0.2, 0.3), (0.7, 0.7, 0.7)), grading=(2.0, 1.0, 0.5))
+    U = rng.normal(size=(mesh.n_cells, 3)) * np.array([1.5, 1.0, 0.8])
+    if seed == 2:
+        U[:, 1] = 0.0
+    n = 30000 if seed == 1 else 3000                            # dense / sparse (fewer than 8 per cell)
+    xyz = np.array([-0.2, 0.0, 0.1]) + rng.random((n, 3)) * np.array([1.2, 0.9, 0.8])
+    opts = [{}, {"box_records": 0}, {"stream_lookup": 0}, {"box_records": 0, "stream_lookup": 0}]
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.09, 6, opts,
+              lambda o: ", 5>" if o.get("stream_lookup") == 0 else ", 3>")
+
+
+@pytest.mark.parametrize("field", ["diag", "signs", "half"])
+def test_refined_box_ties_and_faces(oracle_libs, gpu_ctx_factory, field):
+    """... and the structured clouds of test_box_records_ties_and_faces on a unit grid with a refined block: particles on the
+    faces, edges and vertices of coarse AND fine cells, on the pieces of split faces, equal dT on several axes."""
+    rng = np.random.default_rng(13)
+    nx, ny, nz = 8, 6, 6
+    mesh = _refined_unit_box(nx, ny, nz, ((2.0, 1.0, 1.0), (6.0, 5.0, 5.0)))
+    cc, _ = mesh.cell_centres_volumes()
+    one = np.ones(mesh.n_cells)
+    U = {"diag": np.stack([one, one, one], 1), "signs": np.sign(np.sin(1.7 * cc + np.array([0.3, 1.1, 2.0]))),
+         "half": 0.5 * np.sign(np.cos(2.3 * cc[:, [1, 2, 0]]))}[field]
+    coarse = _structured_cloud(nx, ny, nz, rng)
+    fine = 0.5 * _structured_cloud(2 * nx, 2 * ny, 2 * nz, rng)             # the fine cells' centres, faces, edges, vertices
+    xyz = np.concatenate([coarse, fine[rng.random(len(fine)) < 0.3]])
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1.0, 4, [{}, {"box_records": 0}], lambda o: ", 3>", check_inside=False)
+
+
+def test_refined_box_kick_and_velocity_refresh_same_bits(gpu_ctx_factory):
+    """(with the kick there is no CPU statement to match; with and without the option the same kernel must run)"""
+    from cudaparticlesfoam_amd.cases import refined_box
+    rng = np.random.default_rng(3)
+    mesh, _ = refined_box(10, 9, 8, (0.0, 0.0, 0.0), (1.0, 0.9, 0.8), ((0.2, 0.2, 0.2), (0.7, 0.7, 0.6)))
+    U = rng.normal(size=(mesh.n_cells, 3))
+    xyz = rng.random((40000, 3)) * np.array([1.0, 0.9, 0.8])
+    outs = []
+    for opts in ({}, {"box_records": 0}):
+        ctx = gpu_ctx_factory()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_mesh(mesh); ctx.set_velocity(U); ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
+        ctx.set_seed(5)
+        ctx.step(0.04, 1e-3, 6)
+        U2 = U[::-1].copy()
+        ctx.set_velocity(U2)                                    # (a velocity refresh between two launches)
+        ctx.step(0.04, 1e-3, 3, 2)
+        xyzw, cell, vel = ctx.get_particles(want_vel=True)
+        outs.append((xyzw.copy(), cell.copy(), vel.copy(), ctx.counters()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0].view(np.int64), outs[1][0].view(np.int64))
+    assert np.array_equal(outs[0][2].view(np.int64), outs[1][2].view(np.int64))
+    assert outs[0][3] == outs[1][3]

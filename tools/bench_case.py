@@ -31,7 +31,7 @@ def main():
     ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     n = int(a.particles)
     for kv in a.opt:
-        if kv.split("=")[0] in ("mixed_records",):          # (options that shape the mesh tables go in before the mesh)
+        if kv.split("=")[0] in ("mixed_records", "box_records"):          # (options that shape the mesh tables go in before the mesh)
             ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     mesh, x, y, z, c, fields = make_case(a.case, ctx, torch, n, dev, a.field)
     dt = POLY_DT if a.case in POLY_CASES else 1e-4
