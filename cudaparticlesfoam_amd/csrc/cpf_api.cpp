@@ -130,6 +130,7 @@ cpf::MeshView meshView(const cpf_context* c) {
     m.allHex = (c->host.minCellFaces == 6 && c->host.maxCellFaces == 6 && c->host.nGroups() == 0) ? 1 : 0;
     m.zPairLast = c->host.zPairLast ? 1 : 0;
     m.zThin = (c->host.zThin && c->zFold) ? 1 : 0;
+    m.zSide0 = c->host.zSide0 ? 1 : 0;
     m.mixed = (c->d_cellRec && !m.allHex) ? (c->host.nBigCells > 0 ? 2 : 1) : 0;      // 2: two-record and / or header cells
     return m;
 }
@@ -184,6 +185,7 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     freeMesh(ctx);
+    ctx->streamState.flatField = false;
     ctx->host = std::move(t);
     const cpf::HostTables& h = ctx->host;
     auto up = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
@@ -463,6 +465,12 @@ int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
     CPF_REQUIRE(ctx, U && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity: U is null or nCells differs from the mesh");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_U3, U, (size_t)nCells * 24, hipMemcpyHostToDevice, ctx->stream));
+    {
+        // no z component anywhere?  (the flat walk of 2-D cases, cpf_walk.h; only asked on meshes that qualify)
+        bool flat = ctx->host.zSide0;
+        for (int64_t c = 0; c < nCells && flat; ++c) flat = U[3 * c + 2] == 0.0;
+        ctx->streamState.flatField = flat;
+    }
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, ctx->d_U3, ctx->d_U, nCells));
     if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // U may be pageable host memory owned by the caller
@@ -475,6 +483,7 @@ int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells) {
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_velocity_dev: call cpf_set_mesh first");
     CPF_REQUIRE(ctx, dU && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity_dev: bad arguments");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->streamState.flatField = false;              // (a device array: not inspected)
     CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, dU, ctx->d_U, nCells));
     if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
     ctx->haveU = true;
@@ -794,6 +803,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->mixedRecords = value != 0;
         return CPF_OK;
     }
+    if (k == "flat_walk") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "flat_walk must be 0 or 1");
+        ctx->streamState.flat = (int)value;
+        return CPF_OK;
+    }
     if (k == "box_records") {
         CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "box_records must be 0 or 1");
         ctx->boxRecords = value != 0;
@@ -832,7 +846,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     }
     if (k == "stream_lookup") {
         // (2, 3, 5 on an all-hex mesh: diagnostics -- what the mixed-mesh instantiations cost by themselves; same results)
-        CPF_REQUIRE(ctx, value == -1 || (value >= 0 && value <= 6 && value == (int)value), CPF_ERR_ARG, "stream_lookup must be -1 (auto) or 0 ... 6");
+        CPF_REQUIRE(ctx, value == -1 || (value >= 0 && value <= 6 && value == (int)value), CPF_ERR_ARG, "stream_lookup must be -1 (auto) or 0 ... 6");  // (8: chosen by the library, "flat_walk")
         ctx->streamState.lookup = (int)value;
         return CPF_OK;
     }
@@ -900,7 +914,7 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
     else if (v == 4 || v == 5) {
         // (the record lookup is picked per launch from the particle count: the most recent launch's, else the owned cloud's)
-        const int lf = cpf::stream_lookup_mode(ctx->lastStepN >= 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState);
+        const int lf = cpf::stream_lookup_mode(ctx->lastStepN >= 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState, brown);
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream<%s, %s, %s, %s, %d>", b[brown], b[reflect], b[sv], b[ctx->stats], lf);
     }
     else if (v == 3) snprintf(tmp, sizeof tmp, "cpf::step_kernel_coop<%s, %s, %s, %s>", b[brown], b[reflect], b[sv], b[ctx->stats]);

@@ -25,6 +25,7 @@ struct MeshView {
     int32_t nCells;
     int32_t allHex;           // every cell has exactly 6 face slots (slot = 6*cell + s) and there are no face groups
     int32_t zPairLast;        // ... and slots 4, 5 of every cell are its two faces with an exactly z-parallel normal (cpf_mesh.cpp)
+    int32_t zSide0;           // ... and the four other faces of every cell have nz == 0 exactly (2-D mesh extruded straight in z)
     int32_t zThin;            // ... and both are boundary faces in every cell: one cell thick in z (cpf_walk.h, fold_z)
     int32_t mixed;            // records exist although the mesh is not all-hex: 1 = padded records (< 6 slots) and face groups only, 2 = header-only records (> 6 slots) as well
 };
@@ -67,11 +68,15 @@ struct StreamState {
     // per round than the 128-per-cell threshold, tuned on pitzDaily, assumes.
     const volatile unsigned long long* occupiedHost = nullptr;
     int densityLookup = 0;    // "stream_lookup_by_density"
+    // the velocity field last set has no z component anywhere (U.z == +-0 in every cell; known for fields set from the host,
+    // cpf_set_velocity): with MeshView::zSide0 and without the kick the FLAT instantiation runs (cpf_walk.h "flat walk")
+    bool flatField = false;
+    int flat = 1;             // "flat_walk": 0 = never (diagnostics; bit-identical either way)
 };
 
 hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t n, double dt, bool reflect,
                              const MeshView& m, unsigned long long* counters, StreamState& ss, double* dbg);
-int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records, 6 fixed compare + box records
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool brown = true);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records, 6 fixed compare + box records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
 constexpr int kFusedCoopCycles = 8;       // fused launches of this many cycles or more run the wave-cooperative kernel (round 3: the

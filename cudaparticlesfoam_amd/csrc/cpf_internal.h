@@ -31,6 +31,7 @@ struct HostTables {
     int64_t nHugeCells = 0;         // ... of which: more than 12 (header record + CSR walk; 7..12: two records, cpf_walk.h)
     int64_t nGroups() const { return (int64_t)groupOff.size() - 1; }
     bool zThin = false;             // zPairLast and the two z faces of every cell are boundary faces (one cell thick in z)
+    bool zSide0 = false;            // zPairLast and the other four faces of every cell have nz == 0 exactly: a 2-D mesh extruded in z (the flat walk, cpf_walk.h)
     bool zPairLast = false;         // all-hex mesh whose cells each have exactly two faces with an exactly z-parallel normal: they sit in slots 4, 5
     // [nCells][16] BOX RECORDS, or empty: every cell is an axis-aligned box (six planes with normals exactly +-e_x, +-e_y,
     // +-e_z, one of each: blockMesh cases such as the TJunction tutorial) -- 128 bytes per cell instead of the 256-byte

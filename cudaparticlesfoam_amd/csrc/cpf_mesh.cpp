@@ -235,6 +235,14 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
         }
     }
 
+    // ---- ... and extruded STRAIGHT: the four other faces of every cell have nz == 0 exactly (the flat walk, cpf_walk.h)
+    out.zSide0 = out.zPairLast;
+    for (int64_t c = 0; c < nCells && out.zSide0; ++c) {
+        const size_t s0 = (size_t)out.cellOff[(size_t)c];
+        for (int s = 0; s < 4; ++s)
+            if (out.planes[4 * (s0 + s) + 2] != 0.0) out.zSide0 = false;
+    }
+
     // ---- one cell thick in z: z-layered, the two z faces of every cell are boundary faces, and all cells share the two
     // planes (to 1e-12 of the thickness: the offsets come out of per-face centroids).  What it is for: cpf_walk.h, fold_z.
     out.zThin = out.zPairLast;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #ifndef CPF_STREAM_SLOTS_BROWN
 #define CPF_STREAM_SLOTS_BROWN 10
 #endif
-    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5) ? kStreamSlots : (LOOKUP == 6 ? (BROWNIAN ? CPF_STREAM_SLOTS_BOX_B : CPF_STREAM_SLOTS_BOX) : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed));
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5 || LOOKUP == 8) ? kStreamSlots : (LOOKUP == 6 ? (BROWNIAN ? CPF_STREAM_SLOTS_BOX_B : CPF_STREAM_SLOTS_BOX) : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed));
     // LOOKUP 6: the mesh's 128-byte BOX records instead of the 256-byte ones (cpf_walk.h "box records")
     constexpr bool BOX = LOOKUP == 6;
     constexpr int kStride = BOX ? 4 : kSlotStride;               // double4 per slot
@@ -180,12 +180,14 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   1e7 particles 0.673 / 0.631 -> 0.641 / 0.607; in the dense regime the same change costs 6 % (0.259 -> 0.277)
     //   5 = as 3 (mixed records without header records) with the LOOP lookup and six slots: a refined mesh that still holds
     //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see DESIGN.md 5.6)
-    constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5;
+    //   8 = as 0 with the FLAT walk (cpf_walk.h): a 2-D mesh extruded straight in z, a field without a z component, no kick
+    constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5 && LOOKUP != 8;
+    constexpr bool FLAT = LOOKUP == 8;
     constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
     const bool zFold = !BOX && BROWNIAN && REFLECT && m.zThin != 0;      // (stream_lookup_mode: no box records on a mesh one cell thick)
-    const bool zLast = !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
+    const bool zLast = !FLAT && !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
     // (a group's counter keeps counting) saturate instead of wrapping.
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
                             if (BOX) next = trace_box<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
+                            else if (FLAT) next = trace_lds4_flat<true>(S_, E, cur, rec, token, outSlot);
                             else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<(!BROWNIAN && (CPF_STREAM_L1_ZERO_SKIP || LOOKUP != 1)), mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
@@ -842,8 +845,8 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     // finer chunks and a longer tile-by-tile tail (tools/sweep3d_opts.sh: 3 / 0.2 against 4 / 0.1 on the 3-D box 0.2632 /
     // 0.2701 -> 0.2585 / 0.2661 ms, TJunction 0.1581 / 0.1708 -> 0.1569 / 0.1687, 5 particles per cell 0.682 / 0.670 -> 0.677 /
     // 0.636; pitzDaily is at its optimum with 4 / 0.1, tools/tail_sweep.sh)
-    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : ((LF == 0 || LF == 5) ? 4 : 3);
-    const double tailFraction = ss.tailFraction >= 0.0 ? ss.tailFraction : ((LF == 0 || LF == 5) ? 0.1 : 0.2);
+    int tpc = ss.tilesPerChunk > 0 ? ss.tilesPerChunk : ((LF == 0 || LF == 5 || LF == 8) ? 4 : 3);
+    const double tailFraction = ss.tailFraction >= 0.0 ? ss.tailFraction : ((LF == 0 || LF == 5 || LF == 8) ? 0.1 : 0.2);
     while (tpc > 1 && nTiles / tpc < 4 * slotsOnChip) tpc = tpc > 2 ? tpc - 1 : 1;
     // the first (1 - tailFraction) of the cloud in chunks of tpc tiles, the rest tile by tile
     int64_t bigChunks = (int64_t)((double)(nTiles / tpc) * (1.0 - tailFraction));
@@ -869,7 +872,7 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
 }
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
-int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
+int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool brown) {
     // particles per cell that HOLDS particles, if the last sort counted them for a cloud of about this size (StreamState)
     int64_t cells = m.nCells;
     if (ss.densityLookup && ss.occupiedHost != nullptr) {
@@ -881,16 +884,19 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
     const bool box = m.boxRec != nullptr && m.zThin == 0;
     if (ss.lookup >= 0) return (ss.lookup == 6 && !box) ? 1 : ss.lookup;      // "stream_lookup": 0, 1, 4 or 6 (2, 3, 5: diagnostics)
     if (n < kStreamSparsePerCell * cells) return (box && CPF_STREAM_BOX_SPARSE) ? 6 : 4;
-    return n < 128 * cells ? (box ? 6 : 1) : 0;
+    if (n < 128 * cells) return box ? 6 : 1;
+    // many particles per cell on a 2-D mesh, a field without a z component, no kick: the flat walk
+    return (!brown && ss.flat && ss.flatField && m.zSide0 != 0) ? 8 : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
                               bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
                               StreamState& ss) {
-    const int lf = stream_lookup_mode(n, m, ss);
+    const int lf = stream_lookup_mode(n, m, ss, brown);
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
+        if (lf == 8) { if (!B) return launch_stream_inst<false, R, SV, ST, 8>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss); return hipErrorInvalidValue; } \
         if (lf == 6) return launch_stream_inst<B, R, SV, ST, 6>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 5) return launch_stream_inst<B, R, SV, ST, 5>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 4) return launch_stream_inst<B, R, SV, ST, 4>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

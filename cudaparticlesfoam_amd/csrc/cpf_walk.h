@@ -308,6 +308,57 @@ __device__ __forceinline__ void trace_lds6_record(const D3& P0, const D3& Pd, co
     }
 }
 
+// FLAT WALK (MeshView::zSide0 + a velocity field without a z component + no Brownian kick: a 2-D case as both tutorials'
+// pitzDaily run it with D = 0): the mesh is z-layered with its z faces in slots 4, 5 (zPairLast) and the four side faces of
+// every cell have nz == 0 EXACTLY; no particle has a displacement in z (Pd.z == +-0 exactly: dt * 0 added to and subtracted
+// from P.z, and a mirror about a wall with nz == 0 leaves E.z alone).  Then, bit for bit: the z faces have den == +-0 for
+// every lane and are never accepted (the zLast shortcut of trace_lds6, here decided at launch instead of per round), and a
+// side face's den = fma(nz, Pd.z, t) = t and fd = fma(-nz, P0.z, u) = u up to the sign of a zero result, which no comparison
+// sees -- two FMAs per face that need not be issued, a vote and a branch per round that need not be taken, and no z in the walk.
+template <bool ZERO_SKIP>
+__device__ __forceinline__ void face_test_flat(const double4& p, int bs, const D3& P0, const D3& Pd, int token, int s,
+                                               double& dTmin, int& next, int& best) {
+    const double den = fma(p.y, Pd.y, p.x * Pd.x);
+    if (ZERO_SKIP && ballot64(den != 0.0) == 0ull) return;
+    const double fd = fma(-p.y, P0.y, fma(-p.x, P0.x, p.w));
+    if (((ballot64(den <= fd) | ballot64(fd >= 0.0)) & __builtin_amdgcn_uicmp((unsigned)bs, (unsigned)token, 33 /* ne */)) != 0ull) {
+        const bool c1 = fabs(fd) <= fabs(den), c2 = den < 0.0 || fd >= 0.0;
+        const bool c3 = fd < kTol, c4 = bs != token;
+        if (c1 && c2 && c3 && c4) {
+            const double dT = fd / den;
+            if (dT > kTol && dT < dTmin) { dTmin = dT; next = bs; best = s; }
+        }
+    }
+}
+// (S.z is left alone: fma(dT, +-0, P0.z) is P0.z)
+template <bool ZERO_SKIP>
+__device__ __forceinline__ int trace_lds4_flat(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, 0.0};
+    int next = cur, best = -1;
+    double dTmin = 2.0;
+    const int2* nb = reinterpret_cast<const int2*>(rec + 7);
+    {
+        double4 p0 = rec[0], p1 = rec[1];
+        const int2 b = nb[0];
+        CPF_PIN_W(p0, p1)
+        face_test_flat<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
+        face_test_flat<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
+    }
+    {
+        double4 p2 = rec[2], p3 = rec[3];
+        const int2 b = nb[1];
+        CPF_PIN_W(p2, p3)
+        face_test_flat<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
+        face_test_flat<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
+    }
+    if (best >= 0) {
+        S.x = fma(dTmin, Pd.x, P0.x); S.y = fma(dTmin, Pd.y, P0.y);
+        outSlot = best;
+    }
+    return next;
+}
+
 // The same six face tests, two faces per wave-uniform decision: both denominators and both plane distances are computed
 // up front (four independent FMA chains instead of two short ones between branches), then ONE test decides whether either
 // face has a candidate lane.  No zero-denominator skip: a lane with den == 0 is a candidate only with fd >= 0, and is then

@@ -193,7 +193,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert bs["D"] == 1.5e-5 and bs["sort_interval"] == 25 and bs["sorts_inside"] == 1 and bs["steps"] == 30 and 0 < bs["frac"] < 1
         assert bs["kernel"] == b["kernel"] and bs["frac"] <= bs["kernel_frac"] * 1.02
         assert af["steps"] == 4 and af["kernel"] == d["roofline"]["kernel"] and 0 < af["frac"] < 1 and af["cells_visited_per_particle_step"] > 1
-        assert tj["particles"] == 300_000 and tj["cells"] == 248_000 and tj["D"] == 1.5e-5 and tj["records_bytes_once"] == 256 * 248_000
+        assert tj["particles"] == 300_000 and tj["cells"] == 248_000 and tj["D"] == 1.5e-5 and tj["records_bytes_once"] == 128 * 248_000      # (box records)
         assert tj["kernel"].startswith("cpf::step_kernel_stream<true, true, false, false,") and 0 < tj["frac"] < 1
         assert tj["mesh_flags"]["all_hex"] == 1 and tj["mesh_flags"]["z_thin"] == 0
         a = d["config"]["strong_anchor_1e8"]               # the N = 1 point of the strong-scaling curve (here: 4e5)

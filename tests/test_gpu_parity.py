@@ -74,9 +74,65 @@ def test_lookup_method_follows_the_particles_per_cell(setup):
     cell) the pipelined-gather one, up to 128 per cell the fixed tag compare, above that the loop over distinct cells."""
     ctx, pz = setup["ctx"], setup["pz"]
     ctx.set_option("step_variant", -1); ctx.set_option("stream_lookup", -1)
-    for n, want in ((20_000, ", 4>"), (300_000, ", 1>"), (1_700_000, ", 0>")):                 # 12 225 cells: 1.6, 24.5, 139 per cell
+    ctx.set_velocity(setup["pitz"]["U_uniform"])
+    # (139 per cell: the loop lookup -- with the FLAT walk where it applies: a 2-D mesh, a field without a z component, no kick)
+    for n, want in ((20_000, ", 4>"), (300_000, ", 1>"), (1_700_000, ", 8>")):                 # 12 225 cells: 1.6, 24.5, 139 per cell
         ctx.set_particles(_seed_points(pz, n, pz.DOMAIN_BOX, seed=3))
         assert ctx.step_kernel_name(0.0, 0).endswith(want), (n, ctx.step_kernel_name(0.0, 0))
+    assert ctx.step_kernel_name(1e-5, 0).endswith(", 0>")                                       # the kick moves particles in z
+    ctx.set_option("flat_walk", 0)
+    assert ctx.step_kernel_name(0.0, 0).endswith(", 0>")
+    ctx.set_option("flat_walk", 1)
+    Uz = setup["pitz"]["U_uniform"].copy(); Uz[77, 2] = 1e-300
+    ctx.set_velocity(Uz)                                                                        # ONE cell with a z component
+    assert ctx.step_kernel_name(0.0, 0).endswith(", 0>")
+    ctx.set_velocity(setup["pitz"]["U_uniform"])
+
+
+@pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
+def test_flat_walk_bit_exact(setup, field):
+    """The FLAT instantiation (csrc/cpf_walk.h "flat walk": 2-D mesh extruded straight in z, no z velocity, no kick -- the headline
+    configuration): four side faces with two-term dot products, no z pair, no z in the walk.  Bit for bit (compared as BITS: the
+    argument is about signs of zeros) the CPU statement and the same library with ``flat_walk`` 0 -- plain and fused launches,
+    statistics, stored velocities, particles with z == -0.0 and on the front / back planes."""
+    from cudaparticlesfoam_amd import _lib as L
+    pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
+    U = setup["pitz"][field]
+    n = 1_600_000                                                   # > 128 per cell: the loop lookup
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=41)
+    zlo, zhi = pz.DOMAIN_BOX[0][2], pz.DOMAIN_BOX[1][2]
+    xyz[::7, 2] = zlo; xyz[1::7, 2] = zhi                           # on the front / back planes
+    if zlo < 0 < zhi:
+        xyz[2::7, 2] = -0.0
+    dt = 4e-4 if field == "U_uniform" else 2e-4
+    ctx.set_option("step_variant", -1); ctx.set_option("stream_lookup", -1)
+    x, y, z = (xyz[:, k].copy() for k in range(3))
+    c = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
+    st = np.zeros(3, np.int64)
+    for k in (1, 3, 8):
+        st += np.asarray(cw.step(x, y, z, c, dt, k, t, U, nthreads=cw.max_threads))
+    outs = {}
+    for flat in (1, 0):
+        ctx.set_option("flat_walk", flat)
+        ctx.set_option("stats", 1)
+        ctx.set_velocity(U); ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
+        assert ctx.step_kernel_name(0.0, 0).endswith(", 8>" if flat else ", 0>")
+        c0 = ctx.counters()
+        ctx.step(dt, 0.0, 1, 0); ctx.step(dt, 0.0, 3, L.STEP_FUSE_CYCLES); ctx.step(dt, 0.0, 8, L.STEP_STORE_VEL)
+        c1 = ctx.counters()
+        xyzw, cell, vel = ctx.get_particles(want_vel=True)
+        outs[flat] = (xyzw[:, :3].copy(), cell.copy(), vel[:, :3].copy())
+        assert c1["cells_visited"] - c0["cells_visited"] == int(st[0]) and c1["reflections"] - c0["reflections"] == int(st[1])
+    ctx.set_option("flat_walk", 1)
+    # (the cloud was sorted: compare through the sort's own order -- both runs sort alike)
+    assert np.array_equal(outs[1][1], outs[0][1])
+    assert np.array_equal(outs[1][0].view(np.int64), outs[0][0].view(np.int64))
+    live = outs[1][1] >= 0                                          # (a particle outside the mesh never gets a velocity stored)
+    assert np.array_equal(outs[1][2][live].view(np.int64), outs[0][2][live].view(np.int64))
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]   # noqa: E731
+    ref = np.stack([x, y, z], 1)
+    assert np.array_equal(key(outs[1][0]).view(np.int64), key(ref).view(np.int64))
+    assert np.array_equal(np.sort(outs[1][1]), np.sort(c))
 
 
 def test_initial_locate_matches_bruteforce(setup):

@@ -28,8 +28,9 @@ json.dump(dict(label=label, kernels=d["kernels"]), open(os.path.join(P, label + 
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", label, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(P, label + "_kernel_stats.csv"))
 if "--bench" in sys.argv:
-    main = "<false, true, false, false, 0>"      # headline: no kick, reflecting walls, no stored velocity, statistics off, loop lookup
-    k = max((k for k in steps if main in k["kernel"]), key=lambda k: k["calls"])
+    # headline: no kick, reflecting walls, no stored velocity, statistics off, loop lookup -- with the flat walk (8) since round 4
+    mains = ("<false, true, false, false, 8>", "<false, true, false, false, 0>")
+    k = max((k for k in steps if any(m in k["kernel"] for m in mains)), key=lambda k: k["calls"])
     n = 10_000_000
     out = dict(label=label, kernel=k["kernel"], particles_per_launch=n,
                rocprofv3_kernel_trace=dict(calls=k["calls"], avg_us=round(k["avg_us"], 2), min_us=round(k["min_us"], 2), max_us=round(k["max_us"], 2),

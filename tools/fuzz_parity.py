@@ -3,7 +3,9 @@
 statement, bit for bit.  Random graded/sheared hex blocks (tests/test_oracle_random._case), random cell-constant U,
 time steps that cross several cells and bounce off several walls; every case runs with the statistics on and off
 (two instantiations), plain and fused launches, sorted and unsorted clouds, and with exactly axis-aligned flow
-(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed|poly|box]
+(zero-denominator faces).  python tools/fuzz_parity.py [first_seed] [count] [mixed|poly|box|flat]
+"flat": 2-D meshes extruded straight in z (1-3 layers of sheared, graded quads), fields without a z component, more than 128
+particles per cell: the FLAT instantiation (csrc/cpf_walk.h "flat walk") against the CPU statement, positions compared as BITS.
 "box": axis-aligned boxes (uniform or graded blockMesh boxes: BOX RECORDS, csrc/cpf_walk.h) with half of the cloud snapped to
 fractions of the grid spacing and velocities that are +-1 / +-1/2 cells per step per axis on every other seed -- particles on
 faces, edges and vertices, equal dT on two or three axes: the cases the three-candidate face test hands to the six-face form.
@@ -28,6 +30,7 @@ def main():
     mixed = len(sys.argv) > 3 and sys.argv[3] in ("mixed", "poly")
     poly = len(sys.argv) > 3 and sys.argv[3] == "poly"
     box = len(sys.argv) > 3 and sys.argv[3] == "box"
+    flat = len(sys.argv) > 3 and sys.argv[3] == "flat"
     import torch  # noqa: F401  (its HIP runtime first)
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -70,8 +73,21 @@ def main():
                 mesh = box_mesh(*nb, lower=tuple(lo3), upper=tuple(lo3 + ext), grading=tuple(rng.choice([0.25, 1.0, 3.0], size=3)))
                 U = rng.normal(size=(mesh.n_cells, 3)) * ext * float(rng.choice([0.5, 2.0, 6.0]))
                 dt = float(rng.choice([0.05, 0.2]))
+        if flat:
+            import dataclasses
+            from cudaparticlesfoam_amd.cases import box_mesh
+            nb = [int(rng.integers(3, 9)), int(rng.integers(3, 8)), int(rng.integers(1, 4))]
+            mesh = box_mesh(*nb, upper=(float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.05, 0.5))),
+                            grading=tuple(rng.choice([0.3, 1.0, 2.5], size=3)))
+            P = np.array(mesh.points, dtype=np.float64)
+            sx, sy = rng.uniform(-0.4, 0.4, size=2)
+            P[:, 0], P[:, 1] = P[:, 0] + sx * P[:, 1] + 0.05 * P[:, 1] ** 2, P[:, 1] + sy * P[:, 0]      # z stays: straight extrusion
+            mesh = dataclasses.replace(mesh, points=P)
+            U = rng.normal(size=(mesh.n_cells, 3)) * float(rng.choice([0.5, 2.0, 6.0]))
+            U[:, 2] = rng.choice([0.0, -0.0], size=mesh.n_cells)
+            dt = float(rng.choice([0.02, 0.1, 0.3]))
         mode = seed % 4
-        if mode == 1 and not box:                                    # axis-aligned flow: whole families of faces have den == 0
+        if mode == 1 and not box and not flat:                                    # axis-aligned flow: whole families of faces have den == 0
             amp = float(np.abs(U).max()) or 1.0
             U = np.zeros_like(U); U[:, seed % 3] = rng.normal(size=U.shape[0]) * amp
         if mode == 2:
@@ -79,6 +95,8 @@ def main():
         t = cw.build(mesh)
         lo, hi = mesh.bounds()
         n = int(rng.integers(1000, 60000))
+        if flat:
+            n = int(mesh.n_cells * rng.integers(130, 200))
         xyz = rng.uniform(lo - 0.02 * (hi - lo), hi + 0.02 * (hi - lo), size=(n, 3))
         if box and seed % 2:                             # half of the cloud on quarter-cell positions (strictly inside the domain)
             k = n // 2
@@ -105,7 +123,9 @@ def main():
                 ctx.set_option("stats", stats)
                 if os.environ.get("CPF_FUZZ_VARIANT"):
                     ctx.set_option("step_variant", int(os.environ["CPF_FUZZ_VARIANT"]))
-                if box:
+                if flat:
+                    ctx.set_option("flat_walk", 0 if (seed + stats + fused) % 5 == 0 else 1)
+                elif box:
                     ctx.set_option("stream_lookup", (6, 6, 1, 4)[(seed // 2 + stats + 2 * fused) % 4])
                 else:
                     ctx.set_option("stream_lookup", (0, 1) [(seed // 2 + stats) % 2] if mixed else (0, 1, 4)[(seed // 2 + stats) % 3])      # all record-lookup methods of the streaming kernel
@@ -120,6 +140,8 @@ def main():
                 xyzw, cell = ctx.get_particles()
                 ok = ok and np.array_equal(cell, c) and np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) \
                     and np.array_equal(xyzw[:, 2], z)
+                if flat:                                 # bits: the flat walk's argument is about signs of zeros
+                    ok = ok and np.array_equal(xyzw[:, :3].view(np.int64), np.stack([x, y, z], 1).view(np.int64))
                 ctx.close()
                 if not ok:
                     bad += 1
