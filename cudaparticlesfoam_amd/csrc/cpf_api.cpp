@@ -34,6 +34,8 @@ struct cpf_context {
     bool boxRecords = true;         // "box_records": 0 = never use them (diagnostics; bit-identical either way)
     double4* d_cellRec = nullptr;   // packed per-cell records (all-hex meshes; mixed meshes: cpf_walk.h "cell records")
     unsigned long long* d_occupied = nullptr;   // [0] occupied cells, [1] live particles of the last sort (device) ...
+    hipEvent_t evFieldFlag = nullptr;           // recorded behind the read-back of "the field has a z component" (cpf_set_velocity_dev)
+    bool fieldFlagPending = false;              // ... and not yet seen complete: until then the field counts as having one
     unsigned long long* h_occupied = nullptr;   // ... and their pinned host copy (StreamState::occupiedHost)
     int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
@@ -253,6 +255,35 @@ WriterRegistry::~WriterRegistry() {
 
 namespace cpf { bool vtu_binary(const cpf_context* ctx) { return ctx && ctx->vtuBinary; } }
 
+namespace {
+// U[nCells][3] (device) -> the padded field and the cell records; on a mesh that qualifies for the flat walk (cpf_walk.h) the
+// kernel also notes whether any cell has a z component, and the note is read back behind it (8 bytes, asynchronous)
+hipError_t layOutField(cpf_context* ctx, const double* dU3, int64_t nCells) {
+    const bool ask = ctx->host.zSide0 && ctx->d_occupied && ctx->h_occupied;
+    ctx->streamState.flatField = false;
+    ctx->fieldFlagPending = false;
+    hipError_t e = hipSuccess;
+    if (ask) e = hipMemsetAsync(ctx->d_occupied + 2, 0, 8, ctx->stream);
+    if (e == hipSuccess) e = cpf::launch_u3_to_u4(ctx->stream, dU3, ctx->d_U, nCells, ask ? ctx->d_occupied + 2 : nullptr);
+    if (e == hipSuccess && ctx->d_cellRec) e = cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells);
+    if (e == hipSuccess && ask) {
+        e = hipMemcpyAsync(ctx->h_occupied + 2, ctx->d_occupied + 2, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->evFieldFlag, ctx->stream);
+        ctx->fieldFlagPending = e == hipSuccess;
+    }
+    return e;
+}
+// the read-back is known to be complete (after a synchronise, or its event has been seen): take the note
+void fieldFlagArrived(cpf_context* ctx) {
+    if (!ctx->fieldFlagPending) return;
+    ctx->streamState.flatField = ctx->h_occupied[2] == 0;
+    ctx->fieldFlagPending = false;
+}
+void pollFieldFlag(cpf_context* ctx) {
+    if (ctx->fieldFlagPending && hipEventQuery(ctx->evFieldFlag) == hipSuccess) fieldFlagArrived(ctx);
+}
+}  // namespace
+
 extern "C" {
 
 int cpf_abi_version(void) { return CPF_ABI_VERSION; }
@@ -274,9 +305,11 @@ int cpf_create(int device, cpf_context** out) {
     e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, (cpf::kCounterSlots * 4 + 4) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_occupied, 16);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_occupied, 16, hipHostMallocDefault);
-    if (e == hipSuccess) { ctx->h_occupied[0] = ctx->h_occupied[1] = 0; ctx->streamState.occupiedHost = ctx->h_occupied; }
+    // ([2]: "the velocity field has a z component", written by the kernel that lays the field out -- the flat walk)
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_occupied, 32);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_occupied, 32, hipHostMallocDefault);
+    if (e == hipSuccess) { ctx->h_occupied[0] = ctx->h_occupied[1] = 0; ctx->h_occupied[2] = 1; ctx->streamState.occupiedHost = ctx->h_occupied; }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFieldFlag, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->streamState.d_grab, cpf::kStreamGrabBytes);
     if (e == hipSuccess) e = hipMemset(ctx->streamState.d_grab, 0, cpf::kStreamGrabBytes);
     if (e == hipSuccess) {
@@ -309,6 +342,7 @@ int cpf_destroy(cpf_context* ctx) {
     freeMesh(ctx); freeCloud(ctx);
     freeDev(ctx->scratch); freeDev(ctx->d_counters); freeDev(ctx->streamState.d_grab); freeDev(ctx->streamState.d_hitSpill);
     freeDev(ctx->d_occupied);
+    if (ctx->evFieldFlag) { (void)hipEventDestroy(ctx->evFieldFlag); ctx->evFieldFlag = nullptr; }
     if (ctx->h_occupied) { (void)hipHostFree(ctx->h_occupied); ctx->h_occupied = nullptr; ctx->streamState.occupiedHost = nullptr; }
     freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -465,15 +499,9 @@ int cpf_set_velocity(cpf_context* ctx, const double* U, int64_t nCells) {
     CPF_REQUIRE(ctx, U && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity: U is null or nCells differs from the mesh");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_U3, U, (size_t)nCells * 24, hipMemcpyHostToDevice, ctx->stream));
-    {
-        // no z component anywhere?  (the flat walk of 2-D cases, cpf_walk.h; only asked on meshes that qualify)
-        bool flat = ctx->host.zSide0;
-        for (int64_t c = 0; c < nCells && flat; ++c) flat = U[3 * c + 2] == 0.0;
-        ctx->streamState.flatField = flat;
-    }
-    CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, ctx->d_U3, ctx->d_U, nCells));
-    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
+    CPF_HIP(ctx, layOutField(ctx, ctx->d_U3, nCells));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // U may be pageable host memory owned by the caller
+    fieldFlagArrived(ctx);
     ctx->haveU = true;
     return CPF_OK;
 }
@@ -483,9 +511,7 @@ int cpf_set_velocity_dev(cpf_context* ctx, const double* dU, int64_t nCells) {
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_set_velocity_dev: call cpf_set_mesh first");
     CPF_REQUIRE(ctx, dU && nCells == ctx->host.nCells, CPF_ERR_ARG, "cpf_set_velocity_dev: bad arguments");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->streamState.flatField = false;              // (a device array: not inspected)
-    CPF_HIP(ctx, cpf::launch_u3_to_u4(ctx->stream, dU, ctx->d_U, nCells));
-    if (ctx->d_cellRec) CPF_HIP(ctx, cpf::launch_update_record_velocity(ctx->stream, ctx->d_U, ctx->d_cellRec, ctx->d_boxRec, nCells));
+    CPF_HIP(ctx, layOutField(ctx, dU, nCells));        // (asynchronous: the flat walk waits until the flag has been seen to arrive)
     ctx->haveU = true;
     return CPF_OK;
 }
@@ -582,6 +608,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     CPF_REQUIRE(ctx, !vertexU || ctx->haveVertVel, CPF_ERR_STATE, "cpf_step: CPF_STEP_VERTEX_VELOCITY needs cpf_set_tets and cpf_set_vertex_velocity");
     const cpf::MeshView m = meshView(ctx);
     const bool fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
+    pollFieldFlag(ctx);
     const int nLaunch = fuse ? 1 : nCycles;   // fused with nCycles == 0: load+store only (bandwidth calibration)
     const int cycPerLaunch = fuse ? nCycles : 1;
     for (int c = 0; c < nLaunch; ++c) {
@@ -903,6 +930,7 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     CPF_REQUIRE(ctx, ctx && buf && bufBytes > 0, CPF_ERR_ARG, "null argument");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_step_kernel_name: call cpf_set_mesh first");
     const cpf::MeshView m = meshView(ctx);
+    pollFieldFlag(ctx);
     // (a fused launch's kernel depends on how many cycles it fuses: the most recent launch's count stands in)
     const int v = cpf::effective_step_variant(ctx->stepVariant, m, true, (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1,
                                               ctx->streamState.coopMaxCells);

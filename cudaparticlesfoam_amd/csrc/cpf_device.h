@@ -68,8 +68,8 @@ struct StreamState {
     // per round than the 128-per-cell threshold, tuned on pitzDaily, assumes.
     const volatile unsigned long long* occupiedHost = nullptr;
     int densityLookup = 0;    // "stream_lookup_by_density"
-    // the velocity field last set has no z component anywhere (U.z == +-0 in every cell; known for fields set from the host,
-    // cpf_set_velocity): with MeshView::zSide0 and without the kick the FLAT instantiation runs (cpf_walk.h "flat walk")
+    // the velocity field last set has no z component anywhere (U.z == +-0 in every cell; found by the kernel that lays the field
+    // out, read back behind it): with MeshView::zSide0 and without the kick the FLAT instantiation runs (cpf_walk.h "flat walk")
     bool flatField = false;
     int flat = 1;             // "flat_walk": 0 = never (diagnostics; bit-identical either way)
 };
@@ -110,7 +110,7 @@ hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, cons
 hipError_t launch_build_cell_records_mixed(hipStream_t st, const int32_t* cellOff, const double4* planes, const int32_t* nbr,
                                            const double4* U, const int32_t* recB, double4* rec, int64_t nCells);
 hipError_t launch_update_record_velocity(hipStream_t st, const double4* U, double4* rec, double* box, int64_t nCells);
-hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells);
+hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells, unsigned long long* zFlag = nullptr);
 
 // stage-by-stage kernels on the reference's AoS layouts
 hipError_t launch_stage_advect(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,

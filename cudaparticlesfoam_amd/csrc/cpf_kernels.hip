@@ -901,9 +901,13 @@ __global__ void pack_by_gid_kernel(const double* __restrict__ x, const double* _
         velOut[4 * g + 2] = vel ? vel[3 * i + 2] : 0.0; velOut[4 * g + 3] = -1.0;   // particles.cu:361
     }
 }
-__global__ void u3_to_u4_kernel(const double* __restrict__ u3, double4* __restrict__ u4, int64_t nCells) {
+// (zFlag: may be null; set to 1 if any cell's velocity has a z component -- what decides the flat walk, cpf_walk.h)
+__global__ void u3_to_u4_kernel(const double* __restrict__ u3, double4* __restrict__ u4, int64_t nCells, unsigned long long* zFlag) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (c < nCells) u4[c] = make_double4(u3[3 * c], u3[3 * c + 1], u3[3 * c + 2], 0.0);
+    if (c >= nCells) return;
+    const double uz = u3[3 * c + 2];
+    u4[c] = make_double4(u3[3 * c], u3[3 * c + 1], uz, 0.0);
+    if (zFlag != nullptr && !(uz == 0.0)) *zFlag = 1ull;          // (NaN counts as a component; every writer writes the same value)
 }
 // packed 256-byte cell records for all-hex meshes: [0..5] planes, [6] U, [7] six neighbour ids + pad
 __global__ void build_cell_records_kernel(const double4* __restrict__ planes, const int32_t* __restrict__ nbr,
@@ -987,8 +991,8 @@ hipError_t launch_pack_by_gid(hipStream_t st, const double* x, const double* y, 
                            velOut, n);
     return hipGetLastError();
 }
-hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells) {
-    if (nCells > 0) hipLaunchKernelGGL(u3_to_u4_kernel, grid_for(nCells), dim3(kBlock), 0, st, u3, u4, nCells);
+hipError_t launch_u3_to_u4(hipStream_t st, const double* u3, double4* u4, int64_t nCells, unsigned long long* zFlag) {
+    if (nCells > 0) hipLaunchKernelGGL(u3_to_u4_kernel, grid_for(nCells), dim3(kBlock), 0, st, u3, u4, nCells, zFlag);
     return hipGetLastError();
 }
 hipError_t launch_build_cell_records(hipStream_t st, const double4* planes, const int32_t* nbr, const double4* U,

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see DESIGN.md 5.6)
     //   8 = as 0 with the FLAT walk (cpf_walk.h): a 2-D mesh extruded straight in z, a field without a z component, no kick
     constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5 && LOOKUP != 8;
-    constexpr bool FLAT = LOOKUP == 8;
+    //   9 = as 1 with the flat walk (a 2-D mesh with fewer than 128 particles per cell: refined 2-D cases)
+    constexpr bool FLAT = LOOKUP == 8 || LOOKUP == 9;
     constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
@@ -884,9 +885,10 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool
     const bool box = m.boxRec != nullptr && m.zThin == 0;
     if (ss.lookup >= 0) return (ss.lookup == 6 && !box) ? 1 : ss.lookup;      // "stream_lookup": 0, 1, 4 or 6 (2, 3, 5: diagnostics)
     if (n < kStreamSparsePerCell * cells) return (box && CPF_STREAM_BOX_SPARSE) ? 6 : 4;
-    if (n < 128 * cells) return box ? 6 : 1;
-    // many particles per cell on a 2-D mesh, a field without a z component, no kick: the flat walk
-    return (!brown && ss.flat && ss.flatField && m.zSide0 != 0) ? 8 : 0;
+    // a 2-D mesh, a field without a z component, no kick: the flat walk (8 = 0, 9 = 1 with it)
+    const bool flat = !brown && ss.flat && ss.flatField && m.zSide0 != 0;
+    if (n < 128 * cells) return box ? 6 : (flat ? 9 : 1);
+    return flat ? 8 : 0;
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
@@ -897,6 +899,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
         if (lf == 8) { if (!B) return launch_stream_inst<false, R, SV, ST, 8>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss); return hipErrorInvalidValue; } \
+        if (lf == 9) { if (!B) return launch_stream_inst<false, R, SV, ST, 9>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss); return hipErrorInvalidValue; } \
         if (lf == 6) return launch_stream_inst<B, R, SV, ST, 6>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 5) return launch_stream_inst<B, R, SV, ST, 5>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 4) return launch_stream_inst<B, R, SV, ST, 4>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

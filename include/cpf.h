@@ -241,9 +241,9 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   LDS), cells beyond that a header record and are walked through the CSR tables inside kernel 4.
  *                   0 = such meshes run the generic walk (kernel 0)
  *   "flat_walk"     (1) a 2-D case -- mesh extruded straight in z (z faces exactly along z, every other face with nz == 0 exactly:
- *                   both tutorials' pitzDaily), velocity field without a z component (checked by cpf_set_velocity on the host
- *                   array; a field set with cpf_set_velocity_dev is not inspected), D == 0, at least 128 particles per cell --
- *                   runs kernel 4's FLAT instantiation: four side faces with two-term dot products, no z faces, no z in the
+ *                   both tutorials' pitzDaily), velocity field without a z component (noted on the device while the field is
+ *                   laid out; after cpf_set_velocity_dev the note arrives asynchronously and the field counts as having one
+ *                   until it has), D == 0, at least 8 particles per cell -- runs kernel 4's FLAT instantiations: four side faces with two-term dot products, no z faces, no z in the
  *                   walk.  0 = never.  Bit-identical either way (csrc/cpf_walk.h "flat walk", tests/test_gpu_parity.py)
  *   "box_records"   (1) on a mesh whose cells are ALL axis-aligned boxes (cpf_mesh_box_records_host) kernel 4 walks 128-byte box
  *                   records -- three candidate faces per visit instead of six -- whenever it would use the fixed tag compare

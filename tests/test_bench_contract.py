@@ -175,8 +175,9 @@ def test_bench_runs_and_prints_one_json_line(extra):
     d = _check(lines[0], need_cpu_baseline=False)
     assert d["steps"] == 6 and d["warmup"] == 2 and d["config"]["particles_total"] == 200_000
     assert d["config"]["particles_after"] == 200_000                      # every boundary reflects: nobody is lost
-    # what really ran: 2e5 particles on 12 225 cells = 16 per cell, so the fixed-compare record lookup (last parameter)
-    assert d["roofline"]["kernel"] == "cpf::step_kernel_stream<false, true, false, false, 1>"
+    # what really ran: 2e5 particles on 12 225 cells = 16 per cell, so the fixed-compare record lookup -- with the flat walk
+    # of a 2-D case without a z velocity (last parameter: 9 = 1 + flat)
+    assert d["roofline"]["kernel"] == "cpf::step_kernel_stream<false, true, false, false, 9>"
     assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None      # other launch size than the PMC run
     if extra:
         h = d["config"]["ms_in_handoff"]

@@ -20,7 +20,8 @@ def _kernel(opts):
     if opts.get("step_variant", -1) == 0:
         return "cpf::step_kernel<0,"
     if opts.get("box_records", 1) == 0:
-        return {0: ", 0>", 4: ", 4>"}.get(opts.get("stream_lookup"), ", 1>")
+        # (", 9>": a field without a z component on a box mesh is a flat case too -- csrc/cpf_walk.h "flat walk")
+        return {0: ", 0>", 4: ", 4>"}.get(opts.get("stream_lookup"), (", 1>", ", 9>"))
     return {0: ", 0>", 1: ", 1>", 4: ", 4>"}.get(opts.get("stream_lookup"), ", 6>")
 
 

@@ -76,7 +76,7 @@ def test_lookup_method_follows_the_particles_per_cell(setup):
     ctx.set_option("step_variant", -1); ctx.set_option("stream_lookup", -1)
     ctx.set_velocity(setup["pitz"]["U_uniform"])
     # (139 per cell: the loop lookup -- with the FLAT walk where it applies: a 2-D mesh, a field without a z component, no kick)
-    for n, want in ((20_000, ", 4>"), (300_000, ", 1>"), (1_700_000, ", 8>")):                 # 12 225 cells: 1.6, 24.5, 139 per cell
+    for n, want in ((20_000, ", 4>"), (300_000, ", 9>"), (1_700_000, ", 8>")):                 # 12 225 cells: 1.6, 24.5, 139 per cell
         ctx.set_particles(_seed_points(pz, n, pz.DOMAIN_BOX, seed=3))
         assert ctx.step_kernel_name(0.0, 0).endswith(want), (n, ctx.step_kernel_name(0.0, 0))
     assert ctx.step_kernel_name(1e-5, 0).endswith(", 0>")                                       # the kick moves particles in z
@@ -86,11 +86,26 @@ def test_lookup_method_follows_the_particles_per_cell(setup):
     Uz = setup["pitz"]["U_uniform"].copy(); Uz[77, 2] = 1e-300
     ctx.set_velocity(Uz)                                                                        # ONE cell with a z component
     assert ctx.step_kernel_name(0.0, 0).endswith(", 0>")
+    # a field handed over as a device array: the note "no z component" comes back asynchronously -- flat once it has been
+    # seen to arrive, never before
+    import torch
+    Ud = torch.from_numpy(np.ascontiguousarray(setup["pitz"]["U_uniform"])).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.set_velocity_dev(Ud.data_ptr(), Ud.shape[0])
+    ctx.synchronize()
+    assert ctx.step_kernel_name(0.0, 0).endswith(", 8>")
+    Uzd = torch.from_numpy(Uz).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.set_velocity_dev(Uzd.data_ptr(), Uzd.shape[0])
+    assert ctx.step_kernel_name(0.0, 0).endswith(", 0>")                                        # (pending or arrived: not flat)
+    ctx.synchronize()
+    assert ctx.step_kernel_name(0.0, 0).endswith(", 0>")
     ctx.set_velocity(setup["pitz"]["U_uniform"])
 
 
+@pytest.mark.parametrize("n,want", [(1_600_000, ", 8>"), (300_000, ", 9>")])
 @pytest.mark.parametrize("field", ["U_uniform", "U_analytic"])
-def test_flat_walk_bit_exact(setup, field):
+def test_flat_walk_bit_exact(setup, field, n, want):
     """The FLAT instantiation (csrc/cpf_walk.h "flat walk": 2-D mesh extruded straight in z, no z velocity, no kick -- the headline
     configuration): four side faces with two-term dot products, no z pair, no z in the walk.  Bit for bit (compared as BITS: the
     argument is about signs of zeros) the CPU statement and the same library with ``flat_walk`` 0 -- plain and fused launches,
@@ -98,8 +113,7 @@ def test_flat_walk_bit_exact(setup, field):
     from cudaparticlesfoam_amd import _lib as L
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     U = setup["pitz"][field]
-    n = 1_600_000                                                   # > 128 per cell: the loop lookup
-    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=41)
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=41)             # (> 128 per cell: the loop lookup; fewer: the fixed compare)
     zlo, zhi = pz.DOMAIN_BOX[0][2], pz.DOMAIN_BOX[1][2]
     xyz[::7, 2] = zlo; xyz[1::7, 2] = zhi                           # on the front / back planes
     if zlo < 0 < zhi:
@@ -116,10 +130,10 @@ def test_flat_walk_bit_exact(setup, field):
         ctx.set_option("flat_walk", flat)
         ctx.set_option("stats", 1)
         ctx.set_velocity(U); ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
-        assert ctx.step_kernel_name(0.0, 0).endswith(", 8>" if flat else ", 0>")
         c0 = ctx.counters()
         ctx.step(dt, 0.0, 1, 0); ctx.step(dt, 0.0, 3, L.STEP_FUSE_CYCLES); ctx.step(dt, 0.0, 8, L.STEP_STORE_VEL)
         c1 = ctx.counters()
+        assert ctx.step_kernel_name(0.0, 0).endswith(want if flat else {", 8>": ", 0>", ", 9>": ", 1>"}[want])
         xyzw, cell, vel = ctx.get_particles(want_vel=True)
         outs[flat] = (xyzw[:, :3].copy(), cell.copy(), vel[:, :3].copy())
         assert c1["cells_visited"] - c0["cells_visited"] == int(st[0]) and c1["reflections"] - c0["reflections"] == int(st[1])

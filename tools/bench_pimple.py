@@ -27,6 +27,8 @@ def main():
     mesh = m0.renumber_cells(x_slab_renumbering(c0)); cen, _ = mesh.cell_centres_volumes()
     t_mesh = time.perf_counter() - t0
     ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for kv in os.environ.get("CPF_OPTS", "").split():              # e.g. CPF_OPTS="flat_walk=0"
+        ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     t0 = time.perf_counter(); ctx.set_mesh(mesh); t_ingest = time.perf_counter() - t0
     base = pz.analytic_step_u(mesh, cen)
     ctx.set_velocity(base); ctx.set_option("stats", 0)
