@@ -21,6 +21,8 @@ def test_step_kernel_resources():
     assert int(big[1]) <= 72 and int(big[3]) <= 96 and int(big[8]) <= 160 * 1024 // 28, big
     brown = rows["void cpf::step_kernel_stream<true, true, false, false, 0>"]         # tutorial diffusion: 6 waves
     assert int(brown[1]) <= 80 and int(brown[8]) <= 160 * 1024 // 24, brown
+    flat = rows["void cpf::step_kernel_stream<false, true, false, false, 8>"]           # what the headline configuration runs
+    assert int(flat[1]) <= 72 and int(flat[3]) <= 96 and int(flat[8]) <= 160 * 1024 // 28, flat
     for name, r in rows.items():
         if "step_kernel_stream" in name or "step_kernel_coop" in name:
             assert int(r[4]) == 0 and int(r[7]) == 0, (name, r)            # no scratch, no VGPR spills
