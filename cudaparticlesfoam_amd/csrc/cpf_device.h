@@ -79,8 +79,9 @@ hipError_t launch_step_ahead(hipStream_t st, double* x, double* y, double* z, in
 int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool brown = true);    // 0 loop, 1 fixed compare, 4 fixed compare for sparse clouds, 2 / 3 fixed compare + mixed records with / without header records, 5 loop + mixed records, 6 fixed compare + box records
 // the variant launch_step really runs for a requested one (non-hex meshes: generic; record-offset limits)
 int effective_step_variant(int variant, const MeshView& m, bool haveStream, int cyclesPerLaunch, int coopMaxCells);
-constexpr int kFusedCoopCycles = 8;       // fused launches of this many cycles or more run the wave-cooperative kernel (round 3: the
-                                          // streaming kernel is 4 % faster per cycle at 3 fused cycles, 2 % slower at 8; it was 5 % / 10 % slower)
+constexpr int kFusedCoopCycles = 1 << 30;  // fused launches of this many cycles or more run the wave-cooperative kernel: never since round 4
+                                          // (round 3, 8: the streaming kernel was 4 % faster per cycle at 3 fused cycles, 2 % slower at 8; with
+                                          // the flat walk and box records it is 5-30 % faster at 8 and 16 -- cpf_kernels.hip, effective_step_variant)
 // ss == nullptr: the streaming variant is not available (falls back to the wave-cooperative kernel)
 hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                        double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,

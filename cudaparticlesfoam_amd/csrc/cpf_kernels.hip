@@ -441,6 +441,9 @@ int effective_step_variant(int variant, const MeshView& m, bool haveStream, int 
     // cycle on pitzDaily: 3 cycles per launch the streaming kernel is 4 % FASTER (0.0982 vs 0.1026 ms; with the Brownian
     // kick 0.181 vs 0.190), 8 cycles 2 % slower (0.0930 vs 0.0911; kick: equal).  Round 2: 5 % slower at 3, 10 % at 8.
     // (Final build of round 3, exact face normals: 8 cycles 0.0865 vs 0.0846 ms per cycle, with the kick 0.167 vs 0.172.)
+    // Round 4: the streaming kernel's flat walk and box records turned that around -- 8 cycles per launch, pitzDaily 0.0799 vs
+    // 0.0863 ms per cycle (16 cycles: 0.0783 vs 0.0822), with the kick 0.159 vs 0.169, TJunction 0.0855 vs 0.1216 -- and
+    // kFusedCoopCycles went up to "never" (the switch stays for builds without the streaming kernel).
     if (variant == kVariantAuto)
         variant = (haveStream && !(cyclesPerLaunch >= kFusedCoopCycles && m.nCells <= coopMaxCells)) ? kVariantStream : kVariantCoop;
     if ((variant == kVariantStream || variant == kVariantAhead) && !haveStream) variant = kVariantCoop;

@@ -1,5 +1,6 @@
 // Streaming step kernel (gfx950 / CDNA4, wave64): all-hex meshes, and meshes with a minority of other cells (mixed cell
-// records: padded, face groups, header records -- the LOOKUP 2 / 3 / 5 instantiations; DESIGN.md 5.2 has the table).
+// records: padded, face groups, header records -- the LOOKUP 2 / 3 / 5 instantiations; DESIGN.md 5.1 has the table; LOOKUP 6:
+// box records, 8 / 9: the flat walk of 2-D cases).
 //
 // Same fused cycle and the same per-particle arithmetic as step_kernel_coop (cpf_kernels.hip) -- advect -> Brownian
 // kick -> plane-exit walk -> wall reflect -> move, src/advect.H:96-161 -- organised around what the measurements of
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   1e7 particles 0.673 / 0.631 -> 0.641 / 0.607; in the dense regime the same change costs 6 % (0.259 -> 0.277)
     //   5 = as 3 (mixed records without header records) with the LOOP lookup and six slots: a refined mesh that still holds
     //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see DESIGN.md 5.6)
+    //   6 = as 1 on the mesh's 128-byte BOX records (every cell an axis-aligned box: cpf_walk.h "box records") -- dense and sparse
+    //   clouds alike: three candidate faces per visit, one LDS round trip per record, one cache line per gathered record
     //   8 = as 0 with the FLAT walk (cpf_walk.h): a 2-D mesh extruded straight in z, a field without a z component, no kick
     constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5 && LOOKUP != 8;
     //   9 = as 1 with the flat walk (a 2-D mesh with fewer than 128 particles per cell: refined 2-D cases)

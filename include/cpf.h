@@ -219,9 +219,9 @@ int cpf_get_counters(cpf_context* ctx, int64_t out[4]);
  * constant the reference seeds cuRAND with (cuda/particles.cu:544). */
 int cpf_set_seed(cpf_context* ctx, uint32_t seed);
 /* tuning knobs, never semantics (every step variant is bit-identical):
- *   "step_variant"  -1 (default) chosen per launch: 4, but 3 for launches that fuse 8 or more cycles
- *                     (CPF_STEP_FUSE_CYCLES: the particle stream is loaded and stored once per launch there, and kernel
- *                     3's 8 waves per SIMD win by a few per cent per cycle)
+ *   "step_variant"  -1 (default): 4 wherever the mesh has cell records, fused launches (CPF_STEP_FUSE_CYCLES) of any length
+ *                     included (until round 4 launches fusing 8 or more cycles went to 3, which was a few per cent faster
+ *                     per cycle there then)
  *                   0 generic CSR walk (any polyhedral mesh; runs by itself when more than a quarter of the cells have
  *                     more than six faces, or with option "mixed_records" 0)
  *                   3 wave-cooperative LDS cell cache on packed 256-byte cell records, one block per 128 particles

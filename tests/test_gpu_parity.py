@@ -286,8 +286,9 @@ def test_fused_cycles_and_sort_do_not_change_results(setup, gpu_ctx_factory):
 
 
 def test_kernel_choice_per_launch(setup):
-    """Default step_variant -1: single-cycle launches run the streaming kernel, launches that fuse eight or more cycles
-    the wave-cooperative one (faster there); an explicit variant is obeyed.  Results are the same either way."""
+    """Default step_variant -1: the streaming kernel, for single-cycle launches and fused ones of any length (until round 4
+    launches that fuse eight or more cycles went to the wave-cooperative kernel, which was faster there then); an explicit
+    variant is obeyed.  Results are the same either way."""
     from cudaparticlesfoam_amd import _lib as L
     pz, ctx = setup["pz"], setup["ctx"]
     ctx.set_velocity(setup["pitz"]["U_analytic"])
@@ -302,7 +303,8 @@ def test_kernel_choice_per_launch(setup):
         name2 = ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES)
         ctx.step(1e-4, 0.0, 9, L.STEP_FUSE_CYCLES)
         name9 = ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES)
-        want = {-1: ("stream", "stream", "coop"), 4: ("stream", "stream", "stream"), 3: ("coop", "coop", "coop")}[variant]
+        # (-1: the streaming kernel for fused launches of any length since round 4 -- it used to hand nine cycles to the other one)
+        want = {-1: ("stream", "stream", "stream"), 4: ("stream", "stream", "stream"), 3: ("coop", "coop", "coop")}[variant]
         assert tuple("coop" if "step_kernel_coop" in nm else "stream" if "step_kernel_stream" in nm else nm
                      for nm in (name1, name2, name9)) == want
         got.append(ctx.get_particles())
@@ -329,8 +331,9 @@ def test_coop_kernel_cell_limit_guard(setup):
             ctx.step(1e-4, 0.0, 9, L.STEP_FUSE_CYCLES)
             names.append(ctx.step_kernel_name(0.0, L.STEP_FUSE_CYCLES))
             got.append(ctx.get_particles())
-        assert all(("step_kernel_coop" in nm) == (limit == 0) for nm in names), names
-        assert all(("step_kernel_stream" in nm) == (limit != 0) for nm in names), names
+        # names[0]: the explicit variant 3; names[1]: the default, the streaming kernel whatever the limit
+        assert ("step_kernel_coop" in names[0]) == (limit == 0) and ("step_kernel_stream" in names[0]) == (limit != 0), names
+        assert "step_kernel_stream" in names[1], names
     for g in got[1:]:
         assert np.array_equal(g[0], got[0][0]) and np.array_equal(g[1], got[0][1])
     ctx.set_option("coop_max_cells", 0); ctx.set_option("step_variant", -1)
