@@ -887,10 +887,14 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool
     if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * cells) ? 5 : 3);
     const bool box = m.boxRec != nullptr && m.zThin == 0;
     if (ss.lookup >= 0) return (ss.lookup == 6 && !box) ? 1 : ss.lookup;      // "stream_lookup": 0, 1, 4 or 6 (2, 3, 5: diagnostics)
-    if (n < kStreamSparsePerCell * cells) return (box && CPF_STREAM_BOX_SPARSE) ? 6 : 4;
+    // box records whatever the density: also above 128 particles per cell they beat the loop lookup on 256-byte records (round 4,
+    // 3-D boxes of 2 048 / 20 480 / 61 440 cells with 1e7 particles: 0.1216 / 0.1648 / 0.2036 -> 0.1203 / 0.1617 / 0.1892 ms, with the
+    // kick 0.1584 / 0.2178 / 0.2729 -> 0.1568 / 0.2052 / 0.2375)
+    if (box && CPF_STREAM_BOX_SPARSE) return 6;
+    if (n < kStreamSparsePerCell * cells) return 4;
     // a 2-D mesh, a field without a z component, no kick: the flat walk (8 = 0, 9 = 1 with it)
     const bool flat = !brown && ss.flat && ss.flatField && m.zSide0 != 0;
-    if (n < 128 * cells) return box ? 6 : (flat ? 9 : 1);
+    if (n < 128 * cells) return flat ? 9 : 1;
     return flat ? 8 : 0;
 }
 

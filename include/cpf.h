@@ -246,8 +246,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   until it has), D == 0, at least 8 particles per cell -- runs kernel 4's FLAT instantiations: four side faces with two-term dot products, no z faces, no z in the
  *                   walk.  0 = never.  Bit-identical either way (csrc/cpf_walk.h "flat walk", tests/test_gpu_parity.py)
  *   "box_records"   (1) on a mesh whose cells are ALL axis-aligned boxes (cpf_mesh_box_records_host) kernel 4 walks 128-byte box
- *                   records -- three candidate faces per visit instead of six -- whenever it would use the fixed tag compare
- *                   ("stream_lookup" 1 or 4: fewer than 128 particles per cell); 0 = the 256-byte records everywhere.
+ *                   records -- three candidate faces per visit instead of six -- at every cloud density (measured faster than
+ *                   the loop lookup on 256-byte records up to 4 900 particles per cell); 0 = the 256-byte records everywhere.
  *                   Bit-identical either way (tests/test_gpu_box.py)
  *   "stream_tiles_per_chunk" (4; 3 on meshes with few particles per cell), "stream_tail_fraction" (0.1; 0.2), "stream_waves_per_cu" (0 = occupancy query):
  *                   work distribution of variant 4; "stream_lookup" (-1 = by particles per cell, 0 loop over the
