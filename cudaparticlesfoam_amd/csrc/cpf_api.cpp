@@ -236,6 +236,8 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
         CPF_HIP(ctx, e);
         ctx->nSecondRecords = nSecond;
         ctx->meshBytes += (size_t)(nCells + nSecond) * 256;
+        // every cell an axis-aligned box although the mesh has face groups (2:1-refined boxes): box records too
+        if (!h.boxRec.empty() && nSecond == 0) CPF_HIP(ctx, up(ctx->d_boxRec, h.boxRec.data(), h.boxRec.size() * 8));
     }
     ctx->meshBytes += (size_t)nCells * (sizeof(double4) + 24);
     ctx->haveMesh = true;

@@ -273,7 +273,9 @@ std::string build_tables(const double* points, int64_t nPoints, const Label* fac
     // (ties in dT go to the lower ORIGINAL slot) and the signs of the normal's two zero components (a mirrored -0.0
     // coordinate keeps its sign exactly as with the full planes).  U (doubles 10..12) is filled in on the device.
     out.boxRec.clear();
-    if (out.minCellFaces == 6 && out.maxCellFaces == 6 && out.nGroups() == 0 && nCells > 0) {
+    // (face groups are welcome -- a box with a split face keeps ONE slot for it, its neighbour code the group's: the castellated
+    // kind of refined mesh, 2:1-refined boxes without snapping)
+    if (out.minCellFaces == 6 && out.maxCellFaces == 6 && nCells > 0) {
         std::vector<double> box((size_t)nCells * 16, 0.0);
         bool ok = true;
         for (int64_t c = 0; c < nCells && ok; ++c) {

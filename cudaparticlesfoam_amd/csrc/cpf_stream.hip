@@ -115,9 +115,9 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
-    static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
+    static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : (kMixed ? 6 : (LOOKUP == 6 ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -129,9 +129,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #ifndef CPF_STREAM_SLOTS_BROWN
 #define CPF_STREAM_SLOTS_BROWN 10
 #endif
-    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5 || LOOKUP == 8) ? kStreamSlots : (LOOKUP == 6 ? (BROWNIAN ? CPF_STREAM_SLOTS_BOX_B : CPF_STREAM_SLOTS_BOX) : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed));
+    constexpr int NS = (LOOKUP == 0 || LOOKUP == 5 || LOOKUP == 8) ? kStreamSlots : ((LOOKUP == 6 || LOOKUP == 11) ? (BROWNIAN ? CPF_STREAM_SLOTS_BOX_B : CPF_STREAM_SLOTS_BOX) : (BROWNIAN && LOOKUP == 1 ? CPF_STREAM_SLOTS_BROWN : kStreamSlotsFixed));
     // LOOKUP 6: the mesh's 128-byte BOX records instead of the 256-byte ones (cpf_walk.h "box records")
-    constexpr bool BOX = LOOKUP == 6;
+    constexpr bool BOX = LOOKUP == 6 || LOOKUP == 11;             // (11: ... on a mesh with face groups: 2:1-refined boxes)
     constexpr int kStride = BOX ? 4 : kSlotStride;               // double4 per slot
     constexpr unsigned kRecBytes = 32u * kStride;
     constexpr unsigned ALL = NS == 32 ? 0xFFFFFFFFu : ((1u << NS) - 1u);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
 #endif
     constexpr bool HIT_IN_REGS = !BROWNIAN && (LOOKUP != 2 || CPF_STREAM_HIT_REGS_L2);
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
-    static_assert(!(kInRound && (LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5)), "in-round reflection knows neither face groups nor two-record cells");
-    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5) ? 16 : CPF_STREAM_HIT_POOL);
+    static_assert(!(kInRound && (LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11)), "in-round reflection knows neither face groups nor two-record cells");
+    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11) ? 16 : CPF_STREAM_HIT_POOL);
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     constexpr bool LOOKUP_FIXED = LOOKUP != 0 && LOOKUP != 5 && LOOKUP != 8;
     //   9 = as 1 with the flat walk (a 2-D mesh with fewer than 128 particles per cell: refined 2-D cases)
     constexpr bool FLAT = LOOKUP == 8 || LOOKUP == 9;
-    constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5;
+    constexpr bool mixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11;
     constexpr bool bigCells = LOOKUP == 2;
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
     const bool zFold = !BOX && BROWNIAN && REFLECT && m.zThin != 0;      // (stream_lookup_mode: no box records on a mesh one cell thick)
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // few particles per cell = a 3-D mesh: every face is live, two faces per decision (cpf_walk.h;
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
-                            if (BOX) next = trace_box<!BROWNIAN>(S_, E, cur, rec, token, outSlot);
+                            if (BOX) next = trace_box<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot);
                             else if (FLAT) next = trace_lds4_flat<true>(S_, E, cur, rec, token, outSlot);
                             else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                     key2 = 0;
                                 }
                             }
-                            if (BOX) next = trace_box<false>(S_, E, cur, rec, token, outSlot);
+                            if (BOX) next = trace_box<false, mixed>(S_, E, cur, rec, token, outSlot);
                             else if (!gBig)
                             next = trace_fixed<6, false, mixed, kGatherAhead>(S_, E, cur, rec, reinterpret_cast<const int32_t*>(rec + 7), token, outSlot, 0);
                             if (STATS) ++st.hops;
@@ -884,6 +884,8 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool
         if (occ > 0 && occ <= cells && live > 0 && live <= 2 * n && n <= 2 * live) cells = occ;
     }
     // not all-hex: with / without big cells (more than six slots); without them and with many particles per cell, the loop lookup
+    // (every cell a box although the mesh has face groups -- 2:1-refined boxes: box records with group slots, 11)
+    if (m.mixed == 1 && m.boxRec != nullptr && m.zThin == 0 && ss.lookup < 0) return 11;
     if (m.mixed) return m.mixed == 2 ? 2 : ((ss.lookup >= 0 ? ss.lookup == 0 : n >= 128 * cells) ? 5 : 3);
     const bool box = m.boxRec != nullptr && m.zThin == 0;
     if (ss.lookup >= 0) return (ss.lookup == 6 && !box) ? 1 : ss.lookup;      // "stream_lookup": 0, 1, 4 or 6 (2, 3, 5: diagnostics)
@@ -906,6 +908,7 @@ hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, i
 #define CPF_STREAM_GO(B, R, SV, ST)                                                                                          \
     do {                                                                                                                     \
         if (lf == 8) { if (!B) return launch_stream_inst<false, R, SV, ST, 8>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss); return hipErrorInvalidValue; } \
+        if (lf == 11) return launch_stream_inst<B, R, SV, ST, 11>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 9) { if (!B) return launch_stream_inst<false, R, SV, ST, 9>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss); return hipErrorInvalidValue; } \
         if (lf == 6) return launch_stream_inst<B, R, SV, ST, 6>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \
         if (lf == 5) return launch_stream_inst<B, R, SV, ST, 5>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss);  \

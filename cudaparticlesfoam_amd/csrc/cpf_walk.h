@@ -453,6 +453,7 @@ __device__ __forceinline__ double4 box_wall_plane(const double4* rec4, int k) {
     return p;
 }
 // the reference's predicate on all six faces of a box record, ties to the lower ORIGINAL slot (rare path of trace_box)
+template <bool GROUPS>
 __device__ __forceinline__ void trace_box_slow(const D3& P0, const D3& Pd, const double4* rec4, int token, double& dTmin, int& next, int& best) {
     const double* rd = reinterpret_cast<const double*>(rec4);
     const int* ri = reinterpret_cast<const int*>(rec4);
@@ -471,10 +472,16 @@ __device__ __forceinline__ void trace_box_slow(const D3& P0, const D3& Pd, const
         double dT = fd / den;
         if (__builtin_isinf(dT)) dT = -1.0;
         if (nb == token) continue;
+        if (GROUPS && is_group(nb) && !(den < 0.0)) continue;       // face groups: outward crossings only (trace_in_cell)
         if (fd < kTol && dT > kTol && dT <= 1.0 && (dT < dTmin || (dT == dTmin && ord < ordBest))) { dTmin = dT; next = nb; best = k; ordBest = ord; }
     }
 }
-template <bool ZERO_SKIP>
+// GROUPS (a mesh of boxes with face groups -- 2:1-refined boxes, the castellated kind: a box with a split face keeps one slot for
+// it, neighbour code = the group's): a group slot is only ever left with den < 0, i.e. through the face the particle moves
+// TOWARDS -- the three candidates cover it as they are; away from it (den > 0) it is never accepted, so it does not count
+// among the "outside a face" lanes either (a lane that came INTO the big cell through one of the group's pieces sits on that
+// face with a token that is not the group's code)
+template <bool ZERO_SKIP, bool GROUPS = false>
 __device__ __forceinline__ int trace_box(D3& S, const D3& E, int cur, const double4* rec4, int token, int& outSlot) {
     const D3 P0 = S;
     const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
@@ -486,14 +493,11 @@ __device__ __forceinline__ int trace_box(D3& S, const D3& E, int cur, const doub
     int next = cur, best = -1;
     double dTmin = 2.0;
     // lanes the three-candidate form does not cover (see above); voted on once, after the candidates
-    const unsigned long long odd =
-        (ballot64(f0 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.x, (unsigned)token, 33 /* ne */)) |
-        (ballot64(f1 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.y, (unsigned)token, 33)) |
-        (ballot64(f2 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.z, (unsigned)token, 33)) |
-        (ballot64(f3 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nA.w, (unsigned)token, 33)) |
-        (ballot64(f4 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nB.x, (unsigned)token, 33)) |
-        (ballot64(f5 > 0.0) & __builtin_amdgcn_uicmp((unsigned)nB.y, (unsigned)token, 33)) |
-        ballot64(!(fabs(Pd.x) + fabs(Pd.y) + fabs(Pd.z) < __builtin_inf()));
+#define CPF_BOX_ODD(F, NB) (ballot64(F > 0.0) & __builtin_amdgcn_uicmp((unsigned)NB, (unsigned)token, 33 /* ne */) & (GROUPS ? ballot64(!is_group(NB)) : ~0ull))
+    const unsigned long long odd = CPF_BOX_ODD(f0, nA.x) | CPF_BOX_ODD(f1, nA.y) | CPF_BOX_ODD(f2, nA.z) | CPF_BOX_ODD(f3, nA.w) |
+                                   CPF_BOX_ODD(f4, nB.x) | CPF_BOX_ODD(f5, nB.y) |
+                                   ballot64(!(fabs(Pd.x) + fabs(Pd.y) + fabs(Pd.z) < __builtin_inf()));
+#undef CPF_BOX_ODD
     bool tie = false;
 #define CPF_BOX_AXIS(A, D, FD0, FD1, NB0, NB1)                                                                     \
     if (!ZERO_SKIP || ballot64(D != 0.0) != 0ull) {                                                                \
@@ -516,7 +520,7 @@ __device__ __forceinline__ int trace_box(D3& S, const D3& E, int cur, const doub
 #undef CPF_BOX_AXIS
     if ((odd | ballot64(tie)) != 0ull) {
         next = cur; best = -1; dTmin = 2.0;
-        trace_box_slow(P0, Pd, rec4, token, dTmin, next, best);
+        trace_box_slow<GROUPS>(P0, Pd, rec4, token, dTmin, next, best);
     }
     if (best >= 0) {
         S = axpy(dTmin, Pd, P0);

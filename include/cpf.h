@@ -245,7 +245,8 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   laid out; after cpf_set_velocity_dev the note arrives asynchronously and the field counts as having one
  *                   until it has), D == 0, at least 8 particles per cell -- runs kernel 4's FLAT instantiations: four side faces with two-term dot products, no z faces, no z in the
  *                   walk.  0 = never.  Bit-identical either way (csrc/cpf_walk.h "flat walk", tests/test_gpu_parity.py)
- *   "box_records"   (1) on a mesh whose cells are ALL axis-aligned boxes (cpf_mesh_box_records_host) kernel 4 walks 128-byte box
+ *   "box_records"   (1) on a mesh whose cells are ALL axis-aligned boxes (cpf_mesh_box_records_host; 2:1-refined boxes with their
+ *                   face groups included) kernel 4 walks 128-byte box
  *                   records -- three candidate faces per visit instead of six -- at every cloud density (measured faster than
  *                   the loop lookup on 256-byte records up to 4 900 particles per cell); 0 = the 256-byte records everywhere.
  *                   Bit-identical either way (tests/test_gpu_box.py)

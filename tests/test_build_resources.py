@@ -26,4 +26,4 @@ def test_step_kernel_resources():
     for name, r in rows.items():
         if "step_kernel_stream" in name or "step_kernel_coop" in name:
             assert int(r[4]) == 0 and int(r[7]) == 0, (name, r)            # no scratch, no VGPR spills
-    assert len([n for n in rows if "step_kernel_stream" in n]) == 128
+    assert len([n for n in rows if "step_kernel_stream" in n]) == 144

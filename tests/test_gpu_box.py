@@ -147,10 +147,10 @@ def _refined_unit_box(nx, ny, nz, region):
 
 @pytest.mark.parametrize("seed", [1, 2])
 def test_refined_box_random_cloud(oracle_libs, gpu_ctx_factory, seed):
-    """A 2:1-refined box (face groups around the refined block: the snappyHexMesh kind of mesh).  Its cells are all axis-aligned
-    boxes too, but a mesh with face groups walks the ordinary mixed records (box data inside them were built and measured in round
-    4: slower on dense clouds, docs/experiments.md) -- ``box_records`` must be a no-op there.  Bit-identical to the CPU statement
-    with both lookups, sparse and dense."""
+    """A 2:1-refined box (face groups around the refined block: castellated snappyHexMesh output).  Its cells are all axis-aligned
+    boxes too -- a coarse box next to the block keeps ONE slot for its split face, neighbour code = the group's -- so the mesh
+    gets box records and the LOOKUP 11 instantiation: box records + group slots (a group is only ever left through the face the
+    particle moves towards).  Bit-identical to the CPU statement and to the ordinary mixed records, sparse and dense."""
     from cudaparticlesfoam_amd.cases import refined_box
     rng = np.random.default_rng(seed)
     mesh, _ = refined_box(10, 9, 8, (-0.2, 0.0, 0.1), (1.0, 0.9, 0.9), ((0.1, 0.2, 0.3), (0.7, 0.7, 0.7)), grading=(2.0, 1.0, 0.5))
@@ -161,7 +161,7 @@ def test_refined_box_random_cloud(oracle_libs, gpu_ctx_factory, seed):
     xyz = np.array([-0.2, 0.0, 0.1]) + rng.random((n, 3)) * np.array([1.2, 0.9, 0.8])
     opts = [{}, {"box_records": 0}, {"stream_lookup": 0}, {"box_records": 0, "stream_lookup": 0}]
     _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 0.09, 6, opts,
-              lambda o: ", 5>" if o.get("stream_lookup") == 0 else ", 3>")
+              lambda o: ", 5>" if o.get("stream_lookup") == 0 else (", 3>" if o.get("box_records", 1) == 0 else ", 11>"))
 
 
 @pytest.mark.parametrize("field", ["diag", "signs", "half"])
@@ -178,11 +178,12 @@ def test_refined_box_ties_and_faces(oracle_libs, gpu_ctx_factory, field):
     coarse = _structured_cloud(nx, ny, nz, rng)
     fine = 0.5 * _structured_cloud(2 * nx, 2 * ny, 2 * nz, rng)             # the fine cells' centres, faces, edges, vertices
     xyz = np.concatenate([coarse, fine[rng.random(len(fine)) < 0.3]])
-    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1.0, 4, [{}, {"box_records": 0}], lambda o: ", 3>", check_inside=False)
+    _run_case(oracle_libs, gpu_ctx_factory, mesh, U, xyz, 1.0, 4, [{}, {"box_records": 0}],
+              lambda o: ", 3>" if o.get("box_records", 1) == 0 else ", 11>", check_inside=False)
 
 
 def test_refined_box_kick_and_velocity_refresh_same_bits(gpu_ctx_factory):
-    """(with the kick there is no CPU statement to match; with and without the option the same kernel must run)"""
+    """(with the kick there is no CPU statement to match: box records with group slots against the ordinary mixed records)"""
     from cudaparticlesfoam_amd.cases import refined_box
     rng = np.random.default_rng(3)
     mesh, _ = refined_box(10, 9, 8, (0.0, 0.0, 0.0), (1.0, 0.9, 0.8), ((0.2, 0.2, 0.2), (0.7, 0.7, 0.6)))

@@ -68,8 +68,9 @@ def _kernel_for(opts):
     if opts.get("mixed_records", 1) == 0 or opts.get("step_variant", -1) == 0:
         return "cpf::step_kernel<0,"
     # step_kernel_stream<..., 3>: fixed compare + mixed records, no cell with > 6 slots; 5: the same with the loop lookup
-    # (picked above 128 particles per cell, or by the option)
-    return {0: ", 5>", 1: ", 3>"}.get(opts.get("stream_lookup"), (", 3>", ", 5>"))
+    # (picked above 128 particles per cell, or by the option); 11: a refined mesh whose cells are all axis-aligned boxes walks
+    # box records with group slots (tests/test_gpu_box.py) unless a lookup is asked for
+    return {0: ", 5>", 1: ", 3>"}.get(opts.get("stream_lookup"), (", 3>", ", 5>", ", 11>"))
 
 
 def _kernel_for_big(opts):
@@ -277,7 +278,7 @@ def test_diffusion_on_a_mixed_mesh_loses_nobody(which, oracle_libs, gpu_ctx_fact
     if which == "refined_box":
         from cudaparticlesfoam_amd.cases import refined_box
         mesh, _ = refined_box(8, 6, 5, (0, 0, 0), (8, 6, 5), ((2.0, 1.5, 1.0), (6.0, 4.5, 4.0)), grading=(2.0, 1.0, 0.5))
-        hi, want = [8, 6, 5], ", 5>"                                  # 360 particles per cell: the loop lookup
+        hi, want = [8, 6, 5], ", 11>"                                 # every cell a box: box records with group slots (round 3: ", 5>")
     elif which == "cut_corners":
         from cudaparticlesfoam_amd.cases.polygons import cut_corner_box
         mesh, _ = cut_corner_box(11, 8, 3, every=4)

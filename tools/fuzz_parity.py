@@ -73,6 +73,13 @@ def main():
                 mesh = box_mesh(*nb, lower=tuple(lo3), upper=tuple(lo3 + ext), grading=tuple(rng.choice([0.25, 1.0, 3.0], size=3)))
                 U = rng.normal(size=(mesh.n_cells, 3)) * ext * float(rng.choice([0.5, 2.0, 6.0]))
                 dt = float(rng.choice([0.05, 0.2]))
+            box_refined = seed % 3 == 2
+            if box_refined:                              # ... with a random subset of the cells split 2 x 2 x 2: boxes with face groups (LOOKUP 11)
+                from cudaparticlesfoam_amd.cases.refine import refine_hexes
+                mask = rng.random(mesh.n_cells) < rng.choice([0.1, 0.3])
+                mask[int(rng.integers(mesh.n_cells))] = True
+                mesh, parent = refine_hexes(mesh.points, mesh.hexes, mask, split_z=True)
+                U = U[parent]
         if flat:
             import dataclasses
             from cudaparticlesfoam_amd.cases import box_mesh
@@ -125,6 +132,8 @@ def main():
                     ctx.set_option("step_variant", int(os.environ["CPF_FUZZ_VARIANT"]))
                 if flat:
                     ctx.set_option("flat_walk", 0 if (seed + stats + fused) % 5 == 0 else 1)
+                elif box and box_refined:
+                    ctx.set_option("box_records", (1, 1, 0)[(seed // 2 + stats + 2 * fused) % 3])        # 11 against 3
                 elif box:
                     ctx.set_option("stream_lookup", (6, 6, 1, 4)[(seed // 2 + stats + 2 * fused) % 4])
                 else:
