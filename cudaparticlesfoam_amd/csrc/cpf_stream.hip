@@ -94,6 +94,12 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 #ifndef CPF_STREAM_BOX_SPARSE
 #define CPF_STREAM_BOX_SPARSE 1
 #endif
+// the zero-denominator vote per face in the flat walk: off -- a 2-D mesh whose side faces are exactly parallel to everybody's
+// displacement is a mesh of boxes in axis-aligned flow; pitzDaily's trapezoids never are, and the vote costs the headline 2.3 %
+// (0.1048-0.1063 -> 0.1032-0.1033 ms, analytic field 0.0986-0.0999 -> 0.0985-0.0986).  Same results either way.
+#ifndef CPF_STREAM_FLAT_ZERO_SKIP
+#define CPF_STREAM_FLAT_ZERO_SKIP 0
+#endif
 #ifndef CPF_STREAM_SLOTS_BOX
 #define CPF_STREAM_SLOTS_BOX 9
 #endif
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                             // measured 1-2 % there, nothing with the Brownian kick, and a loss where faces drop out for
                             // zero denominators)
                             if (BOX) next = trace_box<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot);
-                            else if (FLAT) next = trace_lds4_flat<true>(S_, E, cur, rec, token, outSlot);
+                            else if (FLAT) next = trace_lds4_flat<(CPF_STREAM_FLAT_ZERO_SKIP != 0)>(S_, E, cur, rec, token, outSlot);
                             else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<(!BROWNIAN && (CPF_STREAM_L1_ZERO_SKIP || LOOKUP != 1)), mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);
