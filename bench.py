@@ -66,6 +66,10 @@ def parse(argv=None):
                          "set-up before the timed region leaves it idle for seconds; 0 = off")
     ap.add_argument("--timing-stride", type=int, default=4,
                     help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms)")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="N>1 (or --force-dist): run ONLY communicator init -> first re-cut -> one all-to-all-v with per-stage "
+                         "timings, print them as the one JSON line and exit: a failing scaling run then costs seconds and "
+                         "names the collective")
     ap.add_argument("--force-dist", action="store_true",
                     help="single rank, but still create the RCCL group and run hand-off + rebalance (smoke of the N>1 path)")
     ap.add_argument("--self-launch", action="store_true",
@@ -321,7 +325,7 @@ class GpuMachine:
     """What `run()` needs from the machine: one MI355X per rank through the C-ABI, collectives over RCCL.
     No CPU fallback: without a GPU or without the HIP library the constructor exits."""
 
-    collectives = "RCCL all-to-all"
+    collectives = "RCCL all-gather + all-reduce + grouped send/recv all-to-all-v"
 
     def __init__(self, args, rank, world, local):
         import torch
@@ -333,6 +337,8 @@ class GpuMachine:
         torch.cuda.set_device(local)
         self.device = torch.device("cuda", local)
         self.dist_on = world > 1 or args.force_dist
+        self.comm = None
+        self.control = False                                # a torch.distributed (gloo) group for the control plane exists
         if self.dist_on:
             # stdout belongs to the ONE JSON line.  This image exports NCCL_DEBUG=VERSION, which makes every rank print a
             # five-line banner on stdout (NCCL_DEBUG_FILE does not move it): ask for warnings only instead, send whatever
@@ -341,21 +347,31 @@ class GpuMachine:
                 os.environ["NCCL_DEBUG"] = "WARN"
             os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
             import datetime
-            # a stuck collective must raise (and take the rank down), not hang: process-group timeout + the watchdog's abort
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            from cudaparticlesfoam_amd import _lib as L
+            from cudaparticlesfoam_amd.parallel import Communicator, unique_id
             tmo = datetime.timedelta(seconds=max(1.0, args.collective_timeout))
             # who is where, before the first collective (stderr; one line per rank)
             print("[bench rank %d/%d] device cuda:%d of %d visible, pid %d, HSA_ENABLE_IPC_MODE_LEGACY=%s"
                   % (rank, world, local, torch.cuda.device_count(), os.getpid(), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")),
                   file=sys.stderr, flush=True)
             stage("rccl_init")
-            if "WORLD_SIZE" not in os.environ:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.device, timeout=tmo)
+            t_init = time.perf_counter()
+            # CONTROL plane (rendezvous token, barriers, the max-over-ranks clock): torch.distributed over gloo on host memory.
+            # DATA plane: the library's own RCCL communicator (cpf_comm_create: ncclCommInitRank from the token; the hand-off's
+            # all-gather / all-reduce / grouped send-recv all-to-all-v are issued by csrc/cpf_shard_core.h, not from Python)
+            token = [None]
+            if world > 1:
+                dist.init_process_group("gloo", timeout=tmo)
+                self.control = True
+                if rank == 0:
+                    token[0] = unique_id(L.COMM_RCCL)
+                dist.broadcast_object_list(token, src=0)
             else:
-                dist.init_process_group("nccl", device_id=self.device, timeout=tmo)
+                token[0] = unique_id(L.COMM_RCCL)
+            self.comm = Communicator(token[0], rank, world, local)
+            self.comm_init_s = time.perf_counter() - t_init
             if rank == 0:
-                print("[bench] rccl_ranks %d" % dist.get_world_size(), file=sys.stderr, flush=True)
+                print("[bench] rccl_ranks %d (cpf_comm_create %.2f s)" % (self.comm.world, self.comm_init_s), file=sys.stderr, flush=True)
         self.ctx = Context(local)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -364,9 +380,9 @@ class GpuMachine:
         self.ctx.set_mesh(mesh)
         self.ctx.set_velocity(U)
 
-    def make_ops(self):
-        from cudaparticlesfoam_amd.parallel import HipOps
-        return HipOps(self.ctx)
+    def make_cloud(self, cell_lo, capacity, **kw):
+        from cudaparticlesfoam_amd.parallel import ShardedCloud
+        return ShardedCloud(self.ctx, cell_lo, capacity, self.comm, **kw)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -374,21 +390,15 @@ class GpuMachine:
     def seed_in_fluid(self, n, box, seed, cell_range=None):
         return seed_in_fluid(self.ctx, self.torch, n, box, seed, self.device, cell_range)
 
-    def prepare_cloud(self, cloud, args):
-        from cudaparticlesfoam_amd import _lib as L
-        if args.force_dist and self.world == 1:
-            cloud.send_capacity = cloud.capacity
-            cloud.sendbuf = self.torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=self.torch.float64, device=self.device)
-            cloud.recvbuf = self.torch.empty(cloud.capacity * L.HANDOFF_DOUBLES, dtype=self.torch.float64, device=self.device)
-
-    def spinup(self, cloud, dt, ms):
-        """Device spin-up (see --spinup-ms): the cloud itself is untouched, the W warm-up steps and the K timed steps
-        are the first steps it ever takes."""
+    def spinup(self, scratch, dt, ms):
+        """Device spin-up (see --spinup-ms) on `scratch` = (x, y, z, cell) copies of the rank's seeded particles: the cloud
+        itself is untouched, the W warm-up steps and the K timed steps are the first steps it ever takes."""
         torch, ctx = self.torch, self.ctx
-        if ms <= 0 or cloud.n <= 0:
+        if ms <= 0 or scratch is None or scratch[0].numel() <= 0:
             return None
         sp = lambda a: a.data_ptr()   # noqa: E731
-        sx, sy, sz, sc = (a[:cloud.n].clone() for a in (cloud.x, cloud.y, cloud.z, cloud.cell))
+        sx, sy, sz, sc = scratch
+        ns = int(sx.numel())
         # (the statistics-on instantiation, like the warm-up steps: a profiler's per-kernel average of the headline
         # instantiation then covers the timed launches and nothing else)
         ctx.set_option("stats", 1)
@@ -396,17 +406,11 @@ class GpuMachine:
         ts, launches = time.perf_counter(), 0
         while (time.perf_counter() - ts) * 1e3 < ms:
             for _ in range(40):
-                ctx.step_dev(sp(sx), sp(sy), sp(sz), sp(sc), None, None, cloud.n, dt, 0.0, 0, 1, 0)
+                ctx.step_dev(sp(sx), sp(sy), sp(sz), sp(sc), None, None, ns, dt, 0.0, 0, 1, 0)
             launches += 40
             torch.cuda.synchronize()
         return {"ms": round((time.perf_counter() - ts) * 1e3, 1), "launches": launches,
                 "on": "a scratch copy of the rank's cloud, discarded; the cloud's own first steps are the warm-up steps"}
-
-    def comm_ms(self, events):
-        tot = 0.0
-        for a_, b_ in events:
-            b_.synchronize(); tot += a_.elapsed_time(b_)
-        return tot
 
     def extras(self, cloud, dt, args, box):
         """Outside the timed region, single GPU only, never `value`: (brownian, fused, steady, anchor)."""
@@ -439,19 +443,19 @@ class GpuMachine:
         # advect.H does between two output points; results identical, tests/test_gpu_parity.py)
         fused = None
         if args.fused_extra > 0:
-            p = lambda a: a.data_ptr()   # noqa: E731
             K = 8
-            ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
-                         cloud.step_index, K, L.STEP_FUSE_CYCLES)
+            a = cloud.arrays()                   # device addresses of the shard's arrays (cpf_shard_arrays)
+            s0 = cloud.step_index
+            ctx.step_dev(a["x"], a["y"], a["z"], a["cell"], a["gid"], None, a["n"], dt, 0.0, s0, K, L.STEP_FUSE_CYCLES)
             torch.cuda.synchronize()
             tf = time.perf_counter()
             for r in range(args.fused_extra):
-                ctx.step_dev(p(cloud.x), p(cloud.y), p(cloud.z), p(cloud.cell), p(cloud.gid), None, cloud.n, dt, 0.0,
-                             cloud.step_index + K * (r + 1), K, L.STEP_FUSE_CYCLES)
+                ctx.step_dev(a["x"], a["y"], a["z"], a["cell"], a["gid"], None, a["n"], dt, 0.0, s0 + K * (r + 1), K,
+                             L.STEP_FUSE_CYCLES)
             torch.cuda.synchronize()
             tf = time.perf_counter() - tf
             fused = {"cycles_per_launch": K, "launches": args.fused_extra,
-                     "Mparticle_steps_per_s": round(cloud.n * K * args.fused_extra / tf / 1e6, 1),
+                     "Mparticle_steps_per_s": round(a["n"] * K * args.fused_extra / tf / 1e6, 1),
                      "ms_per_cycle": round(tf / (K * args.fused_extra) * 1e3, 4)}
 
         # steady state -- one full sort interval, so the periodic re-sort the short window may miss is in
@@ -515,12 +519,12 @@ class GpuMachine:
     # ---- what the tutorials actually run (never `value`)
     def _fresh_cloud(self, n, box, seed, ctx=None, sort_interval=0):
         """A new single-rank cloud of n particles seeded over the fluid domain, located and sorted, on `ctx`."""
-        from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+        from cudaparticlesfoam_amd.parallel import ShardedCloud
         torch = self.torch
         ctx = ctx or self.ctx
         x, y, z, c = seed_in_fluid(ctx, torch, n, box, seed, self.device)
-        cl = ShardedCloud(HipOps(ctx), [0, ctx.mesh_info()["n_cells"]], n + 4096, self.device, send_fraction=0.0)
-        cl.set_particles(x, y, z, c, torch.arange(n, dtype=torch.int64, device=self.device))
+        cl = ShardedCloud(ctx, None, n + 4096, None, send_fraction=0.0, exchange_interval=0)
+        cl.set_particles(x, y, z, c, None)
         del x, y, z, c
         cl.sort_interval = sort_interval
         cl.sort()
@@ -623,16 +627,18 @@ class GpuMachine:
         return r
 
     def finish(self):
-        if self.dist_on:
+        if self.control:
             self.dist.barrier()
             self.dist.destroy_process_group()
+        if self.comm is not None:
+            self.comm.close()
         self.ctx.close()
 
 
 def run(args, M):
     """The measurement.  Returns the JSON record on rank 0, None elsewhere."""
     from cudaparticlesfoam_amd.cases import pitzdaily as pz
-    from cudaparticlesfoam_amd.parallel import ShardedCloud, slab_bounding_box, slab_cell_ranges, x_slab_renumbering
+    from cudaparticlesfoam_amd.parallel import slab_bounding_box, slab_cell_ranges, x_slab_renumbering
     torch, dist, rank, world, device = M.torch, M.dist, M.rank, M.world, M.device
     dist_on = world > 1 or args.force_dist
 
@@ -658,36 +664,48 @@ def run(args, M):
         box[1][0] = min(box[1][0], float(hi_pt[0]) + 1e-9)
     x, y, z, c = M.seed_in_fluid(n_local, box, 1000 + rank,
                                  (int(cell_lo[rank]), int(cell_lo[rank + 1])) if world > 1 else None)
-    gid = torch.arange(n_local, dtype=torch.int64, device=device) + rank * n_local
     # 288 GB of HBM: slack is free.  3x capacity and a send buffer as large as the shard make an overflow
     # impossible even if a whole neighbouring slab drains into this rank between two rebalances.
     cap = (int(n_local * 3.0) if world > 1 else n_local) + 4096
-    cloud = ShardedCloud(M.make_ops(), cell_lo, cap, device, rank, world, send_fraction=1.0 if world > 1 else 0.01,
-                         exchange_interval=args.exchange_interval)
+    # the shard, its hand-off buffers and every collective live behind the C-ABI (cpf_shard_*, csrc/cpf_shard_core.h)
+    cloud = M.make_cloud(cell_lo, cap, send_fraction=1.0 if dist_on else 0.01, exchange_interval=args.exchange_interval)
     cloud.force_collectives = args.force_dist
-    M.prepare_cloud(cloud, args)
     cloud.rebalance_interval = args.rebalance_interval
     cloud.overlap_steps = args.overlap_steps
-    cloud.timing_on = True
     if dist_on and args.balance == "time":
         cloud.enable_time_balancing()
     cloud.sort_interval = 0 if args.no_sort else args.sort_interval
-    cloud.set_particles(x, y, z, c, gid)
-    del x, y, z, c, gid
+    cloud.set_particles(x, y, z, c, None, first_gid=rank * n_local)
+    scratch = (x, y, z, c) if args.spinup_ms > 0 else None          # the spin-up steps these copies, never the cloud
+    del x, y, z, c
+    dry = None
     if dist_on:
         stage("first_exchange")
+        M.sync(); t_fx = time.perf_counter()
         cloud.rebalance(mesh.n_cells)         # also pays RCCL's one-time all-reduce / all-to-all set-up before timing
+        M.sync(); t_rb = time.perf_counter()
         cloud.exchange()
+        M.sync(); t_ex = time.perf_counter()
+        dry = {"comm_init_s": round(getattr(M, "comm_init_s", 0.0), 3), "first_recut_and_handoff_s": round(t_rb - t_fx, 3),
+               "second_handoff_s": round(t_ex - t_rb, 4), "handed_off": cloud.handed_off, "particles_on_rank0": cloud.n}
+        if args.dry_collectives:
+            # only init -> first re-cut -> one all-to-all-v, with per-stage timings: a failing scaling run costs seconds and
+            # names the collective (the stage trail on stderr says how far it got)
+            total = cloud.global_count()
+            M.finish()
+            stage("done")
+            return {"dry_collectives": dry, "n_gpus": world, "particles_total": total, "rccl_ranks": world} if rank == 0 else None
     if not args.no_sort:
         cloud.sort()
     M.sync()
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier()                          # (control plane: gloo)
 
     dt = 1e-4
-    spinup = M.spinup(cloud, dt, args.spinup_ms)
+    spinup = M.spinup(scratch, dt, args.spinup_ms)
+    del scratch
     ctx.set_option("stats", 1)
     counters0 = ctx.counters()
     stage("warmup")
@@ -702,9 +720,10 @@ def run(args, M):
     ctx.timing_enable(True)
     ctx.timing_read()                              # drop the warm-up launches' events
     handed0, ms0, launches0, psteps0 = cloud.handed_off, cloud.kernel_ms, cloud.kernel_launches, cloud.particle_steps
-    hhost0, ncomm0, ex0 = cloud.handoff_host_ms, len(cloud._comm_events), cloud.exchanges
-    hwait0 = getattr(cloud, "handoff_wait_ms", 0.0)
+    hhost0, ex0 = cloud.handoff_host_ms, cloud.exchanges
+    hwait0 = cloud.handoff_wait_ms
     cloud.profile_comm = True                      # keep the (start, end) events of the hand-offs' collectives
+    comm0 = cloud.comm_ms()
     M.sync(); barrier()
     stage("timed_region")
     t0 = time.perf_counter()
@@ -717,21 +736,19 @@ def run(args, M):
     psteps = cloud.particle_steps - psteps0
     ctx.timing_enable(False)
     handoff_host_ms = cloud.handoff_host_ms - hhost0
-    comm_events = cloud._comm_events[ncomm0:]
-    handoff_comm_ms = M.comm_ms(comm_events)
+    handoff_comm_ms = cloud.comm_ms() - comm0
     handoffs = cloud.exchanges - ex0
     cloud.profile_comm = False
-    rccl_ranks = dist.get_world_size() if dist_on else 1
+    rccl_ranks = world if dist_on else 1
     per_rank = [cloud.n]
-    if world > 1:
-        tn = torch.tensor([cloud.n], dtype=torch.int64, device=device)
+    if world > 1:                                  # control plane (gloo, host tensors)
+        tn = torch.tensor([cloud.n], dtype=torch.int64)
         rows = [torch.empty_like(tn) for _ in range(world)]
         dist.all_gather(rows, tn)
         per_rank = [int(r.item()) for r in rows]
-    t = torch.tensor([el], dtype=torch.float64, device=device)
-    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+        el = float(t.item())
     n_after = cloud.global_count()
 
     brown = fused = steady = anchor = None
@@ -782,10 +799,12 @@ def run(args, M):
                        "handoff_fraction_per_step": (round((cloud.handed_off - handed0) / max(1, cloud.n) / args.steps, 6)
                                                      if dist_on else None),
                        "rccl_ranks": rccl_ranks,
+                       "collectives": (M.collectives + ", issued by the library (cpf_shard_*, csrc/cpf_shard_core.h)") if dist_on else None,
+                       "first_collectives": dry,
                        "ms_in_handoff": ({"host_ms_total": round(handoff_host_ms, 3), "collectives_device_ms_total": round(handoff_comm_ms, 3),
                                           "handoffs": handoffs,
-                                          "host_wait_ms_total": round(getattr(cloud, "handoff_wait_ms", 0.0) - hwait0, 3),
-                                          "host_work_ms_per_handoff": round((handoff_host_ms - (getattr(cloud, "handoff_wait_ms", 0.0) - hwait0)) / max(1, handoffs), 4),
+                                          "host_wait_ms_total": round(cloud.handoff_wait_ms - hwait0, 3),
+                                          "host_work_ms_per_handoff": round((handoff_host_ms - (cloud.handoff_wait_ms - hwait0)) / max(1, handoffs), 4),
                                           "host_ms_per_step": round(handoff_host_ms / max(1, args.steps), 4)}
                                          if dist_on else None),
                        "ms_per_step_steady": steady, "brownian": brown, "device_spinup": spinup,

@@ -18,6 +18,7 @@ CPF_OK, CPF_ERR_ARG, CPF_ERR_STATE, CPF_ERR_MESH, CPF_ERR_HIP, CPF_ERR_NOMEM = r
 CELL_LOST, CELL_FROZEN = -1, -2
 STEP_DEFAULT, STEP_NO_REFLECT, STEP_STORE_VEL, STEP_FUSE_CYCLES, STEP_VERTEX_VELOCITY = 0, 1, 2, 4, 8
 HANDOFF_DOUBLES = 5
+MAX_RANKS, COMM_ID_BYTES, COMM_RCCL, COMM_INPROCESS = 64, 128, 1, 2
 
 
 class CpfError(RuntimeError):
@@ -37,6 +38,64 @@ class MeshPart(C.Structure):
     """cpf_mesh_part (include/cpf.h): one rank's piece of a decomposed polyMesh."""
     _fields_ = [("points", _vp), ("nPoints", _i64), ("faceOffsets", _vp), ("faceVerts", _vp), ("nFaces", _i64),
                 ("owner", _vp), ("neighbour", _vp), ("nInternalFaces", _i64), ("nCells", _i64), ("labelBytes", _int)]
+
+
+# cpf_comm (include/cpf.h): the three collectives of a hand-off, on device memory, asynchronous on a stream
+ALL_GATHER_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, C.c_size_t, _vp)
+ALL_REDUCE_FN = C.CFUNCTYPE(_int, _vp, _vp, C.c_size_t, _vp)
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(_int, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp, C.POINTER(_i64), C.POINTER(_i64), _vp)
+COMM_DESTROY_FN = C.CFUNCTYPE(None, _vp)
+COMM_ERROR_FN = C.CFUNCTYPE(C.c_char_p, _vp)
+
+
+class Comm(C.Structure):
+    _fields_ = [("self", _vp), ("rank", _int), ("nRanks", _int), ("all_gather", ALL_GATHER_FN),
+                ("all_reduce_sum_f64", ALL_REDUCE_FN), ("all_to_all_v", ALL_TO_ALL_V_FN), ("destroy", COMM_DESTROY_FN),
+                ("last_error", COMM_ERROR_FN)]
+
+
+class ShardStats(C.Structure):
+    """cpf_shard_stats (include/cpf.h)"""
+    _fields_ = [("n", _i64), ("capacity", _i64), ("stepIndex", _i64), ("particleSteps", _i64), ("handedOff", _i64),
+                ("exchanges", _i64), ("rebalances", _i64), ("grown", _i64), ("sendGrown", _i64), ("kernelLaunches", _i64),
+                ("kernelMs", _dbl), ("handoffHostMs", _dbl), ("handoffWaitMs", _dbl), ("hostWorkMsPerHandoff", _dbl),
+                ("commDeviceMs", _dbl), ("commEvents", _i64), ("overlapDepth", _i32), ("nRanks", _i32), ("rank", _i32)]
+
+
+_shard = C.c_void_p
+# the cpf_shard_* entry points: exported by the product library AND, over a host-memory stand-in device, by the tests' own
+# tests/host_shard/libcpf_shard_host.so (see bind_shard_signatures)
+SHARD_SIGNATURES = {
+    "cpf_shard_create": (_int, [_ctx, C.POINTER(Comm), _i64, _vp, C.POINTER(_shard)]),
+    "cpf_shard_destroy": (_int, [_shard]),
+    "cpf_shard_last_error": (C.c_char_p, [_shard]),
+    "cpf_shard_set_option": (_int, [_shard, C.c_char_p, _dbl]),
+    "cpf_shard_set_particles_dev": (_int, [_shard, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "cpf_shard_seed_box": (_int, [_shard, _i64, _vp, _vp, _int, C.POINTER(_i64)]),
+    "cpf_shard_step": (_int, [_shard, _dbl, _dbl, _int, C.c_uint]),
+    "cpf_shard_flush": (_int, [_shard]),
+    "cpf_shard_exchange": (_int, [_shard]),
+    "cpf_shard_rebalance": (_int, [_shard]),
+    "cpf_shard_sort": (_int, [_shard]),
+    "cpf_shard_set_velocity": (_int, [_shard, _vp, _i64]),
+    "cpf_shard_set_velocity_slice": (_int, [_shard, _vp, _i64]),
+    "cpf_shard_arrays": (_int, [_shard, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                C.POINTER(_i64), C.POINTER(_i64)]),
+    "cpf_shard_get_local": (_int, [_shard, _vp, _vp, _vp, _vp, _vp]),
+    "cpf_shard_global_count": (_int, [_shard, C.POINTER(_i64)]),
+    "cpf_shard_cell_ranges": (_int, [_shard, _vp]),
+    "cpf_shard_gather": (_int, [_shard, _int, _vp, _vp, _vp]),
+    "cpf_shard_write_vtu": (_int, [_shard, _int, C.c_char_p, C.POINTER(_dbl)]),
+    "cpf_shard_get_stats": (_int, [_shard, C.POINTER(ShardStats)]),
+}
+
+
+def bind_shard_signatures(lib):
+    for name, (res, args) in SHARD_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 # name -> (restype, argtypes); mirrors include/cpf.h one to one
@@ -114,7 +173,13 @@ SIGNATURES = {
     "cpf_timing_enable": (_int, [_ctx, _int]),
     "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
     "cpf_timing_poll": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "cpf_device_count": (_int, [C.POINTER(_int)]),
+    "cpf_comm_unique_id": (_int, [_vp, _int]),
+    "cpf_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(C.POINTER(Comm))]),
+    "cpf_comm_destroy": (None, [C.POINTER(Comm)]),
+    "cpf_comm_last_error": (C.c_char_p, []),
 }
+SIGNATURES.update(SHARD_SIGNATURES)
 
 _lib = None
 

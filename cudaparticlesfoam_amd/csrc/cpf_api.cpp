@@ -255,7 +255,13 @@ WriterRegistry::~WriterRegistry() {
 }
 }  // namespace
 
-namespace cpf { bool vtu_binary(const cpf_context* ctx) { return ctx && ctx->vtuBinary; } }
+namespace cpf {
+bool vtu_binary(const cpf_context* ctx) { return ctx && ctx->vtuBinary; }
+void* context_stream(const cpf_context* ctx) { return (void*)ctx->stream; }
+int context_device(const cpf_context* ctx) { return ctx->device; }
+bool context_timing(const cpf_context* ctx) { return ctx->timing; }
+int64_t context_cells(const cpf_context* ctx) { return ctx->haveMesh ? ctx->host.nCells : 0; }
+}  // namespace cpf
 
 namespace {
 // U[nCells][3] (device) -> the padded field and the cell records; on a mesh that qualifies for the flat walk (cpf_walk.h) the
@@ -963,8 +969,8 @@ int cpf_pack_leavers_dev(cpf_context* ctx, double* x, double* y, double* z, int3
                          const int32_t* cellLo_dev, int nRanks, int myRank, double* sendbuf, int64_t sendCapacity,
                          int64_t* counts_dev, int64_t* nStay_dev) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
-    CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && nRanks >= 1 && nRanks <= 16 && myRank >= 0 && myRank < nRanks,
-                CPF_ERR_ARG, "cpf_pack_leavers_dev: bad sizes (1..16 ranks)");
+    CPF_REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) && nRanks >= 1 && nRanks <= CPF_MAX_RANKS && myRank >= 0 && myRank < nRanks,
+                CPF_ERR_ARG, "cpf_pack_leavers_dev: bad sizes (1 .. CPF_MAX_RANKS ranks)");
     CPF_REQUIRE(ctx, cellLo_dev && counts_dev && nStay_dev && (sendbuf || sendCapacity == 0) && (n == 0 || (x && y && z && cell)),
                 CPF_ERR_ARG, "cpf_pack_leavers_dev: null array");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
@@ -990,8 +996,8 @@ int cpf_cell_histogram_dev(cpf_context* ctx, const int32_t* cell, int64_t n, dou
 int cpf_cell_ranges_dev(cpf_context* ctx, const double* weights_dev, int nRanks, int32_t* cellLo_dev) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->haveMesh, CPF_ERR_STATE, "cpf_cell_ranges_dev: call cpf_set_mesh first");
-    CPF_REQUIRE(ctx, weights_dev && cellLo_dev && nRanks >= 1 && nRanks <= 16, CPF_ERR_ARG,
-                "cpf_cell_ranges_dev: bad arguments (1 <= nRanks <= 16)");
+    CPF_REQUIRE(ctx, weights_dev && cellLo_dev && nRanks >= 1 && nRanks <= CPF_MAX_RANKS, CPF_ERR_ARG,
+                "cpf_cell_ranges_dev: bad arguments (1 <= nRanks <= CPF_MAX_RANKS)");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, cpf::cell_ranges(ctx->stream, weights_dev, ctx->host.nCells, nRanks, cellLo_dev));
     return CPF_OK;

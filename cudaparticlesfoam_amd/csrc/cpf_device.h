@@ -149,5 +149,12 @@ hipError_t cell_histogram(hipStream_t st, const int32_t* cell, int64_t n, int64_
 hipError_t cell_ranges(hipStream_t st, const double* weights, int64_t nCells, int nRanks, int32_t* cellLo);
 hipError_t unpack_arrivals(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid,
                            int64_t nStay, const double* recvbuf, int64_t nRecv);
+// output of a sharded cloud (cpf_shard_gather): records of kOutputDoubles doubles = x, y, z, cell, gid, vx, vy, vz
+constexpr int kOutputDoubles = 8;
+hipError_t pack_output(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                       const int64_t* gid, const double* vel3, double* rec, int64_t n);
+hipError_t scatter_output(hipStream_t st, const double* rec, int64_t nRec, int64_t nGlobal, double* xyzw, int32_t* cellOut,
+                          double* velOut, unsigned long long* bad);
+hipError_t sum_rows(hipStream_t st, const double* rows, int nRows, size_t count, double* out);
 
 }  // namespace cpf

@@ -13,7 +13,7 @@ namespace cpf {
 
 constexpr int kItems = 8;                    // particles per thread per tile
 constexpr int kTile = kBlock * kItems;       // 2048 particles per block
-constexpr int kMaxRanks = 16;
+constexpr int kMaxRanks = CPF_MAX_RANKS;   // 64: per-destination counters live in LDS, nothing is unrolled over ranks
 
 __device__ __forceinline__ int owner_rank(int c, const int32_t* __restrict__ cellLo, int nRanks) {
     int r = 0;
@@ -36,20 +36,19 @@ __global__ __launch_bounds__(kBlock) void count_leavers_kernel(const int32_t* __
     if (threadIdx.x < kMaxRanks) sCnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kTile;
-    int mine[kMaxRanks];
-#pragma unroll
-    for (int r = 0; r < kMaxRanks; ++r) mine[r] = 0;
+    const int lane = threadIdx.x & 63;
     for (int it = 0; it < kItems; ++it) {
         const int64_t i = base + (int64_t)it * kBlock + threadIdx.x;
         const int d = (i < n) ? classify(cell[i], cellLo, nRanks, myRank) : -1;
-        for (int r = 0; r < nRanks; ++r) {
+        // one pass per DISTINCT destination among the wave's leavers (usually none or one)
+        unsigned long long any = __ballot(d >= 0);
+        while (any) {
+            const int r = __builtin_amdgcn_readlane(d, __ffsll((long long)any) - 1);
             const unsigned long long b = __ballot(d == r);
-            if ((threadIdx.x & 63) == 0) mine[r] += __popcll(b);
+            if (lane == 0) atomicAdd(&sCnt[r], (int)__popcll(b));
+            any &= ~b;
         }
     }
-    if ((threadIdx.x & 63) == 0)
-        for (int r = 0; r < nRanks; ++r)
-            if (mine[r]) atomicAdd(&sCnt[r], mine[r]);
     __syncthreads();
     if (threadIdx.x < nRanks) blockCnt[(int64_t)blockIdx.x * nRanks + threadIdx.x] = sCnt[threadIdx.x];
 }
@@ -104,6 +103,7 @@ __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
     int32_t* __restrict__ holes, int32_t* __restrict__ fillers, unsigned long long* __restrict__ holeFill) {
     __shared__ int sWave[kBlock / 64][kMaxRanks];
     __shared__ int sRun[kMaxRanks];
+    static_assert((kBlock / 64) * kMaxRanks == kBlock, "sWave is cleared one entry per thread");
     if (holeFill[2] != 0ull) return;                          // split aborted (send buffer too small): move nothing
     if (threadIdx.x < kMaxRanks) sRun[threadIdx.x] = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -116,10 +116,15 @@ __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
         const int c = (i < n) ? cell[i] : -1;
         const int d = (i < n) ? classify(c, cellLo, nRanks, myRank) : -1;
         int myPrefix = 0;
-        for (int r = 0; r < nRanks; ++r) {
+        ((int*)sWave)[threadIdx.x] = 0;                          // kBlock == (kBlock / 64) * kMaxRanks entries
+        __syncthreads();
+        unsigned long long any = __ballot(d >= 0);
+        while (any) {                                            // per distinct destination among the wave's leavers
+            const int r = __builtin_amdgcn_readlane(d, __ffsll((long long)any) - 1);
             const unsigned long long b = __ballot(d == r);
             if (lane == 0) sWave[wave][r] = __popcll(b);
             if (d == r) myPrefix = __popcll(b & ltMask);
+            any &= ~b;
         }
         __syncthreads();
         if (d >= 0) {
@@ -341,24 +346,20 @@ __global__ __launch_bounds__(kHistBlock) void cell_ranges_kernel(const double* _
     }
     __syncthreads();
     const double total = sTotal;
-    int below[kMaxRanks];
-#pragma unroll
-    for (int q = 0; q < kMaxRanks; ++q) below[q] = 0;
+    // element i counts for every cut q with run_i < total*q/nRanks; the thresholds grow with q, so that is every q >= qmin(i),
+    // and run only grows along the chunk, so qmin does too: one LDS count per element at qmin, prefix-summed over q below
     double run = sBase[threadIdx.x];
+    int q = 1;
     for (int i = i0; i < i1; ++i) {
-#pragma unroll
-        for (int q = 1; q < kMaxRanks; ++q)
-            if (q < nRanks && run < total * (double)q / (double)nRanks) ++below[q];
+        while (q < nRanks && !(run < total * (double)q / (double)nRanks)) ++q;
+        if (q < nRanks) atomicAdd(&sCut[q], 1);
         if (i < nCells) run += w[i];
     }
-#pragma unroll
-    for (int q = 1; q < kMaxRanks; ++q)
-        if (q < nRanks && below[q]) atomicAdd(&sCut[q], below[q]);
     __syncthreads();
     if (threadIdx.x == 0) {
-        int prev = 0;
+        int prev = 0, acc = 0;
         cellLo[0] = 0;
-        for (int q = 1; q < nRanks; ++q) { prev = max(prev, sCut[q]); cellLo[q] = prev; }
+        for (int q = 1; q < nRanks; ++q) { acc += sCut[q]; prev = max(prev, acc); cellLo[q] = prev; }
         cellLo[nRanks] = nCells;
     }
 }
@@ -409,6 +410,74 @@ hipError_t unpack_arrivals(hipStream_t st, double* x, double* y, double* z, int3
     if (nRecv > 0)
         hipLaunchKernelGGL(unpack_arrivals_kernel, dim3((unsigned)((nRecv + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            x, y, z, cell, gid, nStay, recvbuf, nRecv);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Output of a sharded cloud (cpf_shard_gather): every rank packs its particles as records of CPF_OUTPUT_DOUBLES
+// doubles (x, y, z, cell, gid, vx, vy, vz), the root receives all of them and scatters them into particle-id order.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pack_output_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                             const double* __restrict__ z, const int32_t* __restrict__ cell,
+                                                             const int64_t* __restrict__ gid, const double* __restrict__ vel3,
+                                                             double* __restrict__ rec, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double* r = rec + i * kOutputDoubles;
+    r[0] = x[i]; r[1] = y[i]; r[2] = z[i];
+    r[3] = (double)cell[i];
+    r[4] = (double)gid[i];
+    r[5] = vel3 ? vel3[3 * i] : 0.0; r[6] = vel3 ? vel3[3 * i + 1] : 0.0; r[7] = vel3 ? vel3[3 * i + 2] : 0.0;
+}
+
+// bad[0] counts records whose id is outside [0, nGlobal): they are dropped
+__global__ __launch_bounds__(kBlock) void scatter_output_kernel(const double* __restrict__ rec, int64_t nRec, int64_t nGlobal,
+                                                                double* __restrict__ xyzw, int32_t* __restrict__ cellOut,
+                                                                double* __restrict__ velOut, unsigned long long* __restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nRec) return;
+    const double* r = rec + k * kOutputDoubles;
+    const int64_t g = (int64_t)r[4];
+    if (g < 0 || g >= nGlobal) { atomicAdd(bad, 1ull); return; }
+    const int32_t c = (int32_t)r[3];
+    if (xyzw) {
+        xyzw[4 * g] = r[0]; xyzw[4 * g + 1] = r[1]; xyzw[4 * g + 2] = r[2];
+        xyzw[4 * g + 3] = (c == CPF_CELL_FROZEN) ? 0.0 : 1.0;
+    }
+    if (cellOut) cellOut[g] = c;
+    if (velOut) { velOut[4 * g] = r[5]; velOut[4 * g + 1] = r[6]; velOut[4 * g + 2] = r[7]; velOut[4 * g + 3] = -1.0; }
+}
+
+hipError_t pack_output(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                       const int64_t* gid, const double* vel3, double* rec, int64_t n) {
+    if (n > 0)
+        hipLaunchKernelGGL(pack_output_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y, z, cell,
+                           gid, vel3, rec, n);
+    return hipGetLastError();
+}
+
+hipError_t scatter_output(hipStream_t st, const double* rec, int64_t nRec, int64_t nGlobal, double* xyzw, int32_t* cellOut,
+                          double* velOut, unsigned long long* bad) {
+    if (nRec > 0)
+        hipLaunchKernelGGL(scatter_output_kernel, dim3((unsigned)((nRec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, nRec,
+                           nGlobal, xyzw, cellOut, velOut, bad);
+    return hipGetLastError();
+}
+
+// In-process communicator (cpf_comm.cpp): buf[i] = rows[0][i] + rows[1][i] + ... in rank order -- the same bits on every rank
+__global__ __launch_bounds__(kBlock) void sum_rows_kernel(const double* __restrict__ rows, int nRows, size_t count,
+                                                          double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    double s = rows[i];
+    for (int r = 1; r < nRows; ++r) s += rows[(size_t)r * count + i];
+    out[i] = s;
+}
+
+hipError_t sum_rows(hipStream_t st, const double* rows, int nRows, size_t count, double* out) {
+    if (count > 0)
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, nRows,
+                           count, out);
     return hipGetLastError();
 }
 

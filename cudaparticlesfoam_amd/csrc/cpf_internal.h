@@ -57,5 +57,11 @@ extern template std::string build_tables<int64_t>(const double*, int64_t, const 
 
 // stores `message` as the context's last error (cpf_last_error); for entry points implemented outside cpf_api.cpp
 void set_context_error(cpf_context* ctx, const char* message);
+// what the sharded-cloud layer (cpf_shard.cpp) needs to know about a context it borrows
+void* context_stream(const cpf_context* ctx);       // the hipStream_t its kernels are launched on
+int context_device(const cpf_context* ctx);
+bool context_timing(const cpf_context* ctx);        // cpf_timing_enable state
+int64_t context_cells(const cpf_context* ctx);      // 0: no mesh yet
+bool vtu_binary(const cpf_context* ctx);            // option "vtu_binary"
 
 }  // namespace cpf

@@ -334,6 +334,124 @@ int cpf_unpack_arrivals_dev(cpf_context* ctx, double* x, double* y, double* z, i
                             int64_t nStay, const double* recvbuf, int64_t nRecv);
 
 /* ---------------------------------------------------------------------------------------------
+ * the sharded cloud: ONE RANK PER GPU behind this ABI.  Replaces the reference's parallel
+ * branch, where every MPI rank gathers to the master and the master alone drives one GPU
+ * (src/initCuda.H:207-484, src/advect.H:59-89): here every rank of `mpirun -np N <solver> -parallel` creates its
+ * own context on its own device, joins one communicator and owns the particles of a contiguous cell range; the
+ * mesh and U are replicated.  The layer below runs the whole hand-off -- re-cut (per-cell histogram -> all-reduce
+ * -> equal-cost cuts), split, ONE all-gather of the counts, ONE all-to-all-v of the leavers on a side stream while
+ * the step loop runs on, append, catch-up replay of the cycles the arrivals missed, growth / overflow retry --
+ * so that a host only calls cpf_shard_step.  cudaparticlesfoam_amd/parallel.py is a binding of these calls.
+ * ------------------------------------------------------------------------------------------- */
+#define CPF_MAX_RANKS 64             /* ranks of one communicator (the split kernels' per-destination counters) */
+#define CPF_COMM_ID_BYTES 128        /* == NCCL_UNIQUE_ID_BYTES */
+#define CPF_COMM_RCCL 1              /* kinds for cpf_comm_unique_id */
+#define CPF_COMM_INPROCESS 2
+/* A communicator is a table of three collectives on DEVICE memory, asynchronous on the hipStream_t they are given
+ * (every rank calls the same collective in the same order, like MPI).  The library ships two implementations
+ * (cpf_comm_create) and accepts any other: a host that would rather route the hand-off through its own transport
+ * fills the table itself (the CPU tests do, over gloo).  Offsets and sizes are BYTES. */
+typedef struct cpf_comm {
+    void* self;
+    int rank, nRanks;
+    /* recv[r * bytesPerRank ...] = rank r's send[0 .. bytesPerRank) */
+    int (*all_gather)(void* self, const void* send, void* recv, size_t bytesPerRank, void* stream);
+    /* buf[i] = sum over ranks of buf[i], in place, every rank gets the same bits */
+    int (*all_reduce_sum_f64)(void* self, double* buf, size_t count, void* stream);
+    /* send[sendOff[r] .. + sendBytes[r]) goes to rank r; recv[recvOff[r] .. + recvBytes[r]) comes from rank r;
+     * arrays of nRanks entries in host memory, valid only during the call; a pair with zero bytes is skipped */
+    int (*all_to_all_v)(void* self, const void* send, const int64_t* sendOff, const int64_t* sendBytes, void* recv,
+                        const int64_t* recvOff, const int64_t* recvBytes, void* stream);
+    void (*destroy)(void* self);     /* nullable */
+    const char* (*last_error)(void* self);   /* nullable */
+} cpf_comm;
+/* Number of HIP devices visible to this process (a rank picks device = local rank % count). */
+int cpf_device_count(int* count);
+/* The rendezvous token of a new communicator: ONE rank calls this and the host broadcasts the bytes to the others
+ * over whatever it has (Pstream::scatter, MPI_Bcast, a torch store).  kind CPF_COMM_RCCL: ncclGetUniqueId -- one
+ * process per GPU, or one thread per GPU, over xGMI.  kind CPF_COMM_INPROCESS: the ranks are threads of THIS
+ * process (any devices, also the same one -- which RCCL refuses): device-to-device copies and a barrier, for
+ * single-process hosts and for tests.  kind 0: the environment variable CPF_COMM ("rccl" / "inprocess"), else RCCL. */
+int cpf_comm_unique_id(void* id /* [CPF_COMM_ID_BYTES] */, int kind);
+/* Joins the communicator `id` names as rank `rank` of `nRanks` on HIP device `device` (collective: returns when
+ * every rank has joined).  RCCL is loaded at run time (librccl.so.1): a single-GPU host needs none. */
+int cpf_comm_create(const void* id, int rank, int nRanks, int device, cpf_comm** out);
+void cpf_comm_destroy(cpf_comm* comm);
+const char* cpf_comm_last_error(void);      /* of the calling thread's last failing cpf_comm_* call */
+
+typedef struct cpf_shard cpf_shard;
+/* This rank's shard on ctx (mesh and velocity set on ctx as for a single GPU -- every rank holds the WHOLE mesh).
+ * comm == NULL: one rank, no collectives.  capacity: particle slots to start with (the arrays grow when arrivals
+ * need more).  cellLo[nRanks + 1] (nullable: equal cell counts) = the initial ownership ranges.
+ * The shard borrows ctx and comm: destroy the shard first. */
+int cpf_shard_create(cpf_context* ctx, const cpf_comm* comm, int64_t capacity, const int32_t* cellLo, cpf_shard** out);
+int cpf_shard_destroy(cpf_shard* s);
+const char* cpf_shard_last_error(const cpf_shard* s);
+/* options (set the same on every rank):
+ *   "exchange_interval"  (0) hand particles to their owners every N cycles with FIXED ranges (0 = only inside re-cuts)
+ *   "rebalance_interval" (0) re-cut the ranges to equal cost + hand-off every N cycles (0 = never)
+ *   "overlap_steps"      (0) cycles the step loop runs on between a split and its exchange; -1 = derived from the
+ *                        measured host time of a hand-off, agreed between the ranks through the counts table
+ *   "sort_interval"      (0) re-sort the shard by cell every N cycles
+ *   "balance_by_time"    (0) cuts of equal MEASURED step time instead of equal particle counts
+ *   "send_fraction"      (0.25) initial send-buffer size as a fraction of the capacity (it grows on overflow)
+ *   "force_collectives"  (0) run the hand-off path even with one rank (smoke of the N > 1 code on one GPU)
+ *   "profile_comm"       (0) keep device time stamps around every hand-off's collectives (cpf_shard_get_stats) */
+int cpf_shard_set_option(cpf_shard* s, const char* key, double value);
+/* Fill the shard from device arrays (copied; cell == NULL: located here; gid == NULL: first, first+1, ...). */
+int cpf_shard_set_particles_dev(cpf_shard* s, const double* x, const double* y, const double* z, const int32_t* cell,
+                                const int64_t* gid, int64_t n, int64_t firstGid);
+/* cudaInitParticles + RTQuery + cudaReportParticles (src/initCuda.H:152-183) for the sharded cloud: rank r seeds the
+ * particle ids [r*nTotal/N, (r+1)*nTotal/N) of the SAME LCG stream a single GPU would draw (cpf_seed_box), locates
+ * them, the ranges are cut to equal particle counts and every particle goes to its owner.  nOutside (nullable):
+ * out-of-domain particles of the whole cloud. */
+int cpf_shard_seed_box(cpf_shard* s, int64_t nTotal, const double lower[3], const double upper[3], int order,
+                       int64_t* nOutside);
+/* nCycles Lagrangian cycles of this rank's particles (cpf_step's contract), with the hand-offs, re-cuts and sorts
+ * that fall due in between.  COLLECTIVE: every rank calls it with the same arguments.  With CPF_STEP_STORE_VEL the
+ * velocities of the last cycle stay aligned with the particles until the next call (whatever falls due on that
+ * cycle runs at the start of the next call instead). */
+int cpf_shard_step(cpf_shard* s, double dt, double D, int nCycles, unsigned flags);
+int cpf_shard_flush(cpf_shard* s);       /* completes a hand-off still in flight (arrivals appended and caught up) */
+int cpf_shard_exchange(cpf_shard* s);    /* one synchronous hand-off with the current ranges */
+int cpf_shard_rebalance(cpf_shard* s);   /* re-cut + hand-off, synchronously */
+int cpf_shard_sort(cpf_shard* s);
+/* New cell velocities (transient solvers, src/advect.H:44-84).  A hand-off in flight is completed first: its
+ * arrivals replay the cycles they missed with the field those cycles were stepped with.
+ * cpf_shard_set_velocity: the whole field from host memory (every rank holds it).
+ * cpf_shard_set_velocity_slice: THIS rank's slice -- the cells of its piece of the decomposed mesh, in the order
+ * of cpf_set_mesh_parts (global cell id = cells of the lower ranks + local id) -- 24 B per local cell cross PCIe,
+ * the slices are all-gathered between the GPUs over the communicator (the reference gathers them to the master
+ * over MPI and pushes 288 B per cell, src/advect.H:59-84). */
+int cpf_shard_set_velocity(cpf_shard* s, const double* U, int64_t nCells);
+int cpf_shard_set_velocity_slice(cpf_shard* s, const double* Uslice, int64_t nLocalCells);
+/* device pointers of the shard's arrays and its particle count (any pointer may be NULL); valid until the next call
+ * that may grow, sort or exchange.  A hand-off in flight is completed first. */
+int cpf_shard_arrays(cpf_shard* s, double** x, double** y, double** z, int32_t** cell, int64_t** gid, int64_t* n,
+                     int64_t* capacity);
+/* this rank's particles on the host (arrays of cpf_shard_arrays' n entries; any may be NULL) */
+int cpf_shard_get_local(cpf_shard* s, int64_t* gid, double* x, double* y, double* z, int32_t* cell);
+int cpf_shard_global_count(cpf_shard* s, int64_t* nGlobal);       /* collective */
+int cpf_shard_cell_ranges(cpf_shard* s, int32_t* cellLo /* [nRanks + 1] */);
+/* COLLECTIVE: the whole cloud in particle-id order on rank `root` (ids must be 0 .. nGlobal-1, as seeded):
+ * xyzw [nGlobal][4], cell [nGlobal], vel [nGlobal][4] as cpf_get_particles; other ranks pass NULLs. */
+int cpf_shard_gather(cpf_shard* s, int root, double* xyzw, int32_t* cell, double* vel);
+/* COLLECTIVE: cpf_shard_gather + the frame writer of cpf_write_vtu on `root` (option "vtu_binary" of the context). */
+int cpf_shard_write_vtu(cpf_shard* s, int root, const char* path, double* totalKE);
+typedef struct cpf_shard_stats {
+    int64_t n, capacity, stepIndex;
+    int64_t particleSteps, handedOff, exchanges, rebalances, grown, sendGrown;
+    int64_t kernelLaunches;          /* step launches whose device time the balancer drained ... */
+    double kernelMs;                 /* ... and their summed time */
+    double handoffHostMs, handoffWaitMs, hostWorkMsPerHandoff;
+    double commDeviceMs;             /* "profile_comm": device time of the hand-offs' collectives so far */
+    int64_t commEvents;
+    int32_t overlapDepth;            /* cycles the next hand-off will overlap */
+    int32_t nRanks, rank;
+} cpf_shard_stats;
+int cpf_shard_get_stats(cpf_shard* s, cpf_shard_stats* out);
+
+/* ---------------------------------------------------------------------------------------------
  * stage-by-stage entry points on the REFERENCE's array layouts, for hosts that keep the
  * reference's five-call cycle (the compat shims advect::cudaAdvect(...) etc. forward here).
  * particles/disps/vels: device [n][4] doubles (Particle / vec4d), ids: device int32 [n] holding

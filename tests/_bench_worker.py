@@ -1,7 +1,7 @@
 """Worker for tests/test_bench_contract.py: one rank of bench.run() on CPU over gloo.
 
-bench.py has no CPU path; this stand-in for its `GpuMachine` (numpy + the cell-walk oracle through tests/fake_ops.py,
-collectives over gloo) lets the N > 1 ORCHESTRATION of bench.run() -- seeding per slab, re-cut, overlapped hand-offs,
+bench.py has no CPU path; this stand-in for its `GpuMachine` (the product's hand-off logic compiled over host memory with
+the cell-walk oracle as its step -- tests/host_shard, tests/hostshard.py -- collectives over gloo) lets the N > 1 ORCHESTRATION of bench.run() -- seeding per slab, re-cut, overlapped hand-offs,
 max-over-ranks timing, the one JSON line -- run without a GPU.  The numbers it prints are meaningless as performance.
 """
 import json
@@ -16,32 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bench                                                                  # noqa: E402
-from fake_ops import FakeOps                                                  # noqa: E402
+import hostshard as H                                                         # noqa: E402
 from oracle import oracle as O                                                # noqa: E402
-
-
-class FakeCtx:
-    """The few context calls bench.run() makes besides the shard operations."""
-    def __init__(self, ops):
-        self.ops = ops
-
-    def set_option(self, key, value):
-        pass
-
-    def counters(self):
-        return {"particle_steps": 0, "cells_visited": 0, "reflections": 0, "lost": 0}
-
-    def timing_enable(self, on=True):
-        pass
-
-    def timing_read(self):
-        return self.ops.step_time(None, True)
-
-    def step_kernel_name(self, D=0.0, flags=0):
-        return "tests/fake_ops.py (CPU oracle stand-in)"
-
-    def close(self):
-        pass
 
 
 class CpuMachine:
@@ -51,16 +27,17 @@ class CpuMachine:
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.device = torch.device("cpu")
         self.cw = O.CellWalk()
-        self.ops = None
         self.ctx = None
+        self.comm = H.GlooComm(dist)
+        self.comm_init_s = 0.0
 
     def set_case(self, mesh, U):
         self.t = self.cw.build(mesh)
-        self.ops = FakeOps(self.cw, self.t, U)
-        self.ctx = FakeCtx(self.ops)
+        self.ctx = H.HostCase(self.t, U)            # the host stand-in's "context" (tests/hostshard.py)
 
-    def make_ops(self):
-        return self.ops
+    def make_cloud(self, cell_lo, capacity, **kw):
+        # parallel.ShardedCloud -- the binding the GPU path uses -- on the product's hand-off logic compiled over host memory
+        return H.cloud(self.ctx, cell_lo, capacity, self.comm, **kw)
 
     def sync(self):
         pass
@@ -80,14 +57,8 @@ class CpuMachine:
         return (torch.from_numpy(p[:, 0].copy()), torch.from_numpy(p[:, 1].copy()), torch.from_numpy(p[:, 2].copy()),
                 torch.from_numpy(c.astype(np.int32)))
 
-    def prepare_cloud(self, cloud, args):
-        pass
-
-    def spinup(self, cloud, dt, ms):
+    def spinup(self, scratch, dt, ms):
         return None
-
-    def comm_ms(self, events):
-        return 0.0
 
     def extras(self, cloud, dt, args, box):
         return None, None, None, None, {}

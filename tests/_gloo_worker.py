@@ -10,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from cudaparticlesfoam_amd.cases import box_mesh                           # noqa: E402
-from cudaparticlesfoam_amd.parallel import ShardedCloud, slab_cell_ranges, x_slab_renumbering  # noqa: E402
-from fake_ops import FakeOps                                                  # noqa: E402
+from cudaparticlesfoam_amd.parallel import slab_cell_ranges, x_slab_renumbering  # noqa: E402
+import hostshard as H                                                         # noqa: E402
 from oracle import oracle as O                                                # noqa: E402
 
 
@@ -37,11 +37,11 @@ def main():
     cell_lo = slab_cell_ranges(vols, world)
     # every rank starts with an arbitrary slice of the cloud (NOT its own slab): first exchange fixes that
     mine = np.arange(rank, n_total, world)
-    ops = FakeOps(cw, t, U, 2.0e-8 * (slow_rank0 if (slow_rank0 and rank == 0) else 1.0))
-    cloud = ShardedCloud(ops, cell_lo, capacity or (n_total + 16), torch.device("cpu"), rank, world,
-                         send_fraction=send_fraction, exchange_interval=interval)
-    cloud.set_particles(torch.from_numpy(xyz[mine, 0].copy()), torch.from_numpy(xyz[mine, 1].copy()),
-                        torch.from_numpy(xyz[mine, 2].copy()), None, torch.from_numpy(mine.astype(np.int64)))
+    # the product's hand-off logic (csrc/cpf_shard_core.h) over the host stand-in device, collectives over gloo
+    case = H.HostCase(t, U, 2.0e-8 * (slow_rank0 if (slow_rank0 and rank == 0) else 1.0))
+    cloud = H.cloud(case, cell_lo, capacity or (n_total + 16), H.GlooComm(dist), send_fraction=send_fraction,
+                    exchange_interval=interval)
+    cloud.set_particles(xyz[mine, 0].copy(), xyz[mine, 1].copy(), xyz[mine, 2].copy(), None, mine.astype(np.int64))
     cloud.exchange()
     g, x, y, z, c = cloud.gather_to_numpy()
     owned_ok = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
@@ -66,6 +66,7 @@ def main():
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
              n_local=cloud.n, grown=cloud.grown, send_grown=cloud.send_grown, cell_lo=np.asarray(cell_lo))
+    cloud.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -584,13 +584,14 @@ def test_cell_ranges_kernel_matches_host_rule(setup, n_ranks):
 
 
 def test_deferred_handoff_catch_up_is_bit_exact(setup, gpu_ctx_factory):
-    """The overlapped hand-off on one GPU, without a process group: split the cloud as rank 0 of 2, keep stepping
-    the OLD range for 3 cycles (the stale tail must be inert), then append the 'arrivals' (the send buffer itself)
-    and let them replay the 3 cycles in one fused launch.  With Brownian motion on, every particle must end
-    exactly where plain stepping puts it: the (gid, step) Philox streams make the replay order-independent."""
+    """The overlapped hand-off's device side on one GPU, call by call (the *_dev entry points the shard layer strings
+    together): split the cloud as rank 0 of 2, keep stepping the OLD range for 3 cycles (the stale tail must be inert), then
+    append the 'arrivals' (the send buffer itself) and let them replay the 3 cycles in one fused launch.  With Brownian
+    motion on, every particle must end exactly where plain stepping puts it: the (gid, step) Philox streams make the replay
+    order-independent."""
     import torch
     from cudaparticlesfoam_amd import _lib as L
-    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges
+    from cudaparticlesfoam_amd.parallel import slab_cell_ranges
     pz, mesh, cw, t = setup["pz"], setup["mesh"], setup["cw"], setup["tables"]
     U = setup["pitz"]["U_analytic"]
     dev = torch.device("cuda", 0)
@@ -601,29 +602,32 @@ def test_deferred_handoff_catch_up_is_bit_exact(setup, gpu_ctx_factory):
     x, y, z = (xyz[:, k].copy() for k in range(3))
     c = cw.locate_initial(x, y, z, t)
     gid = np.arange(n, dtype=np.int64) + 10
-    cell_lo = slab_cell_ranges(setup["pitz"]["vols"], 2)
-    cloud = ShardedCloud(HipOps(ctx), cell_lo, n + 8, dev, rank=0, world=2, send_fraction=1.0)
-    cloud.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), torch.from_numpy(c).to(dev),
-                        torch.from_numpy(gid).to(dev))
+    cell_lo = torch.from_numpy(slab_cell_ranges(setup["pitz"]["vols"], 2)).to(dev)
+    p = lambda a: a.data_ptr()     # noqa: E731
+
+    def upload():
+        return [torch.from_numpy(a).to(dev) for a in (x, y, z, c, gid)]
+    dx, dy, dz, dc, dg = upload()
+    sendbuf = torch.empty(n * L.HANDOFF_DOUBLES, dtype=torch.float64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev); nstay = torch.zeros(1, dtype=torch.int64, device=dev)
     dt, D = 1e-4, 1e-6
-    cloud.ops.step(cloud, dt, D, 0, 2, 0)                                   # steps 0, 1
-    cloud.ops.pack(cloud)                                                   # split after step 1
-    counts = cloud.counts_dev[:2].cpu().tolist(); n_stay = int(cloud.nstay_dev.item())
-    assert counts[0] == 0 and counts[1] > 1000 and n_stay + counts[1] == n
-    assert bool((cloud.cell[n_stay:n] == L.CELL_LOST).all())                # stale tail marked inert
-    cloud.ops.step(cloud, dt, D, 2, 3, 0)                                   # steps 2, 3, 4 on the OLD range
-    cloud.ops.unpack(cloud, n_stay, cloud.sendbuf, counts[1])               # arrivals = what was sent
-    cloud.ops.step_slice(cloud, n_stay, counts[1], dt, D, 2, 3, 0)          # they replay steps 2..4
+    ctx.step_dev(p(dx), p(dy), p(dz), p(dc), p(dg), None, n, dt, D, 0, 2, 0)                     # steps 0, 1
+    ctx.pack_leavers_dev(p(dx), p(dy), p(dz), p(dc), p(dg), n, p(cell_lo), 2, 0, p(sendbuf), n, p(counts), p(nstay))   # split after step 1
+    cnt = counts.cpu().tolist(); n_stay = int(nstay.item())
+    assert cnt[0] == 0 and cnt[1] > 1000 and n_stay + cnt[1] == n
+    assert bool((dc[n_stay:n] == L.CELL_LOST).all())                       # stale tail marked inert
+    ctx.step_dev(p(dx), p(dy), p(dz), p(dc), p(dg), None, n, dt, D, 2, 3, 0)                     # steps 2, 3, 4 on the OLD range
+    ctx.unpack_arrivals_dev(p(dx), p(dy), p(dz), p(dc), p(dg), n_stay, p(sendbuf), cnt[1])       # arrivals = what was sent
+    ctx.step_dev(p(dx) + 8 * n_stay, p(dy) + 8 * n_stay, p(dz) + 8 * n_stay, p(dc) + 4 * n_stay, p(dg) + 8 * n_stay, None, cnt[1],
+                 dt, D, 2, 3, L.STEP_FUSE_CYCLES)                                                # they replay steps 2..4
     torch.cuda.synchronize()
-    g, gx, gy, gz, gc = cloud.gather_to_numpy()
+    g, gx, gy, gz, gc = (a.cpu().numpy() for a in (dg, dx, dy, dz, dc))
     # the answer: the same kernel stepping the undisturbed cloud 5 cycles (device log/cos differ from libm in the
     # last bits, so the Brownian term is compared GPU to GPU; the D = 0 walk is pinned to the oracle elsewhere)
-    plain = ShardedCloud(HipOps(ctx), [0, mesh.n_cells], n, dev)
-    plain.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), torch.from_numpy(c).to(dev),
-                        torch.from_numpy(gid).to(dev))
-    plain.ops.step(plain, dt, D, 0, 5, 0)
+    qx, qy, qz, qc, qg = upload()
+    ctx.step_dev(p(qx), p(qy), p(qz), p(qc), p(qg), None, n, dt, D, 0, 5, 0)
     torch.cuda.synchronize()
-    _, px, py, pz_, pc = plain.gather_to_numpy()
+    px, py, pz_, pc = (a.cpu().numpy() for a in (qx, qy, qz, qc))
     o = g - 10
     assert np.array_equal(np.sort(o), np.arange(n))
     assert np.array_equal(gx, px[o]) and np.array_equal(gy, py[o]) and np.array_equal(gz, pz_[o])
@@ -632,49 +636,49 @@ def test_deferred_handoff_catch_up_is_bit_exact(setup, gpu_ctx_factory):
     assert moved > 1e-4                                                       # and the cloud did move
 
 
-@pytest.mark.parametrize("overlap", [0, 3])
-def test_sharded_cloud_one_rank_rccl_group(setup, gpu_ctx_factory, tmp_path, overlap):
-    """The N>1 host path (histogram -> all-reduce -> device re-cut -> pack -> all-gather of counts -> all-to-all-v
-    -> unpack) on ONE GPU with a real one-rank RCCL group: particle results must not depend on it."""
+@pytest.mark.parametrize("overlap", [0, 3, -1])
+def test_sharded_cloud_one_rank_rccl_group(setup, gpu_ctx_factory, overlap):
+    """The N>1 path behind the C-ABI (cpf_shard_*: histogram -> ncclAllReduce -> device re-cut -> split -> ncclAllGather of
+    the counts -> grouped ncclSend/ncclRecv all-to-all-v on the side stream -> unpack -> catch-up) on ONE GPU with a real
+    one-rank RCCL communicator made by the library (cpf_comm_create): particle results must not depend on it."""
+    from cudaparticlesfoam_amd import _lib as L
     import torch
-    import torch.distributed as dist
-    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+    from cudaparticlesfoam_amd.parallel import Communicator, ShardedCloud, unique_id
     pz, mesh, cw, t = setup["pz"], setup["mesh"], setup["cw"], setup["tables"]
     U = setup["pitz"]["U_analytic"]
     dev = torch.device("cuda", 0)
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1,
-                                device_id=dev)
-        created = True
+    comm = Communicator(unique_id(L.COMM_RCCL), 0, 1, 0)
     try:
         ctx = gpu_ctx_factory()
         ctx.set_mesh(mesh)
         ctx.set_velocity(U)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         n = 200_000
         xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=77)
         x, y, z = (xyz[:, k].copy() for k in range(3))
         c = cw.locate_initial(x, y, z, t)
-        cloud = ShardedCloud(HipOps(ctx), [0, mesh.n_cells], n + 64, dev, 0, 1, send_fraction=1.0, exchange_interval=0)
+        cloud = ShardedCloud(ctx, [0, mesh.n_cells], n + 64, comm, send_fraction=1.0, exchange_interval=0)
         cloud.force_collectives = True
         cloud.rebalance_interval = 3
         cloud.sort_interval = 4
         cloud.overlap_steps = overlap                   # side-stream counts + all-to-all while the loop runs on
         cloud.enable_time_balancing()
-        cloud.set_particles(*(torch.from_numpy(a).to(dev) for a in (x, y, z)), None,
-                            torch.arange(n, dtype=torch.int64, device=dev))
-        cloud.step(1e-4, 10)
+        tx, ty, tz = (torch.from_numpy(a).to(dev) for a in (x, y, z))
         torch.cuda.synchronize()
+        cloud.set_particles(tx, ty, tz, None, None)
+        cloud.step(1e-4, 10)
         assert cloud.rebalances == 3 and cloud.n == n and list(cloud.cell_lo) == [0, mesh.n_cells]
         g, gx, gy, gz, gc = cloud.gather_to_numpy()
         cw.step(x, y, z, c, 1e-4, 10, t, U)
         assert np.array_equal(np.sort(g), np.arange(n))
         assert np.array_equal(gx, x[g]) and np.array_equal(gy, y[g]) and np.array_equal(gz, z[g])
         assert np.array_equal(gc, c[g])
+        # the whole cloud in particle-id order through the collective gather (one rank: the same particles)
+        xyzw, cell, _ = cloud.gather(0)
+        assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z)
+        assert np.array_equal(cell, c)
+        cloud.close()
     finally:
-        if created:
-            dist.destroy_process_group()
+        comm.close()
 
 
 def test_full_size_properties(setup, gpu_ctx_factory):
@@ -1133,32 +1137,44 @@ def test_rank_direct_ingest_equals_whole_mesh_ingest(setup, gpu_ctx_factory, n_p
 
 def test_empty_shard_entry_points(setup, gpu_ctx_factory):
     """A rank whose cell range holds no particle calls every *_dev entry point with n = 0: nothing may be launched
-    with an empty grid, nothing written, no error."""
+    with an empty grid, nothing written, no error -- and the shard layer on top of them steps, sorts, re-cuts and
+    exchanges an empty shard."""
     import torch
     from cudaparticlesfoam_amd import _lib as L
-    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud
+    from cudaparticlesfoam_amd.parallel import ShardedCloud
     mesh = setup["mesh"]
     dev = torch.device("cuda", 0)
     ctx = gpu_ctx_factory(); ctx.set_mesh(mesh); ctx.set_velocity(setup["pitz"]["U_uniform"])
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    cloud = ShardedCloud(HipOps(ctx), [0, 100, mesh.n_cells], 1024, dev, rank=0, world=2, send_fraction=1.0)
-    sentinel = 123.5
-    cloud.x.fill_(sentinel); cloud.cell.fill_(7)
-    cloud.ops.step(cloud, 1e-4, 0.0, 0, 3, 0)
-    cloud.ops.step(cloud, 1e-4, 1e-6, 3, 2, L.STEP_FUSE_CYCLES)
-    cloud.ops.sort(cloud)
-    cloud.ops.locate(cloud)
-    cloud.ops.pack(cloud)
-    cloud.weights_dev = torch.ones(mesh.n_cells, dtype=torch.float64, device=dev)
-    cloud.ops.histogram(cloud, 1.0)
-    cloud.ops.cell_ranges(cloud)
-    cloud.ops.unpack(cloud, 0, cloud.recvbuf, 0)
-    cloud.ops.step_slice(cloud, 0, 0, 1e-4, 0.0, 0, 4, 0)
+    cap, sentinel = 1024, 123.5
+    x = torch.full((cap,), sentinel, dtype=torch.float64, device=dev); y = x.clone(); z = x.clone()
+    cell = torch.full((cap,), 7, dtype=torch.int32, device=dev); gid = torch.zeros(cap, dtype=torch.int64, device=dev)
+    alt = [torch.empty_like(a) for a in (x, y, z, cell, gid)]
+    cell_lo = torch.tensor([0, 100, mesh.n_cells], dtype=torch.int32, device=dev)
+    sendbuf = torch.empty(cap * L.HANDOFF_DOUBLES, dtype=torch.float64, device=dev)
+    counts = torch.full((2,), 5, dtype=torch.int64, device=dev); nstay = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    weights = torch.ones(mesh.n_cells, dtype=torch.float64, device=dev)
+    p = lambda a: a.data_ptr()     # noqa: E731
+    ctx.step_dev(p(x), p(y), p(z), p(cell), p(gid), None, 0, 1e-4, 0.0, 0, 3, 0)
+    ctx.step_dev(p(x), p(y), p(z), p(cell), p(gid), None, 0, 1e-4, 1e-6, 3, 2, L.STEP_FUSE_CYCLES)
+    ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(cell), p(gid), *[p(a) for a in alt], 0)
+    ctx.locate_initial_dev(p(x), p(y), p(z), p(cell), 0)
+    ctx.pack_leavers_dev(p(x), p(y), p(z), p(cell), p(gid), 0, p(cell_lo), 2, 0, p(sendbuf), cap, p(counts), p(nstay))
+    ctx.cell_histogram_dev(p(cell), 0, 1.0, p(weights))
+    ctx.cell_ranges_dev(p(weights), 2, p(cell_lo))
+    ctx.unpack_arrivals_dev(p(x), p(y), p(z), p(cell), p(gid), 0, p(sendbuf), 0)
     torch.cuda.synchronize()
-    assert int(cloud.nstay_dev.item()) == 0 and cloud.counts_dev[:2].tolist() == [0, 0]
-    assert float(cloud.weights_dev.abs().sum().item()) == 0.0
-    assert cloud.cell_lo_dev.tolist() == [0, 0, mesh.n_cells]            # no weight anywhere: all cuts at 0
-    assert bool((cloud.x == sentinel).all()) and bool((cloud.cell == 7).all())
+    assert int(nstay.item()) == 0 and counts.tolist() == [0, 0]
+    assert float(weights.abs().sum().item()) == 0.0
+    assert cell_lo.tolist() == [0, 0, mesh.n_cells]                       # no weight anywhere: all cuts at 0
+    assert bool((x == sentinel).all()) and bool((cell == 7).all())
+    cloud = ShardedCloud(ctx, None, cap, None, send_fraction=1.0, exchange_interval=2)
+    cloud.force_collectives = True
+    cloud.rebalance_interval = 3; cloud.sort_interval = 2; cloud.overlap_steps = 1
+    cloud.step(1e-4, 7)
+    cloud.flush()
+    assert cloud.n == 0 and cloud.global_count() == 0 and cloud.exchanges >= 3
+    cloud.close()
 
 
 def test_merge_failure_is_reported_through_the_context(setup, gpu_ctx_factory):

@@ -1,78 +1,29 @@
-"""GPU: the sharded cloud with TWO ranks on ONE MI355X.
+"""GPU: the sharded cloud with SEVERAL ranks on ONE MI355X, entirely through the C-ABI.
 
-The development loop has a single GPU per box and RCCL refuses two ranks on one device, so the N > 1 host path
-would otherwise meet real leavers for the first time in the driver's scaling run.  Here both ranks run as
-threads of this process, each with its own context, streams and ShardedCloud; only the three collectives are
-replaced by an in-process stand-in (ThreadComm, below).  Everything else is the product: the HIP split /
-histogram / cut / unpack kernels with real leavers, the overlapped hand-off with its catch-up launch, growth of
-a shard, balancing by measured step time.  The answer is the single-process CPU statement, particle by particle.
+The development loop has a single GPU per box and RCCL refuses two ranks on one device, so the N > 1 path would
+otherwise meet real leavers for the first time in the driver's scaling run.  Here the ranks run as threads of this
+process, each with its own context, streams and shard (cpf_shard_*); the collectives are the library's IN-PROCESS
+communicator (cpf_comm_create with a CPF_COMM_INPROCESS token: device-to-device copies and a barrier,
+csrc/cpf_comm.cpp).  Everything else is what an 8-GPU run executes: the HIP split / histogram / cut / unpack kernels with
+real leavers, the overlapped hand-off with its catch-up launch, growth of a shard, balancing by measured step time, all
+strung together by csrc/cpf_shard_core.h.  The answer is the single-process CPU statement, particle by particle.
 """
+import os
 import threading
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-
-class ThreadComm:
-    """all_gather / all_reduce / all_to_all_single between threads of one process (test double for the
-    torch.distributed calls of cudaparticlesfoam_amd/parallel.py; device tensors, lock-step like a collective)."""
-
-    def __init__(self, world):
-        self.world = world
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-        self.tls = threading.local()
-
-    def bind(self, rank):
-        self.tls.rank = rank
-
-    def _sync(self):
-        import torch
-        torch.cuda.current_stream().synchronize()
-
-    def all_gather(self, rows, t, group=None):
-        r = self.tls.rank
-        self._sync()
-        self.slots[r] = t.clone()
-        self._sync(); self.barrier.wait()
-        for k in range(self.world):
-            rows[k].copy_(self.slots[k])
-        self._sync(); self.barrier.wait()
-
-    def all_reduce(self, t, group=None):
-        r = self.tls.rank
-        self._sync()
-        self.slots[r] = t.clone()
-        self._sync(); self.barrier.wait()
-        total = self.slots[0].clone()
-        for k in range(1, self.world):
-            total += self.slots[k]
-        self._sync(); self.barrier.wait()
-        t.copy_(total)
-        self._sync(); self.barrier.wait()
-
-    def all_to_all_single(self, out, inp, out_splits, in_splits, group=None):
-        r = self.tls.rank
-        self._sync()
-        self.slots[r] = (inp.clone(), list(in_splits))
-        self._sync(); self.barrier.wait()
-        off_out = 0
-        for k in range(self.world):
-            src, splits = self.slots[k]
-            a = sum(splits[:r]); n = splits[r]
-            assert n == out_splits[k]
-            out[off_out:off_out + n].copy_(src[a:a + n])
-            off_out += n
-        self._sync(); self.barrier.wait()
+os.environ.setdefault("CPF_COMM_TIMEOUT", "180")      # a rank that died must not leave the others waiting at the barrier for long
 
 
 def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, overlap, balance_by_time, capacity,
-                   dt=1e-4, world=2):
+                   dt=1e-4, world=2, send_fraction=1.0):
     import torch
+    from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
-    from cudaparticlesfoam_amd.parallel import HipOps, ShardedCloud, slab_cell_ranges, x_slab_renumbering
+    from cudaparticlesfoam_amd.parallel import Communicator, ShardedCloud, slab_cell_ranges, unique_id, x_slab_renumbering
     pz = pitz["pz"]
     c0, _ = pitz["mesh"].cell_centres_volumes()
     mesh = pitz["mesh"].renumber_cells(x_slab_renumbering(c0))
@@ -82,46 +33,45 @@ def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, ov
     xyz = pz.uniform_points(321, n_total, *pz.DOMAIN_BOX)
     x, y, z = (xyz[:, k].copy() for k in range(3))
     cell = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
-    comm = ThreadComm(world)
+    token = unique_id(L.COMM_INPROCESS)
     cell_lo = slab_cell_ranges(vols, world)
     dev = torch.device("cuda", 0)
     out, errors = [None] * world, []
 
     def rank_main(rank):
         try:
-            comm.bind(rank)
-            stream = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(stream):
-                ctx = Context(0)
-                ctx.set_stream(stream.cuda_stream)
-                ctx.set_mesh(mesh); ctx.set_velocity(U)
-                mine = np.arange(rank, n_total, world)            # an arbitrary half: the first hand-off sorts it out
-                cloud = ShardedCloud(HipOps(ctx), cell_lo, capacity, dev, rank, world, send_fraction=1.0,
-                                     exchange_interval=exchange, comm=comm)
-                cloud.rebalance_interval = rebalance
-                cloud.overlap_steps = overlap
-                cloud.sort_interval = 5
-                if balance_by_time:
-                    cloud.enable_time_balancing()
-                cloud.set_particles(*(torch.from_numpy(a[mine].copy()).to(dev) for a in (x, y, z)), None,
-                                    torch.from_numpy(mine.astype(np.int64)).to(dev))
-                cloud.exchange()
-                cloud.step(dt, steps)
-                cloud.flush()
-                g, gx, gy, gz, gc = cloud.gather_to_numpy()
-                out[rank] = dict(g=g, x=gx, y=gy, z=gz, c=gc, handed=cloud.handed_off, grown=cloud.grown,
-                                 rebalances=cloud.rebalances, cell_lo=cloud.cell_lo.copy(), n=cloud.n)
-                torch.cuda.current_stream().synchronize()
-                ctx.close()
+            ctx = Context(0)                                      # its own stream
+            ctx.set_mesh(mesh); ctx.set_velocity(U)
+            comm = Communicator(token, rank, world, 0)
+            mine = np.arange(rank, n_total, world)                # an arbitrary share: the first hand-off sorts it out
+            cloud = ShardedCloud(ctx, cell_lo, capacity, comm, send_fraction=send_fraction, exchange_interval=exchange)
+            cloud.rebalance_interval = rebalance
+            cloud.overlap_steps = overlap
+            cloud.sort_interval = 5
+            if balance_by_time:
+                cloud.enable_time_balancing()
+            tx, ty, tz = (torch.from_numpy(a[mine].copy()).to(dev) for a in (x, y, z))
+            tg = torch.from_numpy(mine.astype(np.int64)).to(dev)
+            torch.cuda.synchronize()
+            cloud.set_particles(tx, ty, tz, None, tg)
+            cloud.exchange()
+            cloud.step(dt, steps)
+            cloud.flush()
+            g, gx, gy, gz, gc = cloud.gather_to_numpy()
+            total = cloud.global_count()
+            whole = cloud.gather(0)                               # collective: the cloud in particle-id order on rank 0
+            out[rank] = dict(g=g, x=gx, y=gy, z=gz, c=gc, handed=cloud.handed_off, grown=cloud.grown, send_grown=cloud.send_grown,
+                             rebalances=cloud.rebalances, cell_lo=cloud.cell_lo.copy(), n=cloud.n, total=total, whole=whole)
+            cloud.close(); comm.close(); ctx.close()
         except BaseException as e:                                  # noqa: BLE001 -- reported by the main thread
-            errors.append((rank, repr(e)))
-            comm.barrier.abort()
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
 
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for th in threads:
         th.start()
     for th in threads:
-        th.join(timeout=600)
+        th.join(timeout=900)
     assert not errors, errors
     assert all(o is not None for o in out)
     cw.step(x, y, z, cell, dt, steps, t, U, nthreads=cw.max_threads)
@@ -132,7 +82,11 @@ def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, ov
         seen[g] = True
         assert np.array_equal(o["c"], cell[g])
         assert np.array_equal(o["x"], x[g]) and np.array_equal(o["y"], y[g]) and np.array_equal(o["z"], z[g])
+        assert o["total"] == n_total
     assert seen.all()
+    xyzw, wc, _ = out[0]["whole"]
+    assert np.array_equal(xyzw[:, 0], x) and np.array_equal(xyzw[:, 1], y) and np.array_equal(xyzw[:, 2], z) and np.array_equal(wc, cell)
+    assert all(o["whole"][0] is None for o in out[1:])
     return out, cell
 
 
@@ -166,9 +120,9 @@ def test_two_ranks_fixed_ranges_growing_shard(pitz, oracle_libs):
 
 
 def test_two_ranks_overlap_depth_derived_per_rank(pitz, oracle_libs):
-    """`overlap_steps = -1` (bench.py's default since round 4): every rank derives how many steps it queues between a split and
-    its exchange from its own measured host work per hand-off and its own step time (parallel.py, _overlap) -- the ranks may
-    choose differently, and every particle still equals the one-process run bit for bit."""
+    """`overlap_steps = -1` (bench.py's default since round 4): every rank derives how many steps it would queue between a split
+    and its exchange from its own measured host work per hand-off and its own step time; the ranks agree on the maximum through
+    the counts table (csrc/cpf_shard_core.h, depthNext), and every particle still equals the one-process run bit for bit."""
     out, cell = _run_two_ranks(pitz, oracle_libs, n_total=400_000, steps=32, rebalance=8, exchange=0, overlap=-1,
                                balance_by_time=True, capacity=400_000 + 64)
     assert all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
@@ -187,3 +141,12 @@ def test_four_ranks_as_threads_on_one_gpu(pitz, oracle_libs):
     assert all(np.array_equal(o["cell_lo"], lo) for o in out)
     for r, o in enumerate(out):
         assert ((o["c"] >= lo[r]) & (o["c"] < lo[r + 1]) | (o["c"] < 0)).all()
+
+
+def test_two_ranks_send_buffer_overflow_with_derived_depth(pitz, oracle_libs):
+    """A send buffer of 1 % of the shard with `overlap_steps = -1`: the first hand-offs overflow, the split aborts on the device,
+    every rank reads that in the all-gathered table, the overflowing ranks enlarge their buffers and split again at the current
+    step -- the same step on every rank, because the depth is agreed -- and no particle is lost, duplicated or left behind."""
+    out, cell = _run_two_ranks(pitz, oracle_libs, n_total=300_000, steps=20, rebalance=0, exchange=2, overlap=-1,
+                               balance_by_time=False, capacity=300_000 + 64, send_fraction=0.01)
+    assert sum(o["send_grown"] for o in out) >= 2 and sum(o["n"] for o in out) == 300_000

@@ -5,6 +5,8 @@ import socket
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -114,7 +116,7 @@ def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_lib
 
 @pytest.mark.parametrize("world,interval,rebalance,overlap", [(2, 1, 0, 0), (2, 4, 0, 0), (3, 1, 0, 0), (2, 4, 10, 0),
                                                              (3, 0, 5, 0), (2, 0, 5, 3), (3, 4, 0, 4), (2, 0, 6, 10),
-                                                             (2, 0, 6, -1),      # overlap depth derived per rank (parallel.py, _overlap)
+                                                             (2, 0, 6, -1),      # overlap depth derived from measured host time, agreed between the ranks (cpf_shard_core.h)
                                                              (8, 0, 15, 4)])     # eight ranks, overlapped hand-offs like the bench (the run is 30 steps: 15 divides it)
 def test_sharded_equals_single_process(world, interval, rebalance, overlap, tmp_path, oracle_libs):
     """overlap > 0: the step loop keeps running for that many cycles after the split while counts and payload
@@ -146,14 +148,18 @@ def test_sharded_equals_single_process(world, interval, rebalance, overlap, tmp_
         assert all(np.array_equal(d["cell_lo"], want) for d in ds)
         assert [int(d["n_local"]) for d in ds] == [int(((c >= want[r]) & (c < want[r + 1])).sum()) for r in range(world)]
 
-def test_device_cell_ranges_match_host_rule():
-    """The on-device re-cut (cumsum + searchsorted in torch) applies the same rule as slab_cell_ranges."""
-    import torch
-    from cudaparticlesfoam_amd.parallel import device_cell_ranges, slab_cell_ranges
-    rng = np.random.default_rng(0)
-    for _ in range(300):
-        n = int(rng.integers(1, 400)); w = int(rng.integers(1, 9))
-        h = rng.integers(0, 6, size=n) * (rng.random(n) < rng.random())
-        a = slab_cell_ranges(h.astype(np.float64), w)
-        b = device_cell_ranges(torch.from_numpy(h.astype(np.int64)), w).numpy()
-        assert b.dtype == np.int32 and np.array_equal(a, b)
+def test_overflow_with_derived_overlap_depth(tmp_path, oracle_libs):
+    """`overlap_steps = -1` AND a send buffer that overflows (round-4 advisory): the depth every rank derives from its own
+    measured host time is agreed between the ranks through the counts table, so every rank completes a hand-off at the same
+    step and an overflowing rank's repeated split "at the current step" is current on every receiver -- same particles as one
+    process."""
+    out = str(tmp_path / "ovfauto")
+    _run_workers(2, out, 2, 0, 0, -1, 0, 0, 0.01)            # fixed ranges, hand-off every 2 steps, derived depth, tiny send buffer
+    x, y, z, c = _single_process_answer(oracle_libs)
+    ds = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    assert sum(int(d["send_grown"]) for d in ds) >= 2 and sum(int(d["n_local"]) for d in ds) == 6000
+    for d in ds:
+        g = d["gid"]
+        assert int(d["total0"]) == 6000 and int(d["total1"]) == 6000
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g])
