@@ -1,7 +1,7 @@
 // Test harness: a stand-in for applications/cudaParticlesUncoupledFoam/cudaParticlesUncoupledFoam.C
 // (reference :40-89) built against the MOCK OpenFOAM types: same include order, same
 // `namespace advect { extern "C" int main` shape, same two fragment includes -- but the fragments
-// are this repo's replacements.  Usage: mockUncoupledFoam <caseDir>; writes particle_*.vtu and
+// are this repo's replacements.  Usage: mockUncoupledFoam <caseDir> [<eulerianSteps>]; writes particle_*.vtu and
 // particles_out.f64 / cells_out.i32 into the current directory.
 #include "cuda/common.h"
 #include "cuda/DeviceTetMesh.cuh"
@@ -29,7 +29,17 @@ extern "C" int main(int argc, char* argv[])
 
         #include "initCuda.H"
 
-        #include "advect.H"
+        const int eulerianSteps = argc > 2 ? std::atoi(argv[2]) : 1;
+        for (int cpfE = 0; cpfE < eulerianSteps; ++cpfE)
+        {
+            if (cpfE > 0)
+            {
+                // a transient solver's next step: time moves on and the field changes (as in mockParallelFoam)
+                runTime.t += runTime.dT;
+                for (auto& v : U.f.d) v = vector(0.9*v.x(), 0.9*v.y() + 0.01, 0.9*v.z());
+            }
+            #include "advect.H"
+        }
 
         // harness output: final state in particle-id order
         std::vector<double> xyzw((size_t)numParticles * 4);

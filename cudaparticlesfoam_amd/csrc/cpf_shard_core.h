@@ -322,9 +322,14 @@ class ShardCore {
             if (dr) { CPF_SH(finishExchange()); CPF_SH(recut(balanceByTime)); CPF_SH(beginExchange()); }
             else if (de) { CPF_SH(finishExchange()); CPF_SH(beginExchange()); }
         }
+        // a cycle of zero length without a kick moves nothing: the frame-0 idiom (velocities of one advect in the first output
+        // file, out-of-domain particles frozen; src/initCuda.H:184-201) and not a step of the run -- like cpf_step, the
+        // counter-based Brownian stream and the cadences do not see it
+        const bool frameZero = dt == 0.0 && D == 0.0;
         for (int c = 0; c < nCycles; ++c) {
             if (pending.on && (int64_t)stepIndex - (int64_t)pending.step >= overlapDepth()) CPF_SH(finishExchange());
             CPF_SH(dev.step(x, y, z, cell, gid, storeVel ? vel : nullptr, n, dt, D, stepIndex, 1, flags));
+            if (frameZero) continue;
             ++stepIndex;
             particleSteps += n;
             const bool hold = storeVel && c == nCycles - 1;           // velocities must stay aligned with the particles

@@ -97,10 +97,11 @@ def test_frame_zero_carries_velocities_and_inactive_particles(tmp_path, pitz):
 
 @pytest.mark.parametrize("n_procs", [2, 4])
 def test_parallel_fragments_equal_the_serial_run(tmp_path, pitz, n_procs):
-    """The Pstream branch of the fragments (src/initCuda.H:207-484, src/advect.H:59-84): every "rank" hands its piece
-    of the decomposed mesh and its U slice to the master through gatherList, the master stitches them
-    (cpf_set_mesh_parts) and drives the GPU alone.  One process plays the ranks (mock Pstream); particles and output
-    frames must equal the serial run's bit for bit."""
+    """The Pstream branch of the fragments (replacing src/initCuda.H:207-484, src/advect.H:59-84) is RANK PER GPU: every
+    rank gets every piece of the decomposed mesh (gatherList + scatterList), stitches them (cpf_set_mesh_parts), creates its
+    own context and shard, joins one communicator (token over Pstream::scatter) and owns a cell range; particles change hands
+    between the ranks' shards, frames are gathered to the master.  One process plays the ranks as threads on the one GPU (mock
+    Pstream, in-process communicator); particles and output frames must equal the serial run's byte for byte."""
     from case_dump import dump_case
     from cudaparticlesfoam_amd.cases import split_into_parts
     mesh, U = pitz["mesh"], pitz["U_analytic"]
@@ -116,9 +117,40 @@ def test_parallel_fragments_equal_the_serial_run(tmp_path, pitz, n_procs):
     par = tmp_path / "parallel"; par.mkdir()
     xp, cp, outp = _run("mockParallelFoam", case, str(par), extra=[str(n_procs)])
     assert np.array_equal(xp, xs) and np.array_equal(cp, cs)
-    assert "nCycles: 35" in outp
+    assert "nCycles: 35" in outp and ("%d GPUs" % n_procs) in outp
+    assert outs.split("Out-of-domain particles(-tetID) = ")[1].split()[0] == outp.split("Out-of-domain particles(-tetID) = ")[1].split()[0]
+    handed = int(outp.split(" re-cuts, ")[1].split()[0])
+    assert handed > 0                                                     # particles did change hands between the ranks
     frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
     assert frames == ["particle_%04d.vtu" % k for k in (0, 1, 11, 21, 31)]
+    for f in frames:
+        assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
+
+
+@pytest.mark.parametrize("n_procs", [2, 4])
+def test_parallel_fragments_transient_field_with_diffusion(tmp_path, pitz, n_procs):
+    """Three Eulerian steps of a transient solver with the tutorial's diffusion coefficient: every rank uploads its own U
+    slice each step (cpf_shard_set_velocity_slice: all-gathered between the shards), the counter-based Brownian stream is
+    keyed by (seed, particle id, cycle) so a particle draws the same kicks on whichever rank holds it, and frame 0 does not
+    count as a cycle -- particles and frames equal the serial run's byte for byte."""
+    from case_dump import dump_case
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    mesh, U = pitz["mesh"], pitz["U_analytic"]
+    d = dict(DICT, diffusionCoeff=1.5e-5, saveInterval=7)
+    case = str(tmp_path / "case")
+    dump_case(case, mesh, U, d, 1.0, 20e-4)
+    ser = tmp_path / "serial"; ser.mkdir()
+    xs, cs, outs = _run("mockUncoupledFoam", case, str(ser), extra=["3"])
+    first = 0
+    for r, part in enumerate(split_into_parts(mesh, n_procs)):
+        dump_case(os.path.join(case, "processor%d" % r), part, U[first:first + part.n_cells], d, 1.0, 20e-4)
+        first += part.n_cells
+    par = tmp_path / "parallel"; par.mkdir()
+    xp, cp, outp = _run("mockParallelFoam", case, str(par), extra=[str(n_procs), "3"])
+    assert np.array_equal(xp, xs) and np.array_equal(cp, cs)
+    assert outp.count("nCycles: 20") == 3
+    frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
+    assert frames == sorted(os.path.basename(p) for p in glob.glob(str(ser / "particle_*.vtu"))) and len(frames) >= 9
     for f in frames:
         assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
 
@@ -146,9 +178,9 @@ def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
 
 def test_tjunction_allrun_parallel_equals_serial(tmp_path):
     """The reference's own parallel tutorial run (TJunction/Allrun-parallel:9-12: decomposePar simple (4 1 1), then
-    `mpirun -np 4 cudaParticlesPimpleFoam -parallel`) through the replacement fragments' Pstream branch: the mesh cut
-    into four x slabs of equal cell count, each "rank" handing over its piece and its U slice, the master stitching
-    and driving the GPU.  Particles and frames equal the serial run's bit for bit."""
+    `mpirun -np 4 cudaParticlesPimpleFoam -parallel`) through the replacement fragments' rank-per-GPU branch: the mesh cut
+    into four x slabs of equal cell count, four ranks (threads here) each stitching the pieces, owning a cell range of the
+    cloud and handing particles over -- with the tutorial's diffusion.  Particles and frames equal the serial run's byte for byte."""
     from case_dump import dump_case
     from cudaparticlesfoam_amd.cases import split_into_parts
     from cudaparticlesfoam_amd.cases import tjunction as tj
