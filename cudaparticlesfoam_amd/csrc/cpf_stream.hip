@@ -82,6 +82,13 @@ struct StreamKernArgs {
 };
 static_assert(offsetof(StreamKernArgs, x) == 0 && offsetof(StreamKernArgs, cell) == 24, "kernarg_cloud_ptrs reads bytes 0..31");
 constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(StreamArgs, hitSpill));
+// the Brownian kick's own arguments are read from the kernarg segment where they are needed -- the particle ids once per tile,
+// step0 / seed / sigma once per cycle -- instead of holding seven scalar registers for the whole kernel (CPF_STREAM_BROWN_KERNARG)
+constexpr int kKernArgGid = (int)offsetof(StreamKernArgs, gid), kKernArgSigma = (int)offsetof(StreamKernArgs, sigma);
+constexpr int kKernArgStep0 = (int)offsetof(StreamKernArgs, step0), kKernArgSeed = (int)offsetof(StreamKernArgs, seed);
+#ifndef CPF_STREAM_BROWN_KERNARG
+#define CPF_STREAM_BROWN_KERNARG 1
+#endif
 
 // the zero-denominator skip of a face (cpf_walk.h) in the fixed-lookup instantiation: few particles per cell = a 3-D mesh, where no
 // face is parallel to everybody's displacement (the z pair of a layered mesh is dropped by its own test either way)
@@ -118,12 +125,21 @@ constexpr int kKernArgHitSpill = (int)(offsetof(StreamKernArgs, sa) + offsetof(S
 #ifndef CPF_STREAM_WAVES_L2
 #define CPF_STREAM_WAVES_L2 6
 #endif
+// the Brownian loop-lookup instantiation (pitzDaily with the tutorials' diffusion coefficient): 7 waves per SIMD since round 5 --
+// 70 VGPRs once the kick's own arguments are read from the kernarg segment (no scalar spills into vector lanes), and a hit
+// pool of 18 instead of 40 entries keeps the wave's LDS at 5816 of 5851 bytes.  Measured with Philox-7, one box: 0.1865 -> 0.181 ms
+#ifndef CPF_STREAM_WAVES_B0
+#define CPF_STREAM_WAVES_B0 7
+#endif
+#ifndef CPF_STREAM_HIT_POOL_B0
+#define CPF_STREAM_HIT_POOL_B0 18
+#endif
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : 6))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : CPF_STREAM_WAVES_B0))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
 };
 
 template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     constexpr bool HIT_IN_REGS = !BROWNIAN && (LOOKUP != 2 || CPF_STREAM_HIT_REGS_L2);
     constexpr bool kInRound = CPF_STREAM_INROUND == 2 || (CPF_STREAM_INROUND == 1 && BROWNIAN);
     static_assert(!(kInRound && (LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11)), "in-round reflection knows neither face groups nor two-record cells");
-    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11) ? 16 : CPF_STREAM_HIT_POOL);
+    constexpr int kPool = HIT_IN_REGS ? 1 : ((LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11) ? 16 : ((BROWNIAN && LOOKUP == 0) ? CPF_STREAM_HIT_POOL_B0 : CPF_STREAM_HIT_POOL));
     __shared__ double sLane[3][64];
     __shared__ double sPool[3][kPool];
     __shared__ unsigned sPoolUsed;
@@ -262,9 +278,12 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                           : reinterpret_cast<const char*>(cell + b) + (ul - 32u) * 16u;
                 glds16(s2, preBase + 1024u);                                   // z -> [1024, 1536), cell -> [1536, 1792)
             }
-            if (BROWNIAN && gid != nullptr) {
-                if (ul < 32u) glds16(reinterpret_cast<const char*>(gid + b) + ul * 16u, preBase + 1792u);
-                return 3;
+            if (BROWNIAN) {
+                const int64_t* const g = CPF_STREAM_BROWN_KERNARG ? static_cast<const int64_t*>(kernarg_pointer<kKernArgGid>()) : gid;
+                if (g != nullptr) {
+                    if (ul < 32u) glds16(reinterpret_cast<const char*>(g + b) + ul * 16u, preBase + 1792u);
+                    return 3;
+                }
             }
             return 2;
         }
@@ -274,7 +293,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
         const int vc = (cell + b)[l];
         sPre[ul] = vx; sPre[64 + ul] = vy; sPre[128 + ul] = vz;
         reinterpret_cast<int*>(sPre + 192)[ul] = vc;
-        if (BROWNIAN && gid != nullptr) reinterpret_cast<int64_t*>(sPre + 224)[ul] = (gid + b)[l];
+        if (BROWNIAN) {
+            const int64_t* const g = CPF_STREAM_BROWN_KERNARG ? static_cast<const int64_t*>(kernarg_pointer<kKernArgGid>()) : gid;
+            if (g != nullptr) reinterpret_cast<int64_t*>(sPre + 224)[ul] = (g + b)[l];
+        }
         return 0;
     };
 
@@ -308,7 +330,10 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
             double px = sPre[ul], py = sPre[64 + ul], pz = sPre[128 + ul];
             int pc = reinterpret_cast<const int*>(sPre + 192)[ul];
             uint64_t pid = 0;
-            if (BROWNIAN) pid = gid ? (uint64_t) reinterpret_cast<const int64_t*>(sPre + 224)[ul] : (uint64_t)tile * 64 + ul;
+            if (BROWNIAN) {
+                const bool haveIds = (CPF_STREAM_BROWN_KERNARG ? kernarg_pointer<kKernArgGid>() : (void*)gid) != nullptr;
+                pid = haveIds ? (uint64_t) reinterpret_cast<const int64_t*>(sPre + 224)[ul] : (uint64_t)tile * 64 + ul;
+            }
             // no particle in this lane (beyond the cloud's end, frozen, or lost in an earlier step: w = 0 from now on,
             // cuda/particles.cu:333-338): CPF_CELL_FROZEN, and the lane stores back what it loaded.  Which lanes carry a
             // particle is read off `cur` wherever it is needed (cur >= 0) instead of being kept in wave masks: scalar
@@ -514,7 +539,9 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     // Philox + Box-Muller for the cycle, HERE: behind the hook (the parked result it stores has left the
                     // E slot) and behind the record requests (the deviates overlap their round trip), with almost nothing
                     // of the walk live.  They wait in the lane's E slot -- not needed before the advect, which consumes them.
-                    const D3 xi = normal3(id, step0 + (uint32_t)c, seed);
+                    uint32_t kStep0 = step0, kSeed = seed;
+                    if (CPF_STREAM_BROWN_KERNARG) kernarg_u32_pair<kKernArgStep0, kKernArgSeed>(kStep0, kSeed);
+                    const D3 xi = normal3(id, kStep0 + (uint32_t)c, kSeed);
                     sE[0][lane] = xi.x; sE[1][lane] = xi.y; sE[2][lane] = xi.z;
                 }
 #ifdef CPF_STREAM_TIMELINE
@@ -548,7 +575,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                     D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};           // not yet walked in this cycle: S_ is the position
                     if (BROWNIAN) {                                               // the deviates drawn in the cycle's first round
                         const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
-                        disp = axpy(sigma, xi, disp);
+                        disp = axpy(CPF_STREAM_BROWN_KERNARG ? kernarg_f64<kKernArgSigma>() : sigma, xi, disp);
                     }
                     D3 E = {S_.x + disp.x, S_.y + disp.y, S_.z + disp.z};
                     if (BROWNIAN && REFLECT && zFold) {                           // one cell thick in z: cpf_walk.h, fold_z

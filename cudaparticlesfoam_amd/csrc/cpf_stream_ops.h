@@ -74,6 +74,19 @@ __device__ __forceinline__ void* kernarg_pointer() {                  // one 8-b
     asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(BYTE_OFFSET) : "memory");
     return reinterpret_cast<void*>((uintptr_t)(((unsigned long long)r[1] << 32) | r[0]));
 }
+// two 4-byte arguments / one double at fixed offsets (the Brownian kick's step0 + seed and sigma: needed once per cycle)
+template <int OFF_A, int OFF_B>
+__device__ __forceinline__ void kernarg_u32_pair(uint32_t& a, uint32_t& b) {
+    asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF_A), "n"(OFF_B) : "memory");
+}
+template <int BYTE_OFFSET>
+__device__ __forceinline__ double kernarg_f64() {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(BYTE_OFFSET) : "memory");
+    return __longlong_as_double((long long)(((unsigned long long)r[1] << 32) | r[0]));
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 

@@ -579,9 +579,18 @@ struct GlobalTracer {
 
 // Philox4x32-10 (Salmon et al. SC'11) keyed by (seed, "CPF1"), counter (gid, step): replaces the
 // 48-byte-per-particle cuRAND XORWOW state of cuda/particles.cu:524-575 with nothing at all.
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+// Philox4x32-R (Salmon et al., SC'11).  R = 7: the variant with the fewest rounds that the paper reports as passing the
+// whole of BigCrush ("Crush-resistant"; R = 10 is Random123's default, with a safety margin).  Each round is two
+// quarter-rate 32 x 32 -> 64 multiplies (v_mad_u64_u32) and four XORs per lane and the streaming kernel is bound by its
+// vector ALU: measured on one box (pitzDaily, D = 1.5e-5, 1e7 particles) 10 -> 7 rounds = 0.1865 -> 0.1825 ms per launch;
+// the deviates as a whole (this + Box-Muller below) are 0.052 of the 0.188 ms (A/B build that returns constants instead).
+// oracle/cellwalk.c states the same function; its known-answer test runs at R = 10, where Random123 publishes vectors.
+#ifndef CPF_PHILOX_ROUNDS
+#define CPF_PHILOX_ROUNDS 7
+#endif
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < CPF_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
@@ -589,7 +598,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-// Three N(0,1) deviates for (particle gid, step) from ONE Philox block (parity with the reference's cuRAND stream is
+// Three N(0,1) deviates for (particle gid, step) from ONE Philox4x32-7 block (parity with the reference's cuRAND stream is
 // statistical by contract, SURVEY.md 8c, so the arithmetic is free): Box-Muller evaluated with the fp32 hardware
 // transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32, whose argument is in revolutions: no 2*pi, no range
 // reduction) -- words 0,1 give two deviates (one log, one sqrt), words 2,3 the third.  The radius uniform uses ALL 32
@@ -604,8 +613,11 @@ __device__ __forceinline__ float log2_radius_uniform(uint32_t w) {
     return __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(x)) + (float)(__builtin_amdgcn_frexp_expf(x) - 32);
 }
 __device__ __forceinline__ D3 normal3(uint64_t gid, uint32_t step, uint32_t seed) {
+#ifdef CPF_AB_NO_RNG       // A/B builds only (tools/build_ab.sh): what the kick costs besides its deviates
+    return {0.3 + (double)(gid & 1), -0.2, 0.1 * (double)(step & 1)};
+#endif
     uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0u};
-    philox4x32_10(c, seed, 0x43504631u);
+    philox4x32(c, seed, 0x43504631u);
     const float s = 1.0f / 8388608.0f;                                    // 2^-23
     const float u1 = ((float)(c[1] >> 9) + 0.5f) * s, u3 = ((float)(c[3] >> 9) + 0.5f) * s;
     const float k = -1.3862943611198906f;                                 // -2 ln 2: -2 ln u = k * log2 u

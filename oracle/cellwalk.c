@@ -253,7 +253,7 @@ static int trace_in_cell(v3* Ps, v3 Pe, int cur, const cw_tables* t, int token, 
 }
 
 /* ------------------------------------------------------------------------------------------
- * Philox4x32-10 (Salmon et al., SC'11 "Parallel random numbers: as easy as 1, 2, 3"; constants
+ * Philox4x32-R (Salmon et al., SC'11 "Parallel random numbers: as easy as 1, 2, 3"; constants
  * and known-answer vectors from the Random123 distribution, checked in tests/test_rng.py).
  * Replaces the reference's per-particle cuRAND XORWOW state (cuda/particles.cu:524-575) with
  * a stateless counter (global particle id, step) -- Brownian parity is statistical only.
@@ -264,14 +264,19 @@ static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
     uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-void cw_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void cw_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k[2] = {key[0], key[1]};
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         philox_round(c, k);
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
     }
     memcpy(out, c, sizeof(c));
 }
+/* R = 10: Random123's default, the round count its known-answer vectors are published for (tests/test_rng.py) */
+void cw_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { cw_philox4x32(ctr, key, 10, out); }
+/* What the kernels draw from (csrc/cpf_walk.h, CPF_PHILOX_ROUNDS): R = 7, the fewest rounds the paper reports as passing
+ * BigCrush -- the same round function and key schedule as the vector-checked R = 10, three rounds earlier. */
+#define CW_PHILOX_ROUNDS 7
 /* Box-Muller on the four words of one Philox block, in single precision (the kernels' normal3, csrc/cpf_walk.h, which
  * evaluates log2 / sqrt / sin / cos with the fp32 hardware instructions: the two agree to a few 1e-6, asserted; the
  * statistics are identical).  Words 0,1 -> two deviates, words 2,3 -> the third.
@@ -298,7 +303,7 @@ void cw_normal3_words(const uint32_t w[4], double out[3]) {
 void cw_normal3(uint64_t gid, uint32_t step, uint32_t seed, double out[3]) {
     uint32_t key[2] = {seed, 0x43504631u /* "CPF1" */};
     uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0}, w[4];
-    cw_philox4x32_10(ctr, key, w);
+    cw_philox4x32(ctr, key, CW_PHILOX_ROUNDS, w);
     cw_normal3_words(w, out);
 }
 /* test helper: the (gid, step) in [0, n) x [step0, step0 + nSteps) whose FIRST radius word is smallest, i.e. whose
@@ -310,7 +315,7 @@ void cw_scan_min_radius_word(uint32_t seed, uint32_t step0, int nSteps, int64_t 
     for (int t = 0; t < nSteps; ++t)
         for (int64_t g = 0; g < n; ++g) {
             uint32_t ctr[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), step0 + (uint32_t)t, 0}, w[4];
-            cw_philox4x32_10(ctr, key, w);
+            cw_philox4x32(ctr, key, CW_PHILOX_ROUNDS, w);
             if (w[0] < best) { best = w[0]; bg = g; bs = step0 + (uint32_t)t; }
         }
     *bestGid = bg; *bestStep = bs; *bestWord = best;

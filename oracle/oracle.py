@@ -234,6 +234,7 @@ class CellWalk:
                               C.c_int, _lp, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32]
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
+        L.cw_philox4x32.argtypes = [_up, _up, C.c_int, _up]
         L.cw_normal3.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         L.cw_normal3_words.argtypes = [_up, _dp]
         L.cw_scan_min_radius_word.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.POINTER(C.c_int64),
@@ -276,9 +277,10 @@ class CellWalk:
                                    t.n_cells, t.cell_off, t.planes, nthreads)
         return cell
 
-    def philox(self, ctr, key):
+    def philox(self, ctr, key, rounds=10):
+        """Philox4x32-`rounds` (10: Random123's default, the round count of its known-answer vectors; the kernels draw at 7)"""
         out = np.zeros(4, np.uint32)
-        self.lib.cw_philox4x32_10(_c(ctr, np.uint32), _c(key, np.uint32), out)
+        self.lib.cw_philox4x32(_c(ctr, np.uint32), _c(key, np.uint32), int(rounds), out)
         return out
 
     def normal3(self, gid, step, seed):

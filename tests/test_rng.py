@@ -15,6 +15,30 @@ def test_philox_known_answers(oracle_libs):
         assert tuple(int(v) for v in got) == want
 
 
+def test_seven_round_variant_is_the_same_function_three_rounds_earlier(oracle_libs):
+    """The kernels draw from Philox4x32-7 (csrc/cpf_walk.h: the fewest rounds reported as passing BigCrush).  Random123's
+    published vectors are for R = 10, checked above; R = 7 runs the same round function and key schedule: three more rounds
+    applied to its output, with the key where the schedule has it after seven bumps, give the R = 10 vector."""
+    cw = oracle_libs.CellWalk()
+    ctr, key = (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)
+    w7 = cw.philox(np.array(ctr, np.uint32), np.array(key, np.uint32), rounds=7)
+    k7 = np.array([(key[0] + 7 * 0x9E3779B9) & 0xFFFFFFFF, (key[1] + 7 * 0xBB67AE85) & 0xFFFFFFFF], np.uint32)
+    w10 = cw.philox(w7, k7, rounds=3)
+    assert tuple(int(v) for v in w10) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    assert not np.array_equal(w7, w10)
+    # and the words the deviates are made from are the seven-round ones
+    n3 = cw.normal3(12345, 6, 77)
+    w = cw.philox(np.array([12345, 0, 6, 0], np.uint32), np.array([77, 0x43504631], np.uint32), rounds=7)
+    assert np.array_equal(n3, cw.normal3_words(w))
+    # avalanche at R = 7: flipping one counter bit flips about half of the 128 output bits
+    flips = []
+    for bit in range(0, 64, 3):
+        c2 = np.array([12345 ^ (1 << bit) if bit < 32 else 12345, (1 << (bit - 32)) if bit >= 32 else 0, 6, 0], np.uint32)
+        w2 = cw.philox(c2, np.array([77, 0x43504631], np.uint32), rounds=7)
+        flips.append(sum(bin(int(a) ^ int(b)).count("1") for a, b in zip(w, w2)))
+    assert 52 < np.mean(flips) < 76 and min(flips) > 36
+
+
 def test_normal3_moments(oracle_libs):
     cw = oracle_libs.CellWalk()
     xi = np.array([cw.normal3(g, 3, 42) for g in range(20000)])
