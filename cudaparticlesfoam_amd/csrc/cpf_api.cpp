@@ -40,6 +40,7 @@ struct cpf_context {
     int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_curveRank = nullptr; // per-cell rank along the Morton curve: the sort's major key for sparse clouds ("sort_curve")
+    int sortMethod = 0;             // "sort_method": 0 = hipcub's radix sort for the (key, index) pairs, 1 = this library's own wide-digit one (cpf_kernels.hip, rs_sort_pairs: measured no faster, see there)
     int sortCurve = -1;             // "sort_curve": -1 = Morton rank when the cloud has fewer than 8 particles per cell, 0 = cell id, 1 = Morton rank
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;
@@ -710,7 +711,7 @@ int sortImpl(cpf_context* ctx, double* x, double* y, double* z, int32_t* cell, i
     if (r) return r;
     CPF_HIP(ctx, cpf::sort_by_cell(ctx->stream, x, y, z, cell, gid, vel3, n, endBit, ctx->d_cellBox, ctx->host.subBits,
                                    ctx->host.subOrder, ctx->scratch, ctx->scratchBytes, ox, oy, oz, ocell, ogid, census ? ctx->d_occupied : nullptr,
-                                   curve ? ctx->d_curveRank : nullptr));
+                                   curve ? ctx->d_curveRank : nullptr, ctx->sortMethod));
     // how many cells hold particles: what the streaming kernel's lookup method goes by with "stream_lookup_by_density"
     // (StreamState::occupiedHost).  Only then: the 16-byte device-to-host copy behind the sort costs 0.9 ms on this stack
     // (measured: 1.50 against 0.60 ms per sort of 1e7 particles) -- more than the sort itself.
@@ -888,6 +889,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
     if (k == "stream_lookup_by_density") {
         CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "stream_lookup_by_density must be 0 or 1");
         ctx->streamState.densityLookup = (int)value;
+        return CPF_OK;
+    }
+    if (k == "sort_method") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "sort_method must be 0 (library radix sort) or 1 (hand-written)");
+        ctx->sortMethod = (int)value;
         return CPF_OK;
     }
     if (k == "sort_curve") {

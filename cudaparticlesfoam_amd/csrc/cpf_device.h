@@ -136,7 +136,7 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox = nullptr, double* oy = nullptr, double* oz = nullptr,
                         int32_t* ocell = nullptr, int64_t* ogid = nullptr, unsigned long long* occupied = nullptr,
-                        const int32_t* rank = nullptr);
+                        const int32_t* rank = nullptr, int method = 1);      // method 0: the library radix sort (the order tests compare with)
 
 // multi-GPU hand-off (cpf_handoff.hip)
 size_t handoff_scratch_bytes(int64_t n, int nRanks);

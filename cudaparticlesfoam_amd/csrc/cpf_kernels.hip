@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void gather_all_kernel(const double* __rest
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int64_t j = perm[i];
-    const uint32_t k = keys[i];
+    const uint32_t k = cellFromKey ? keys[i] : 0xFFFFFFFFu;
     const double a = x[j], b = y[j], c = z[j];
     const int64_t g = gid ? gid[j] : 0;
     const int32_t cc = (cellFromKey && k != 0xFFFFFFFFu) ? (int32_t)(k >> nSub) : cell[j];
@@ -1047,13 +1047,305 @@ __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __r
     keys[i] = ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The key sort, hand-written (round 5, option "sort_method" 1; the default stays hipcub::DeviceRadixSort, see MEASURED below):
+// a stable LSD radix sort of (key, index) pairs with WIDE digits -- ceil(endBit / 11) passes,
+// i.e. two for pitzDaily's 21 key bits where the library's 8-bit digits need three -- as chunked counting sorts:
+//   * the cloud is cut into up to 512 contiguous chunks, one workgroup (8 waves) each, every wave owning a contiguous eighth
+//     of its chunk: stability then needs no ordering BETWEEN waves -- wave w's elements simply rank behind those of the waves
+//     before it, through private per-wave counters in LDS ([8][2^bits] words: 64 KB at 11 bits);
+//   * per pass: per-chunk digit counts (pass 1: by the kernel that builds the keys, no extra read), one column scan over the
+//     [chunks][2^bits] matrix, one scatter kernel -- wave histogram, base = bin start + chunks before + waves before, then
+//     the wave walks its elements again in order: lanes with equal digits find each other with one ballot per digit bit,
+//     rank = base + lanes of the group before me, the group's first lane advances the wave's counter;
+//   * the first pass reads no index array (the index is the position), the last writes no keys (the gather reads the cell
+//     where it reads the position).
+// Traffic per particle for two passes: 28 + 4 (keys) + 4 + 8 (pass 1) + 4 + 8 + 4 (pass 2) + 4 + 36 + 36 (gather) = 136 B
+// against ~190 B with three library passes, an index fill and keys carried to the end.
+// MEASURED (rocprofv3 kernel trace, one box, 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago; profiles/
+// r05_sort_kernel_trace.csv): keys + counts 67 us, column scans 2 x 14.5, pass 1 (the low digit is the sub-cell position: every
+// lane of a wave writes to a different bin, 8 bytes per 64-byte line) 183, counts 26, pass 2 (the high digit is the cell: long
+// runs, coalesced) 58, gather 323 -- 0.69 ms, the library path's 0.70 (index fill 12, keys 64, three passes of 90, gather 323).
+// The wide first pass loses to write amplification what it saves in passes; the gather of five arrays through a scrambled
+// permutation (one 64-byte L2 transaction per 8-byte element) is half of either total and is what a faster re-sort would have
+// to remove.  Three 8-bit passes on TJunction's 24 key bits: 0.37 ms against the library's 0.29 -- hence not the default.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRsThreads = 512, kRsWaves = kRsThreads / 64, kRsMaxChunks = 512, kRsMaxBits = 11;
+struct RsPlan {
+    int passes, bits[4], shift[4];
+    int nChunks;
+    int64_t chunk;       // elements per chunk: a multiple of 64 * kRsWaves
+};
+static RsPlan rs_plan(int64_t n, int endBit) {
+    RsPlan p{};
+    p.passes = (endBit + kRsMaxBits - 1) / kRsMaxBits;
+    const int d = (endBit + p.passes - 1) / p.passes;
+    for (int k = 0; k < p.passes; ++k) { p.shift[k] = k * d; p.bits[k] = std::min(d, endBit - k * d); }
+    const int64_t unit = 64 * kRsWaves;
+    int64_t chunk = (n + kRsMaxChunks - 1) / kRsMaxChunks;
+    chunk = std::max<int64_t>(unit * 4, (chunk + unit - 1) / unit * unit);       // at least 4 wave-steps per wave
+    p.chunk = chunk;
+    p.nChunks = (int)((n + chunk - 1) / chunk);
+    return p;
+}
+static inline size_t rs_al(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t rs_scratch_bytes(int64_t n, int endBit) {
+    const RsPlan p = rs_plan(n, endBit);
+    const int maxBits = *std::max_element(p.bits, p.bits + p.passes);
+    // two (key, index) buffers for the ping-pong, the count matrix, the bin totals, one staging array (in-place form)
+    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4) + rs_al(((size_t)1 << maxBits) * 4) + rs_al(24 * (size_t)n);
+}
+
+// a lane's sort key (see sort_keys_kernel)
+__device__ __forceinline__ uint32_t sort_key_of(double px, double py, double pz, int32_t c, const float* __restrict__ cellBox,
+                                                const int32_t* __restrict__ rank, const SubKey& sk, int subBits) {
+    if (c < 0) return 0xFFFFFFFFu;
+    const float* b = cellBox + 6 * (int64_t)c;
+    const float r[3] = {((float)px - b[0]) * b[3], ((float)py - b[1]) * b[4], ((float)pz - b[2]) * b[5]};
+    uint32_t sub = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = sk.order[k];
+        const int q = min((1 << sk.bits[a]) - 1, max(0, (int)(a == 0 ? r[0] : (a == 1 ? r[1] : r[2]))));
+        sub = (sub << sk.bits[a]) | (uint32_t)q;
+    }
+    return ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
+}
+
+// keys of chunk blockIdx.x + its counts of the FIRST pass's digit: counts[chunk][bin]
+__global__ __launch_bounds__(kRsThreads) void rs_keys_hist_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                                  const double* __restrict__ z, const int32_t* __restrict__ cell,
+                                                                  const float* __restrict__ cellBox, const int32_t* __restrict__ rank,
+                                                                  SubKey sk, int subBits, uint32_t* __restrict__ keys, int64_t n,
+                                                                  int64_t chunk, int bits, uint32_t* __restrict__ counts) {
+    extern __shared__ unsigned sHist[];
+    const int bins = 1 << bits;
+    for (int b = threadIdx.x; b < bins; b += kRsThreads) sHist[b] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint32_t mask = (uint32_t)bins - 1u;
+    constexpr int U = 4;
+    for (int64_t base = lo; base < hi; base += (int64_t)U * kRsThreads) {
+        double px[U], py[U], pz[U]; int32_t pc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * kRsThreads + threadIdx.x;
+            pc[u] = -1; px[u] = py[u] = pz[u] = 0.0;
+            if (i < hi) { px[u] = x[i]; py[u] = y[i]; pz[u] = z[i]; pc[u] = cell[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * kRsThreads + threadIdx.x;
+            if (i < hi) {
+                const uint32_t k = sort_key_of(px[u], py[u], pz[u], pc[u], cellBox, rank, sk, subBits);
+                keys[i] = k;
+                atomicAdd(&sHist[k & mask], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* row = counts + (int64_t)blockIdx.x * bins;
+    for (int b = threadIdx.x; b < bins; b += kRsThreads) row[b] = sHist[b];
+}
+
+// counts[chunk][bin] of a later pass's digit.  The keys are sorted by the lower digits by then and the cloud is kept almost
+// sorted: long runs of equal digits -- one LDS atomic per run of a wave instead of one per lane
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t chunk, int shift,
+                                                             int bits, uint32_t* __restrict__ counts) {
+    extern __shared__ unsigned sHist[];
+    const int bins = 1 << bits;
+    for (int b = threadIdx.x; b < bins; b += kRsThreads) sHist[b] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint32_t mask = (uint32_t)bins - 1u;
+    const int lane = threadIdx.x & 63;
+    constexpr int B = 4;
+    for (int64_t base0 = lo; base0 < hi; base0 += (int64_t)B * kRsThreads) {     // (wave-uniform trip counts: chunk is a multiple of the block)
+        uint32_t kk[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int64_t i = base0 + (int64_t)u * kRsThreads + threadIdx.x; kk[u] = i < hi ? keys[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int64_t i = base0 + (int64_t)u * kRsThreads + threadIdx.x;
+            const bool live = i < hi;
+            const uint32_t d = (kk[u] >> shift) & mask;
+            bool todo = live;
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long m = __ballot(todo);
+                if (m == 0ull) break;
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                const unsigned long long same = __ballot(todo && d == dl);
+                if (lane == leader) atomicAdd(&sHist[dl], (unsigned)__popcll(same));
+                if (d == dl) todo = false;
+            }
+            if (todo) atomicAdd(&sHist[d], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* row = counts + (int64_t)blockIdx.x * bins;
+    for (int b = threadIdx.x; b < bins; b += kRsThreads) row[b] = sHist[b];
+}
+
+// counts[chunk][bin] -> number of the bin's elements in the chunks BEFORE this one (in place); totals[bin] = the bin's size.
+// A block takes 64 bins; its 16 row groups split the chunks (lane = bin: every row read is one 256-byte segment).
+constexpr int kRsScanGroups = 16;
+__global__ __launch_bounds__(64 * kRsScanGroups) void rs_colscan_kernel(uint32_t* __restrict__ counts, int nChunks, int bins,
+                                                                       uint32_t* __restrict__ totals) {
+    __shared__ uint32_t sSum[kRsScanGroups][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + lane;
+    const int per = (nChunks + kRsScanGroups - 1) / kRsScanGroups;
+    const int r0 = min(nChunks, grp * per), r1 = min(nChunks, r0 + per);
+    uint32_t s = 0;
+    if (bin < bins)
+        for (int r = r0; r < r1; ++r) s += counts[(int64_t)r * bins + bin];
+    sSum[grp][lane] = s;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int g = 0; g < grp; ++g) run += sSum[g][lane];
+    if (bin < bins) {
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t v = counts[(int64_t)r * bins + bin];
+            counts[(int64_t)r * bins + bin] = run;
+            run += v;
+        }
+        if (grp == kRsScanGroups - 1) totals[bin] = run;
+    }
+}
+
+// One pass: every element of chunk blockIdx.x goes to (start of its bin) + (the bin's elements in earlier chunks) + (in the
+// earlier waves of this chunk) + (earlier in this wave).  idxIn == nullptr: the element's index is its position (first
+// pass); keysOut == nullptr: the keys are not needed any more (last pass).
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ idxIn,
+                                                                uint32_t* __restrict__ keysOut, int32_t* __restrict__ idxOut, int64_t n,
+                                                                int64_t chunk, int shift, int bits, const uint32_t* __restrict__ before,
+                                                                const uint32_t* __restrict__ totals) {
+    extern __shared__ unsigned sMem[];                          // [kRsWaves][bins] wave counters | [bins] bin starts
+    const int bins = 1 << bits;
+    unsigned* const sCnt = sMem;
+    unsigned* const sStart = sMem + kRsWaves * bins;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    for (int b = threadIdx.x; b < kRsWaves * bins; b += kRsThreads) sCnt[b] = 0u;
+    // bin starts = exclusive scan of the totals: every thread sums a run of bins, the runs' sums are scanned by thread 0's wave
+    __shared__ unsigned sRun[kRsThreads];
+    const int perT = (bins + kRsThreads - 1) / kRsThreads;
+    const int b0 = min(bins, (int)threadIdx.x * perT), b1 = min(bins, b0 + perT);
+    unsigned mine = 0;
+    for (int b = b0; b < b1; ++b) mine += totals[b];
+    sRun[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int t = 0; t < kRsThreads; ++t) { const unsigned v = sRun[t]; sRun[t] = run; run += v; }
+    }
+    __syncthreads();
+    {
+        unsigned run = sRun[threadIdx.x];
+        for (int b = b0; b < b1; ++b) { sStart[b] = run; run += totals[b]; }
+    }
+    // phase 1: the wave's own digit counts over its eighth of the chunk
+    const int64_t sub = chunk / kRsWaves;
+    const int64_t lo = (int64_t)blockIdx.x * chunk + (int64_t)wave * sub, hi = min(n, lo + sub);
+    unsigned* const myCnt = sCnt + wave * bins;
+    __syncthreads();
+    constexpr int B = 8;                                        // independent loads in flight per lane
+    for (int64_t base = lo; base < hi; base += 64 * B) {
+        uint32_t kk[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int64_t i = base + 64 * u + lane; kk[u] = i < hi ? keysIn[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int64_t i = base + 64 * u + lane; if (i < hi) atomicAdd(&myCnt[(kk[u] >> shift) & mask], 1u); }
+    }
+    __syncthreads();
+    // phase 2: counts -> first position of (wave, bin)
+    const uint32_t* const row = before + (int64_t)blockIdx.x * bins;
+    for (int b = threadIdx.x; b < bins; b += kRsThreads) {
+        unsigned run = sStart[b] + row[b];
+#pragma unroll
+        for (int w = 0; w < kRsWaves; ++w) { const unsigned v = sCnt[w * bins + b]; sCnt[w * bins + b] = run; run += v; }
+    }
+    __syncthreads();
+    // phase 3: the wave walks its elements again, in order
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int64_t base0 = lo; base0 < hi; base0 += 64 * B) {
+        uint32_t kk[B]; int32_t ss[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int64_t i = base0 + 64 * u + lane;
+            kk[u] = i < hi ? keysIn[i] : 0u;
+            ss[u] = (i < hi && idxIn) ? idxIn[i] : (int32_t)i;
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int64_t i = base0 + 64 * u + lane;
+            const bool live = i < hi;
+            const uint32_t k = kk[u];
+            const uint32_t d = (k >> shift) & mask;
+            unsigned long long same = __ballot(live);           // lanes with my digit: one ballot per digit bit
+            for (int b = 0; b < bits; ++b) {
+                const unsigned long long one = __ballot(((d >> b) & 1u) != 0u);
+                same &= ((d >> b) & 1u) ? one : ~one;
+            }
+            if (live) {
+                const unsigned first = myCnt[d];                 // (every lane of the group reads it before its first lane writes)
+                const unsigned pos = first + (unsigned)__popcll(same & lt);
+                if ((same & lt) == 0ull) myCnt[d] = first + (unsigned)__popcll(same);
+                if (keysOut) keysOut[pos] = k;
+                idxOut[pos] = ss[u];
+            }
+        }
+    }
+}
+
+static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                                const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
+                                char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
+    const RsPlan p = rs_plan(n, endBit);
+    const int maxBits = *std::max_element(p.bits, p.bits + p.passes);
+    uint32_t* kA = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    uint32_t* kB = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    int32_t* iA = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    int32_t* iB = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4);
+    uint32_t* totals = (uint32_t*)scratch;
+    static bool attrSet = false;
+    if (!attrSet) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rs_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (kRsWaves + 1) * (1 << kRsMaxBits) * 4);
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    const uint32_t* kin = kA; const int32_t* iin = nullptr;
+    for (int k = 0; k < p.passes; ++k) {
+        const int bins = 1 << p.bits[k];
+        if (k == 0)
+            hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
+                               nSub, kA, n, p.chunk, p.bits[0], counts);
+        else
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
+        hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
+        const bool last = k == p.passes - 1;
+        uint32_t* kout = (kin == kA) ? kB : kA;
+        int32_t* iout = (iin == iA) ? iB : iA;
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)(kRsWaves + 1) * bins * 4, st, kin, iin,
+                           (last && !keepKeys) ? nullptr : kout, iout, n, p.chunk, p.shift[k], p.bits[k], counts, totals);
+        kin = kout; iin = iout;
+    }
+    *keysSorted = keepKeys ? kin : nullptr;
+    *perm = iin;
+    return hipGetLastError();
+}
+
 size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
     // keys in + keys out + iota + perm + one staging array (24 bytes per particle: also serves the velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(tmp) + al(4 * (size_t)n) * 4 + al(24 * (size_t)n);
+    return std::max(al(tmp) + al(4 * (size_t)n) * 4 + al(24 * (size_t)n), rs_scratch_bytes(n, endBit));
 }
 
 // Out arrays (ox ... ogid) given: the sorted cloud is written there and the input arrays are left alone -- no staging,
@@ -1081,12 +1373,43 @@ __global__ __launch_bounds__(kBlock) void count_cell_runs_kernel(const uint32_t*
 hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, double* vel3,
                         int64_t n, int endBit, const float* cellBox, const int* subBits, const int* subOrder,
                         void* scratch, size_t scratchBytes, double* ox, double* oy, double* oz, int32_t* ocell,
-                        int64_t* ogid, unsigned long long* occupied, const int32_t* rank) {
+                        int64_t* ogid, unsigned long long* occupied, const int32_t* rank, int method) {
     if (n <= 1) return hipSuccess;
     SubKey sk;
     for (int k = 0; k < 3; ++k) { sk.bits[k] = subBits[k]; sk.order[k] = subOrder[k]; }
     const int nSub = subBits[0] + subBits[1] + subBits[2];
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (method != 0) {
+        // ---- the hand-written key sort (see rs_sort_pairs); the same gathers as the library path below
+        if (rs_scratch_bytes(n, endBit) > scratchBytes) return hipErrorInvalidValue;
+        const uint32_t* keysSorted = nullptr; const int32_t* perm = nullptr;
+        hipError_t e = rs_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm);
+        if (e != hipSuccess) return e;
+        double* stage = (double*)((char*)scratch + rs_scratch_bytes(n, endBit) - rs_al(24 * (size_t)n));
+        if (occupied != nullptr) {
+            e = hipMemsetAsync(occupied, 0, 16, st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(count_cell_runs_kernel, grid_for(n), dim3(kBlock), 0, st, keysSorted, n, nSub, 0xFFFFFFFFu, occupied);
+        }
+        if (ox != nullptr) {
+            hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm,
+                               (const uint32_t*)nullptr, nSub, n, false);
+        } else {
+            double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;
+            hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, perm, n);
+            hipLaunchKernelGGL(copy_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, n);
+            int64_t* sg = reinterpret_cast<int64_t*>(stage);
+            int32_t* sc = reinterpret_cast<int32_t*>(stage + n);
+            hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, sc, sg, perm, n);
+            hipLaunchKernelGGL(copy_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, sc, sg, n);
+        }
+        if (vel3) {
+            hipLaunchKernelGGL(gather3_kernel, grid_for(n), dim3(kBlock), 0, st, vel3, stage, perm, n);
+            e = hipMemcpyAsync(vel3, stage, 24 * (size_t)n, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipGetLastError();
+    }
     size_t tmpBytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
@@ -1113,8 +1436,9 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, ox, oy, oz, perm, n);
         hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, ocell, ogid, perm, n);
 #else
+        // (a live particle's cell out of its sorted key: only where no cell bit was shifted out of the 32-bit key)
         hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n,
-                           rank == nullptr);
+                           rank == nullptr && endBit < 32);
 #endif
     } else {
         double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;          // the 24n-byte staging area

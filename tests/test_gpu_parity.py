@@ -1280,3 +1280,56 @@ def test_sparse_clouds_are_sorted_along_the_morton_curve(gpu_ctx_factory, oracle
         d = np.abs(np.diff(cc[cells], axis=0))
         return np.median(d[np.diff(cells) != 0], axis=0)
     assert jump(orders[1])[1:].max() < 0.6 * max(jump(orders[0])[1:].max(), 1e-9) or jump(orders[1]).sum() < jump(orders[0]).sum()
+
+
+@pytest.mark.parametrize("case", ["pitz", "box3d", "box3d_curve", "pitz_census", "tiny"])
+def test_hand_written_key_sort_gives_the_library_sort_order(case, setup, gpu_ctx_factory):
+    """Option "sort_method" 1 (this library's stable wide-digit radix sort, csrc/cpf_kernels.hip rs_sort_pairs: two passes of
+    11 / 10 bits on pitzDaily, three of 8 on a 3-D mesh) orders the cloud exactly like hipcub::DeviceRadixSort (method 0):
+    same permutation, particle for particle -- lost particles at the tail, sizes that do not fill the last chunk, the Morton
+    major key, the occupied-cell census, in place and into a second set of arrays."""
+    import torch
+    from cudaparticlesfoam_amd.cases import box_mesh
+    pz = setup["pz"]
+    dev = torch.device("cuda", 0)
+    if case.startswith("pitz"):
+        mesh, box = setup["mesh"], (np.array(pz.DOMAIN_BOX[0]) - 0.002, np.array(pz.DOMAIN_BOX[1]) + 0.002)
+        sizes = (1_000_003, 4097)
+    elif case == "tiny":
+        mesh, box = setup["mesh"], pz.DOMAIN_BOX
+        sizes = (2, 63, 64, 65, 2049)
+    else:
+        mesh, box = box_mesh(40, 30, 20), (np.array([-0.5, -0.5, -0.5]), np.array([40.5, 30.5, 20.5]))
+        sizes = (700_001,)
+    ctx = gpu_ctx_factory(); ctx.set_mesh(mesh)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if case == "box3d_curve":
+        ctx.set_option("sort_curve", 1)
+    if case == "pitz_census":
+        ctx.set_option("stream_lookup_by_density", 1)
+    p = lambda t: t.data_ptr()   # noqa: E731
+    for n in sizes:
+        rng = np.random.default_rng(n)
+        xyz = rng.uniform(box[0], box[1], size=(n, 3))
+        base = [torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3)]
+        c0 = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx.locate_initial_dev(p(base[0]), p(base[1]), p(base[2]), p(c0), n)
+        g0 = torch.arange(n, dtype=torch.int64, device=dev) * 3 + 1
+        res = {}
+        for method in (0, 1):
+            ctx.set_option("sort_method", method)
+            x, y, z, c, g = (t.clone() for t in (*base, c0, g0))
+            out = [torch.zeros_like(t) for t in (x, y, z, c, g)]
+            ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), *(p(t) for t in out), n)
+            ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(out, (x, y, z, c, g)))
+            res[method] = [t.cpu().numpy() for t in (x, y, z, c, g)]
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        cs = res[1][3]
+        k = int((cs >= 0).sum())
+        assert (cs[:k] >= 0).all() and (cs[k:] < 0).all()
+        if case != "box3d_curve" and n >= 8 * mesh.n_cells:                 # (sparser clouds are ordered along the Morton curve)
+            assert (np.diff(cs[:k].astype(np.int64)) >= 0).all()
+    ctx.use_own_stream()
