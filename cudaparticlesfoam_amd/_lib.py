@@ -173,6 +173,16 @@ SIGNATURES = {
     "cpf_timing_enable": (_int, [_ctx, _int]),
     "cpf_timing_read": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
     "cpf_timing_poll": (_int, [_ctx, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "cpf_traj_create": (_int, [C.POINTER(_vp)]),
+    "cpf_traj_destroy": (None, [_vp]),
+    "cpf_traj_add": (_int, [_ctx, _vp]),
+    "cpf_traj_add_stage": (_int, [_ctx, _vp, _vp, _i64]),
+    "cpf_traj_add_host": (_int, [_vp, _vp, _i64]),
+    "cpf_traj_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "cpf_traj_save_obj": (_int, [_vp, C.c_char_p]),
+    "cpf_traj_write_vtk": (_int, [_vp, C.c_char_p]),
+    "cpf_traj_save_obj_arrays": (_int, [C.c_char_p, _i64, _vp, _vp]),
+    "cpf_traj_write_vtk_arrays": (_int, [C.c_char_p, _i64, _vp, _vp]),
     "cpf_device_count": (_int, [C.POINTER(_int)]),
     "cpf_comm_unique_id": (_int, [_vp, _int]),
     "cpf_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(C.POINTER(Comm))]),

@@ -171,16 +171,40 @@ inline void writeParticles2VTU(unsigned int ti, Particle* d_particles, vec4d* d_
 }
 
 // Trajectory collection and its two writers (cuda/common.h:87-92, cuda/utils.cpp:7-94): in the reference's fragments they sit
-// behind `saveStreamlinetoFile`, which src/initCuda.H:68 hard-codes to false, i.e. they are dead code there.  They are
-// declared here so that a host that kept src/advect.H:163-175 verbatim still compiles; calling one says what is missing.
-inline void addToTrajectories(Particle* /*d_particles*/, int /*numParticles*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
-    throw Error(CPF_ERR_STATE, "addToTrajectories: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
+// behind `saveStreamlinetoFile`, which src/initCuda.H:68 hard-codes to false.  Same signatures: the samples live in the
+// caller's vectors; the device-to-host copy and the two file formats are the library's (cpf_traj_*, csrc/cpf_traj.cpp).
+inline void addToTrajectories(Particle* d_particles, int numParticles, std::vector<std::vector<vec3f>>& trajectories) {
+    cpf_context* c = currentMesh().ctx;
+    if (trajectories.empty()) trajectories.resize((std::size_t)numParticles);
+    std::vector<double> P((std::size_t)numParticles * 4);
+    check(c, cpf_copy_to_host(c, P.data(), d_particles, P.size() * 8));
+    for (int i = 0; i < numParticles; ++i) {
+        if (!P[4 * (std::size_t)i + 3]) continue;                    // inactive particle: no sample (cuda/utils.cpp:21)
+        trajectories[(std::size_t)i].push_back(vec3f{(float)P[4 * (std::size_t)i], (float)P[4 * (std::size_t)i + 1], (float)P[4 * (std::size_t)i + 2]});
+    }
 }
-inline void saveTrajectories(const std::string& /*fileName*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
-    throw Error(CPF_ERR_STATE, "saveTrajectories: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
+namespace detail {
+inline void flattenTrajectories(const std::vector<std::vector<vec3f>>& trajectories, std::vector<std::int64_t>& off, std::vector<float>& xyz) {
+    off.assign(trajectories.size() + 1, 0);
+    std::int64_t total = 0;
+    for (std::size_t t = 0; t < trajectories.size(); ++t) { off[t] = total; total += (std::int64_t)trajectories[t].size(); }
+    off[trajectories.size()] = total;
+    xyz.reserve((std::size_t)total * 3);
+    for (const auto& traj : trajectories)
+        for (const auto& p : traj) { xyz.push_back(p.x); xyz.push_back(p.y); xyz.push_back(p.z); }
 }
-inline void writeStreamline2VTK(const std::string& /*fileName*/, std::vector<std::vector<vec3f>>& /*trajectories*/) {
-    throw Error(CPF_ERR_STATE, "writeStreamline2VTK: not built (dead in the reference: saveStreamlinetoFile = false, src/initCuda.H:68)");
+}  // namespace detail
+inline void saveTrajectories(const std::string& fileName, std::vector<std::vector<vec3f>>& trajectories) {
+    std::vector<std::int64_t> off; std::vector<float> xyz;
+    detail::flattenTrajectories(trajectories, off, xyz);
+    const int r = cpf_traj_save_obj_arrays(fileName.c_str(), (std::int64_t)trajectories.size(), off.data(), xyz.data());
+    if (r != CPF_OK) throw Error(r, "saveTrajectories: cannot write " + fileName);
+}
+inline void writeStreamline2VTK(const std::string& fileName, std::vector<std::vector<vec3f>>& trajectories) {
+    std::vector<std::int64_t> off; std::vector<float> xyz;
+    detail::flattenTrajectories(trajectories, off, xyz);
+    const int r = cpf_traj_write_vtk_arrays(fileName.c_str(), (std::int64_t)trajectories.size(), off.data(), xyz.data());
+    if (r != CPF_OK) throw Error(r, "writeStreamline2VTK: cannot write " + fileName);
 }
 
 inline std::string prettyNumber(std::size_t s) {

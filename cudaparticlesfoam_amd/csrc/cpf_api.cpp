@@ -167,6 +167,11 @@ void freeMesh(cpf_context* c) {
     freeDev(c->d_cellOff); freeDev(c->d_planes); freeDev(c->d_nbr); freeDev(c->d_groupOff); freeDev(c->d_groupNbr); freeDev(c->d_U); freeDev(c->d_U3); freeDev(c->d_cellRec); freeDev(c->d_boxRec); freeDev(c->d_cellBox); freeDev(c->d_curveRank);
     freeDev(c->d_binOff); freeDev(c->d_binCells);
     c->haveMesh = c->haveU = false; c->meshBytes = 0;
+    c->nSecondRecords = 0;
+    // the tet decomposition of the "VertexVelocity" mode belongs to the mesh it was made for (cpf_set_tets checks it against
+    // that mesh's cell count): a new mesh starts without one
+    freeDev(c->d_tetPos); freeDev(c->d_tets); freeDev(c->d_vertVel);
+    c->haveVertVel = false; c->nTets = c->nTetVerts = 0; c->tetsPerCell = 0;
 }
 void freeCloud(cpf_context* c) {
     freeDev(c->x); freeDev(c->y); freeDev(c->z); freeDev(c->vel); freeDev(c->cell); freeDev(c->gid);
@@ -228,8 +233,9 @@ int setMeshImpl(cpf_context* ctx, const double* points, int64_t nPoints, const L
         }
         CPF_REQUIRE(ctx, nCells + nSecond < ((int64_t)1 << 31), CPF_ERR_MESH, "cpf_set_mesh: too many cell records");
         int32_t* d_recB = nullptr;
-        if (nSecond > 0) CPF_HIP(ctx, up(d_recB, recB.data(), recB.size() * 4));
-        hipError_t e = hipMalloc((void**)&ctx->d_cellRec, (size_t)(nCells + nSecond) * 8 * sizeof(double4));
+        hipError_t e = hipSuccess;
+        if (nSecond > 0) e = up(d_recB, recB.data(), recB.size() * 4);          // (freed below on every path)
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_cellRec, (size_t)(nCells + nSecond) * 8 * sizeof(double4));
         if (e == hipSuccess) e = cpf::launch_build_cell_records_mixed(ctx->stream, ctx->d_cellOff, ctx->d_planes, ctx->d_nbr, ctx->d_U, d_recB,
                                                                       ctx->d_cellRec, nCells);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -370,6 +376,7 @@ const char* cpf_last_error(const cpf_context* ctx) {
 int cpf_set_stream(cpf_context* ctx, void* hip_stream) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fieldFlagArrived(ctx);                      // (a field note still on its way was recorded on the old stream: complete now)
     ctx->stream = (hipStream_t)hip_stream;      // NULL == HIP's default stream, a valid choice
     return CPF_OK;
 }
@@ -377,6 +384,7 @@ int cpf_set_stream(cpf_context* ctx, void* hip_stream) {
 int cpf_use_own_stream(cpf_context* ctx) {
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fieldFlagArrived(ctx);
     ctx->stream = ctx->ownStream;
     return CPF_OK;
 }
@@ -614,7 +622,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     const bool reflect = (flags & CPF_STEP_NO_REFLECT) == 0;
     const bool vertexU = (flags & CPF_STEP_VERTEX_VELOCITY) != 0;
-    CPF_REQUIRE(ctx, !vertexU || ctx->haveVertVel, CPF_ERR_STATE, "cpf_step: CPF_STEP_VERTEX_VELOCITY needs cpf_set_tets and cpf_set_vertex_velocity");
+    CPF_REQUIRE(ctx, !vertexU || (ctx->haveVertVel && ctx->nTets == (int64_t)ctx->tetsPerCell * ctx->host.nCells), CPF_ERR_STATE,
+                "cpf_step: CPF_STEP_VERTEX_VELOCITY needs cpf_set_tets and cpf_set_vertex_velocity for the current mesh");
     const cpf::MeshView m = meshView(ctx);
     const bool fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
     pollFieldFlag(ctx);
@@ -1151,7 +1160,8 @@ int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVe
 int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* ids, double* vels, double* disps,
                             double dt, int64_t n) {
     CPF_STAGE_PRE("cpf_stage_advect_vertex", false);
-    CPF_REQUIRE(ctx, ctx->haveVertVel, CPF_ERR_STATE, "cpf_stage_advect_vertex: call cpf_set_tets and cpf_set_vertex_velocity first");
+    CPF_REQUIRE(ctx, ctx->haveVertVel && ctx->nTets == (int64_t)ctx->tetsPerCell * ctx->host.nCells, CPF_ERR_STATE,
+                "cpf_stage_advect_vertex: call cpf_set_tets and cpf_set_vertex_velocity (for the current mesh) first");
     CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect_vertex: null array");
     CPF_HIP(ctx, cpf::launch_stage_advect_vertex(ctx->stream, particles, ids, vels, disps, dt, n, ctx->d_tetPos, ctx->d_tets,
                                                  ctx->tetsPerCell, ctx->d_vertVel));

@@ -532,6 +532,25 @@ int cpf_write_vtu_arrays(const char* path, int64_t n, const double* xyzw, const 
 int cpf_write_vtu_arrays_binary(const char* path, int64_t n, const double* xyzw, const int32_t* cell, const double* vel,
                                 double* totalKE);
 
+/* Trajectory collection and its two writers: addToTrajectories / saveTrajectories / writeStreamline2VTK
+ * (cuda/utils.cpp:7-94, cuda/common.h:87-92; called from src/advect.H:163-175 behind saveStreamlinetoFile).  A trajectory is
+ * the list of fp32 positions a particle had at the sampling instants at which it was active (w != 0); trajectories with fewer
+ * than two points are left out of both files.  Both files byte for byte as the reference writes them. */
+typedef struct cpf_traj cpf_traj;
+int cpf_traj_create(cpf_traj** out);
+void cpf_traj_destroy(cpf_traj* t);
+/* one sample of every active particle: of the context-owned cloud (particle-id order) / of the reference's AoS particle
+ * array in device memory (Particle = double4, [n][4]) / of a host array [n][4].  The first sample fixes the particle count. */
+int cpf_traj_add(cpf_context* ctx, cpf_traj* t);
+int cpf_traj_add_stage(cpf_context* ctx, cpf_traj* t, const double* particles_dev, int64_t n);
+int cpf_traj_add_host(cpf_traj* t, const double* xyzw, int64_t n);
+int cpf_traj_sizes(const cpf_traj* t, int64_t* nTrajectories, int64_t* nPoints);
+int cpf_traj_save_obj(const cpf_traj* t, const char* path);       /* saveTrajectories: Wavefront OBJ, "v" + "l" lines */
+int cpf_traj_write_vtk(const cpf_traj* t, const char* path);      /* writeStreamline2VTK: legacy VTK POLYDATA poly-lines */
+/* the same writers on a host's own storage: trajectory k = points offsets[k] .. offsets[k+1] of xyz[][3] */
+int cpf_traj_save_obj_arrays(const char* path, int64_t nTrajectories, const int64_t* offsets, const float* xyz);
+int cpf_traj_write_vtk_arrays(const char* path, int64_t nTrajectories, const int64_t* offsets, const float* xyz);
+
 /* ---------------------------------------------------------------------------------------------
  * measurement
  * ------------------------------------------------------------------------------------------- */

@@ -47,6 +47,11 @@ expect "$RTX/cuda/utils.cpp"         144 "writeParticles2VTU"
 expect "$RTX/cuda/utils.cpp"         172 "Output particle into VTU file"
 expect "$RTX/cuda/utils.cpp"         217 "h_ctetIDs(numParticles)"
 expect "$RTX/cuda/utils.cpp"         282 "fclose(fp)"
+expect "$RTX/cuda/utils.cpp"         7   "void addToTrajectories"
+expect "$RTX/cuda/utils.cpp"         20  "for (int i = 0; i < numParticles; i++)"
+expect "$RTX/cuda/utils.cpp"         30  "void saveTrajectories"
+expect "$RTX/cuda/utils.cpp"         49  "void writeStreamline2VTK"
+expect "$RTX/cuda/utils.cpp"         96  "void writeParticles2OBJ"
 
 {
   sed -n '82,104p;108,156p;193,199p' "$RTX/cuda/DeviceTetMesh.cuh"   # det, tetBaryCoord, triNorm
@@ -62,6 +67,10 @@ expect "$RTX/cuda/utils.cpp"         282 "fclose(fp)"
 # the body of writeParticles2VTU (host code: the on-disk format).  Its three cudaMemcpy device-to-host copies
 # (:151-170 and :218-221) are left out -- the driver passes host arrays -- everything that formats is the
 # reference's own text.
+# the trajectory collection and its two writers (host code): the sampling loop of addToTrajectories (:20-27, i.e. without its
+# cudaMemcpy -- the driver passes a host array) and saveTrajectories / writeStreamline2VTK whole (:30-47, :49-94)
+sed -n '20,27p'  "$RTX/cuda/utils.cpp" > "$TMP/ref_traj_add.inc"
+sed -n '30,47p;49,94p' "$RTX/cuda/utils.cpp" > "$TMP/ref_traj_writers.inc"
 sed -n '172,217p' "$RTX/cuda/utils.cpp" > "$TMP/ref_vtu_head.inc"
 sed -n '222,282p' "$RTX/cuda/utils.cpp" > "$TMP/ref_vtu_tail.inc"
 

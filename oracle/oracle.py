@@ -114,6 +114,9 @@ class RefLib(_TetApi):
         L.ref_box_mesh.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _ip, C.c_int, C.c_int]
         L.ref_box_mesh.restype = C.c_int
         L.ref_write_vtu.argtypes = [C.c_uint, _dp, _dp, _ip, C.c_int, _ip]
+        L.ref_traj_add.argtypes = [_dp, C.c_int]
+        L.ref_traj_save_obj.argtypes = [C.c_char_p]
+        L.ref_traj_write_vtk.argtypes = [C.c_char_p]
 
     def write_vtu(self, directory, ti, particles, vels, tet_ids, convex_ids):
         """The reference's writeParticles2VTU (cuda/utils.cpp:144-283) on host arrays: <directory>/particle_%04d.vtu."""
@@ -125,6 +128,16 @@ class RefLib(_TetApi):
         finally:
             os.chdir(cwd)
         return os.path.join(directory, "particle_%04d.vtu" % ti)
+
+    def trajectories(self, samples, obj_path, vtk_path):
+        """The reference's addToTrajectories / saveTrajectories / writeStreamline2VTK (cuda/utils.cpp:7-94) on host samples
+        (a list of [n][4] particle arrays, w = 0: inactive)."""
+        self.lib.ref_traj_reset()
+        for P in samples:
+            P = _c(P, np.float64)
+            self.lib.ref_traj_add(P, P.shape[0])
+        self.lib.ref_traj_save_obj(obj_path.encode())
+        self.lib.ref_traj_write_vtk(vtk_path.encode())
 
     def box_mesh(self, nx, ny, nz):
         nV = (nx + 1) * (ny + 1) * (nz + 1); nT = 6 * nx * ny * nz

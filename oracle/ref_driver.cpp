@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <iostream>
+#include <fstream>
 #include <sstream>
 #include <map>
 #include <vector>
@@ -44,6 +45,7 @@ using std::isnan;
 namespace advect {
 typedef double4 Particle;
 #include "ref_extract.inc"                 // generated into a temp dir by build_ref.sh
+#include "ref_traj_writers.inc"            // saveTrajectories, writeStreamline2VTK (cuda/utils.cpp:30-47, 49-94), whole
 }  // namespace advect
 
 using namespace advect;
@@ -213,6 +215,20 @@ int ref_write_vtu(unsigned int ti, const double* particles /* [n][4] */, const d
 #include "ref_vtu_tail.inc"            // utils.cpp:222-282, through fclose(fp)
     return 0;
 }
+
+// The reference's trajectory collection (cuda/utils.cpp:7-28) on a host array -- only its device-to-host copy is replaced
+// by the argument -- and its two writers (:30-94) as they stand.
+static std::vector<std::vector<vec3f>> g_trajectories;
+void ref_traj_reset(void) { g_trajectories.clear(); }
+void ref_traj_add(const double* particles /* [n][4] */, int numParticles) {
+    std::vector<std::vector<vec3f>>& trajectories = g_trajectories;
+    if (trajectories.empty()) trajectories.resize(numParticles);           // :10-11
+    std::vector<Particle> hostParticles(numParticles);
+    std::memcpy(hostParticles.data(), particles, sizeof(Particle) * (size_t)numParticles);
+#include "ref_traj_add.inc"                // utils.cpp:20-27, the sampling loop
+}
+void ref_traj_save_obj(const char* path) { saveTrajectories(path, g_trajectories); }
+void ref_traj_write_vtk(const char* path) { writeStreamline2VTK(path, g_trajectories); }
 
 int ref_max_threads(void) {
 #ifdef _OPENMP

@@ -136,7 +136,7 @@ def test_parallel_fragments_transient_field_with_diffusion(tmp_path, pitz, n_pro
     from case_dump import dump_case
     from cudaparticlesfoam_amd.cases import split_into_parts
     mesh, U = pitz["mesh"], pitz["U_analytic"]
-    d = dict(DICT, diffusionCoeff=1.5e-5, saveInterval=7)
+    d = dict(DICT, diffusionCoeff=1.5e-5, saveInterval=7, saveStreamline=1)        # + the trajectory files (src/advect.H:163-175)
     case = str(tmp_path / "case")
     dump_case(case, mesh, U, d, 1.0, 20e-4)
     ser = tmp_path / "serial"; ser.mkdir()
@@ -151,8 +151,10 @@ def test_parallel_fragments_transient_field_with_diffusion(tmp_path, pitz, n_pro
     assert outp.count("nCycles: 20") == 3
     frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
     assert frames == sorted(os.path.basename(p) for p in glob.glob(str(ser / "particle_*.vtu"))) and len(frames) >= 9
-    for f in frames:
+    for f in frames + ["Streamline.vtk"]:
         assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
+    head = open(str(ser / "Streamline.vtk")).read(400)
+    assert head.startswith("# vtk DataFile Version 4.1") and "POINTS" in head
 
 
 def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):

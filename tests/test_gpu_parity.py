@@ -149,6 +149,50 @@ def test_flat_walk_bit_exact(setup, field, n, want):
     assert np.array_equal(np.sort(outs[1][1]), np.sort(c))
 
 
+@pytest.mark.parametrize("how", ["last_cell_z", "nan_z", "negative_zero_z", "dev_then_set_stream"])
+def test_flat_walk_is_decided_by_the_whole_field(how, setup):
+    """The flat walk runs only for a field WITHOUT a z component, found by the kernel that lays the field out (round-4 advisory):
+    a z component in the very last cell, or a NaN one, switches it off (the particles there do move in z: equal to the CPU
+    statement); -0.0 everywhere keeps it on; and after cpf_set_velocity_dev -- the note arrives asynchronously -- a change of
+    stream before the step neither loses nor misreads it."""
+    import torch
+    pz, ctx, cw, t, mesh = setup["pz"], setup["ctx"], setup["cw"], setup["tables"], setup["mesh"]
+    U = setup["pitz"]["U_analytic"].copy()
+    ctx.set_option("step_variant", -1); ctx.set_option("stream_lookup", -1); ctx.set_option("flat_walk", 1)
+    n = 2_000_000
+    xyz = _seed_points(pz, n, pz.DOMAIN_BOX, seed=43)
+    flat = True
+    if how == "last_cell_z":
+        U[-1, 2] = 0.37; flat = False
+    elif how == "nan_z":
+        U[mesh.n_cells // 2, 2] = np.nan; flat = False
+    elif how == "negative_zero_z":
+        U[:, 2] = -0.0
+    dev = torch.device("cuda", 0)
+    if how == "dev_then_set_stream":
+        s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ctx.set_stream(s1.cuda_stream)
+        dU = torch.from_numpy(U).to(dev); torch.cuda.synchronize()
+        ctx.set_velocity_dev(dU.data_ptr(), mesh.n_cells)       # (the "no z component" note is read back behind it, asynchronously)
+        ctx.set_stream(s2.cuda_stream)                           # ... and the stream changes before anybody has seen it
+    else:
+        ctx.set_velocity(U)
+    ctx.set_particles(xyz); ctx.locate_initial(); ctx.sort_by_cell()
+    ctx.step(2e-4, 0.0, 6, 0)
+    name = ctx.step_kernel_name(0.0, 0)
+    assert name.endswith(", 8>" if flat else ", 0>"), name
+    got, gc = ctx.get_particles()
+    if how != "nan_z":                                           # (a NaN velocity has no CPU answer worth comparing)
+        x, y, z = (xyz[:, k].copy() for k in range(3))
+        c = cw.locate_initial(x, y, z, t, nthreads=cw.max_threads)
+        cw.step(x, y, z, c, 2e-4, 6, t, U, nthreads=cw.max_threads)
+        assert np.array_equal(gc, c) and np.array_equal(got[:, 0], x) and np.array_equal(got[:, 1], y) and np.array_equal(got[:, 2], z)
+        if how == "last_cell_z":
+            assert (np.abs(z - xyz[:, 2]) > 0).any()             # somebody did move in z
+    ctx.use_own_stream()
+    ctx.set_velocity(setup["pitz"]["U_analytic"])
+
+
 def test_initial_locate_matches_bruteforce(setup):
     pz, ctx, cw, t = setup["pz"], setup["ctx"], setup["cw"], setup["tables"]
     n = 20000
