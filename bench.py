@@ -119,9 +119,23 @@ def parse(argv=None):
     return a
 
 
-def cpu_baseline(mesh, centres, U, seconds):
-    """The reference's own functions (oracle/_ref, kind "reference") -- or the C restatement of the same
-    algorithm (kind "port") -- timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(mesh, centres, U, seconds, batch_cycles=50):
+    """The reference's own functions (oracle/_ref, kind "reference") -- or the C restatement of the same algorithm (kind
+    "port") -- timed on this box's host cores on a bounded sample of the same workload, IN THE TIMED REGION'S REGIME: 2e5
+    particles seeded over the fluid domain take `batch_cycles` cycles (5 cm of travel at most, like the bench's warm-up + timed
+    steps) and are then put back where they started -- not thousands of cycles into the outlet wall, as until round 4.  All
+    threads the container may use, then one thread (a sixth of the time budget).  Plus the probe for an OpenFOAM installation
+    (north_star's kinematicCloud baseline): tools/openfoam_baseline.py."""
     from oracle import oracle as O
     from oracle.tetmesh import poly_to_tets
     from cudaparticlesfoam_amd.cases import pitzdaily as pz
@@ -139,24 +153,47 @@ def cpu_baseline(mesh, centres, U, seconds):
     cell = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
     xyz = xyz[cell >= 0][:n]; cell = cell[cell >= 0][:n]
     n = xyz.shape[0]
-    P = np.zeros((n, 4)); P[:, :3] = xyz; P[:, 3] = 1
-    ids = (cell * 12).astype(np.int32)
-    lib.bary_query(P, ids, m, lib.max_threads)
+    P0 = np.zeros((n, 4)); P0[:, :3] = xyz; P0[:, 3] = 1
+    ids0 = (cell * 12).astype(np.int32)
+    lib.bary_query(P0, ids0, m, lib.max_threads)
     vels = np.zeros((n, 4)); disps = np.zeros((n, 4))
+
+    def timed(threads, budget):
+        """batches of `batch_cycles` cycles from the seeded state until the budget is used; the resets are outside the clock"""
+        done, el = 0, 0.0
+        while el < budget and done < 200000:
+            P, ids = P0.copy(), ids0.copy()
+            vels[:] = 0; disps[:] = 0
+            t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, batch_cycles, m, threads); el += time.perf_counter() - t0
+            done += batch_cycles
+        return n * done / el / 1e6, done, el
+
     # the container may own only a slice of the box's hardware threads: pick the team size that is fastest
     best = None
     th = lib.hw_threads
     while th >= 1:
+        P, ids = P0.copy(), ids0.copy()
         t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, 2, m, th); cal = (time.perf_counter() - t0) / 2
         if best is None or cal < best[1]:
             best = (th, cal)
         th //= 2
-    th, cal = best
-    cycles = int(max(3, min(50000, seconds / max(cal, 1e-6))))
-    t0 = time.perf_counter(); lib.cycles(P, ids, vels, disps, 1e-4, cycles, m, th); el = time.perf_counter() - t0
-    return dict(value=round(n * cycles / el / 1e6, 3), unit="Mparticle-steps/s", cores=int(th), kind=kind,
-                sample="%d particles x %d cycles, pitzDaily 146700-tet decomposition, uniform U, OpenMP over "
-                       "particles, %.1f s" % (n, cycles, el))
+    th = best[0]
+    rate, cycles, el = timed(th, seconds)
+    rate1, cycles1, el1 = timed(1, max(1.0, seconds / 6.0))
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import openfoam_baseline as ofb
+        openfoam = ofb.probe()
+        if openfoam["available"]:
+            openfoam = ofb.run(mesh, U, xyz[:20000], steps=batch_cycles)
+    except Exception as e:                                      # noqa: BLE001
+        openfoam = {"available": False, "error": repr(e)[:200]}
+    return dict(value=round(rate, 3), unit="Mparticle-steps/s", cores=int(th), kind=kind, cpu_model=cpu_model(),
+                hw_threads=int(lib.hw_threads), one_thread=round(rate1, 3),
+                sample="%d particles seeded over the fluid domain x %d cycles in batches of %d from the seeded state (the timed "
+                       "region's regime), pitzDaily 146700-tet decomposition, uniform U, OpenMP over particles, %.1f s; one thread: "
+                       "%d cycles, %.1f s" % (n, cycles, batch_cycles, el, cycles1, el1),
+                openfoam_kinematicCloud=openfoam)
 
 
 def seed_in_fluid(ctx, torch, n, box, seed, device, cell_range=None, chunk=20_000_000):
