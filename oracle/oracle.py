@@ -246,6 +246,7 @@ class CellWalk:
         L.cw_step.argtypes = [_dp, _dp, _dp, _ip, C.c_void_p, C.c_int, C.c_double, C.c_int, _ip, _dp, _ip, _ip, _ip, _dp,
                               C.c_int, _lp, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32]
         L.cw_locate_initial.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_int, _ip, _dp, C.c_int]
+        L.cw_step_count.argtypes = [_dp, _dp, _dp, _ip, C.c_int, C.c_double, _ip, _dp, _ip, _ip, _ip, _dp, C.c_int, _ip, _ip]
         L.cw_philox4x32_10.argtypes = [_up, _up, _up]
         L.cw_philox4x32.argtypes = [_up, _up, C.c_int, _up]
         L.cw_normal3.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _dp]
@@ -283,6 +284,14 @@ class CellWalk:
         self.lib.cw_step(x, y, z, cell, vp, x.shape[0], dt, cycles, t.cell_off, t.planes, t.nbr, t.group_off, t.group_nbr,
                          U, nthreads, stats, D, gp, step0, seed)
         return stats
+
+    def step_count(self, x, y, z, cell, dt, t: CellTables, U, nthreads=1):
+        """One cycle (D = 0) in place; returns per-particle (cells visited, wall reflections)."""
+        n = x.shape[0]
+        visits = np.zeros(n, np.int32); refl = np.zeros(n, np.int32)
+        self.lib.cw_step_count(x, y, z, cell, n, dt, t.cell_off, t.planes, t.nbr, t.group_off, t.group_nbr, _c(U, np.float64),
+                               nthreads, visits, refl)
+        return visits, refl
 
     def locate_initial(self, x, y, z, t: CellTables, nthreads=1):
         cell = np.empty(x.shape[0], np.int32)
