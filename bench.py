@@ -258,7 +258,8 @@ def rank_watchdog(args, rank, world):
                               "n_gpus": world}), flush=True)
         print("[bench rank %d] watchdog expired in stage %s" % (rank, _STAGE), file=sys.stderr, flush=True)
         os._exit(124)
-    t = threading.Timer(args.launch_timeout, expire)
+    # (rank 0 first: it owns the error line, and a launcher that sees another rank die may take rank 0 down before it has spoken)
+    t = threading.Timer(args.launch_timeout + (0.0 if rank == 0 else 5.0), expire)
     t.daemon = True
     t.start()
     return t
@@ -729,6 +730,7 @@ def run(args, M):
             # only init -> first re-cut -> one all-to-all-v, with per-stage timings: a failing scaling run costs seconds and
             # names the collective (the stage trail on stderr says how far it got)
             total = cloud.global_count()
+            cloud.close()
             M.finish()
             stage("done")
             return {"dry_collectives": dry, "n_gpus": world, "particles_total": total, "rccl_ranks": world} if rank == 0 else None
@@ -866,6 +868,7 @@ def run(args, M):
             except Exception as e:          # the checker being absent must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mparticle-steps/s", "cores": 0, "kind": "port",
                                        "sample": "unavailable: %r" % (e,)}
+    cloud.close()                       # (the shard borrows the context and the communicator M.finish() destroys)
     M.finish()
     stage("done")
     return out

@@ -44,6 +44,8 @@ class Context:
         L.check(self.lib, self.h, st)
 
     def close(self):
+        for sh in list(getattr(self, "_shards", [])):        # shards made on this context (parallel.ShardedCloud) borrow it
+            sh.close()
         if getattr(self, "h", None):
             self.lib.cpf_destroy(self.h)
             self.h = None

@@ -80,7 +80,7 @@ class ShardCore {
     int depthNext = 2;                    // overlap depth of the NEXT hand-off when derived ("overlap_steps" -1): the maximum of
                                           // what the ranks asked for in the last table, so that every rank completes a hand-off at
                                           // the same step (an overflow re-split "at the current step" is then current everywhere)
-    bool haveCost = false;
+    bool haveCost = false, costWaited = false;
     double costPerParticle = 1.0;
     double hostWorkMs = 0.5;              // running mean of the host's own work per hand-off, without the wait
 
@@ -531,7 +531,10 @@ class ShardCore {
     int measuredCost(double* out) {
         const bool first = !haveCost;
         int64_t launches = 0; double ms = 0.0;
-        CPF_SH(dev.timingRead(first, &launches, &ms));
+        // (the one wait: a re-cut before any step has run finds nothing to wait for and must not make the next one wait again)
+        const bool wait = first && !costWaited && stepIndex > 0;
+        if (wait) costWaited = true;
+        CPF_SH(dev.timingRead(wait, &launches, &ms));
         kernelMs += ms; kernelLaunches += launches;
         if (launches > 0 && n > 0) {
             const double c = std::min(4.0, std::max(0.25, ms / (double)launches / (double)n / kCostUnitMs));

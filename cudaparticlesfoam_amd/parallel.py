@@ -88,8 +88,11 @@ class Communicator:
         if st != L.CPF_OK:
             raise L.CpfError(st, (self.lib.cpf_comm_last_error() or b"").decode())
         self.ptr, self.rank, self.world = out, int(rank), int(world)
+        self._shards = []               # shards that borrow this communicator: destroyed first
 
     def close(self):
+        for sh in list(getattr(self, "_shards", [])):
+            sh.close()
         if getattr(self, "ptr", None):
             self.lib.cpf_comm_destroy(self.ptr)
             self.ptr = None
@@ -118,6 +121,10 @@ class ShardedCloud:
         if st != L.CPF_OK:
             raise L.CpfError(st, (self.lib.cpf_shard_last_error(None) or b"").decode())
         self.h = h
+        # the shard borrows the context and the communicator (include/cpf.h): whoever closes one of them first closes the shard first
+        for owner in (ctx, comm):
+            if owner is not None and hasattr(owner, "__dict__"):
+                owner.__dict__.setdefault("_shards", []).append(self)
         self._opts = dict(exchange_interval=0, rebalance_interval=0, overlap_steps=0, sort_interval=0, balance_by_time=0,
                           force_collectives=0, profile_comm=0, send_fraction=0.25)
         self.send_fraction = send_fraction
@@ -132,6 +139,10 @@ class ShardedCloud:
         if getattr(self, "h", None):
             self.lib.cpf_shard_destroy(self.h)
             self.h = None
+            for owner in (self.ctx, self.comm):
+                lst = getattr(owner, "_shards", None)
+                if lst is not None and self in lst:
+                    lst.remove(self)
 
     def __del__(self):
         try:

@@ -53,6 +53,8 @@ class HostCase:
                                                           p(gnbr), int(goff[-1]), p(U), self.n_cells, float(fake_ms_per_particle)))
 
     def close(self):
+        for sh in list(getattr(self, "_shards", [])):
+            sh.close()
         if self.h:
             self.lib.cpf_host_case_destroy(self.h)
             self.h = None

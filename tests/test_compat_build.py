@@ -41,8 +41,9 @@ def test_mock_solver_fails_loudly_without_gpu(tmp_path, pitz):
 def test_reference_io_block_compiles_against_the_shims(tmp_path):
     """A host that kept the reference's per-cycle I/O block verbatim (src/advect.H:163-175: addToTrajectories,
     writeParticles2VTU, saveTrajectories, writeStreamline2VTK behind saveStreamlinetoFile) and all three cudaAdvect mode
-    strings (cuda/particles.cu:417-445) compiles against compat/cuda/common.h with plain g++; the three trajectory
-    functions -- dead in the reference, src/initCuda.H:68 -- throw advect::Error when called."""
+    strings (cuda/particles.cu:417-445) compiles against compat/cuda/common.h with plain g++; the two trajectory writers --
+    dead in the reference, src/initCuda.H:68 -- run on the host's own vectors (cpf_traj_*_arrays): trajectories with fewer than
+    two points are left out, OBJ vertex numbers are 1-based per file."""
     src = tmp_path / "io_block.cpp"
     src.write_text(r'''
 #include "cuda/common.h"
@@ -64,11 +65,13 @@ int main() {
     }
     void (*advectFn)(Particle*, int*, vec4d*, vec4d*, double, int, vec4i*, vec3d*, vec3d*, std::string) = &cudaAdvect;
     (void)advectFn; (void)d_particle_vels; (void)d_disp; (void)d_particles_tetIDs; (void)d_particles_ConvextetIDs;
-    int thrown = 0;
-    try { addToTrajectories(d_particles, 0, trajectories); } catch (const Error& e) { thrown += std::strstr(e.what(), "src/initCuda.H:68") != nullptr; }
-    try { saveTrajectories("t.obj", trajectories); } catch (const Error&) { ++thrown; }
-    try { writeStreamline2VTK("t.vtk", trajectories); } catch (const Error&) { ++thrown; }
-    return thrown == 3 ? 0 : 1;
+    trajectories.resize(3);
+    trajectories[0] = {vec3f{0.f, 0.f, 0.f}, vec3f{1.f, 0.5f, 0.25f}, vec3f{2.f, 1.f, 0.5f}};
+    trajectories[1] = {vec3f{9.f, 9.f, 9.f}};                    // one sample: in neither file
+    trajectories[2] = {vec3f{-1.f, 0.f, 1e-7f}, vec3f{-2.f, 0.f, 123456.789f}};
+    saveTrajectories("t.obj", trajectories);
+    writeStreamline2VTK("t.vtk", trajectories);
+    return 0;
 }
 ''')
     exe = tmp_path / "io_block"
@@ -76,4 +79,8 @@ int main() {
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), str(src),
                         "-L" + lib, "-lcudaParticleAdvection", "-Wl,-rpath," + lib, "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert subprocess.run([str(exe)]).returncode == 0
+    assert subprocess.run([str(exe)], cwd=str(tmp_path)).returncode == 0
+    obj = open(tmp_path / "t.obj").read().splitlines()
+    assert obj == ["v 0 0 0", "v 1 0.5 0.25", "v 2 1 0.5", "l 1 2", "l 2 3", "v -1 0 1e-07", "v -2 0 123457", "l 4 5"]
+    vtk = open(tmp_path / "t.vtk").read()
+    assert "POINTS 5 float" in vtk and "LINES 2 7" in vtk and "\n3 0 1 2\n2 3 4\n" in vtk and "StreamlineID 1 2 int" in vtk
