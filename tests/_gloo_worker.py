@@ -23,6 +23,7 @@ def main():
     slow_rank0 = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # > 0: balance by "measured" time, rank 0 that much slower
     u_step = int(sys.argv[7]) if len(sys.argv) > 7 else 0                # > 0: the velocity field changes after that many steps
     send_fraction = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0    # small: the send buffer overflows and must grow
+    slices = int(sys.argv[9]) if len(sys.argv) > 9 else 0               # 1: the new field arrives as per-rank slices; + the collective gather
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -53,7 +54,14 @@ def main():
         cloud.enable_time_balancing()
     if u_step:
         cloud.step(0.2, u_step)
-        cloud.set_velocity(U[::-1].copy() * 0.5)          # a transient solver's new field, mid hand-off window
+        U2 = U[::-1].copy() * 0.5                          # a transient solver's new field, mid hand-off window
+        if slices:
+            # every rank hands over ITS slice only (the cells of its piece of a decomposed mesh, here an uneven cut); the
+            # slices are all-gathered through the communicator's all-to-all-v (cpf_shard_set_velocity_slice)
+            cut = [0] + [int(mesh.n_cells * (r + 1) ** 2 / world ** 2) for r in range(world)]
+            cloud.set_velocity_slice(U2[cut[rank]:cut[rank + 1]])
+        else:
+            cloud.set_velocity(U2)
         cloud.step(0.2, 30 - u_step)
     else:
         cloud.step(0.2, 30)
@@ -63,6 +71,9 @@ def main():
     g, x, y, z, c = cloud.gather_to_numpy()
     cell_lo = cloud.cell_lo
     owned_ok2 = bool(((c >= cell_lo[rank]) & (c < cell_lo[rank + 1]) | (c < 0)).all())
+    whole = cloud.gather(0, want_vel=False) if slices else (None, None, None)     # collective: the cloud in particle-id order on rank 0
+    if slices and rank == 0:
+        np.savez(out_path + ".whole.npz", xyzw=whole[0], cell=whole[1])
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
              n_local=cloud.n, grown=cloud.grown, send_grown=cloud.send_grown, cell_lo=np.asarray(cell_lo))

@@ -99,6 +99,23 @@ def test_velocity_update_inside_a_handoff_window(tmp_path, oracle_libs):
     assert seen.all()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_velocity_slices_and_the_collective_gather(world, tmp_path, oracle_libs):
+    """cpf_shard_set_velocity_slice: every rank hands over only the cells of its own (uneven) piece and the ranks all-gather the
+    slices among themselves (an all-to-all-v with one shared source range) -- the same particles as with the whole field on every
+    rank; and cpf_shard_gather brings the whole cloud to rank 0 in particle-id order."""
+    out = str(tmp_path / "slices")
+    _run_workers(world, out, 0, 5, 0, 4, 0, 13, 1.0, 1)
+    x, y, z, c = _single_process_answer(oracle_libs, u_step=13)
+    w = np.load(out + ".whole.npz")
+    assert np.array_equal(w["xyzw"][:, 0], x) and np.array_equal(w["xyzw"][:, 1], y) and np.array_equal(w["xyzw"][:, 2], z)
+    assert np.array_equal(w["cell"], c) and (w["xyzw"][:, 3] == 1).all()
+    for r in range(world):
+        d = np.load(out + ".rank%d.npz" % r)
+        g = d["gid"]
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["cell"], c[g])
+
+
 def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_libs):
     """Re-cut by measured cost: rank 0 pretends to be 3x slower per particle, so the cuts must converge towards
     3*n0 == n1 (n0 -> N/4) instead of n0 == n1; the particle results stay those of one process."""
