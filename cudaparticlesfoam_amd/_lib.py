@@ -86,6 +86,7 @@ SHARD_SIGNATURES = {
     "cpf_shard_cell_ranges": (_int, [_shard, _vp]),
     "cpf_shard_gather": (_int, [_shard, _int, _vp, _vp, _vp]),
     "cpf_shard_write_vtu": (_int, [_shard, _int, C.c_char_p, C.POINTER(_dbl)]),
+    "cpf_shard_write_vtu_wait": (_int, [_shard]),
     "cpf_shard_get_stats": (_int, [_shard, C.POINTER(ShardStats)]),
 }
 

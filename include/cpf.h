@@ -441,8 +441,11 @@ int cpf_shard_cell_ranges(cpf_shard* s, int32_t* cellLo /* [nRanks + 1] */);
 /* COLLECTIVE: the whole cloud in particle-id order on rank `root` (ids must be 0 .. nGlobal-1, as seeded):
  * xyzw [nGlobal][4], cell [nGlobal], vel [nGlobal][4] as cpf_get_particles; other ranks pass NULLs. */
 int cpf_shard_gather(cpf_shard* s, int root, double* xyzw, int32_t* cell, double* vel);
-/* COLLECTIVE: cpf_shard_gather + the frame writer of cpf_write_vtu on `root` (option "vtu_binary" of the context). */
+/* COLLECTIVE: cpf_shard_gather + the frame writer of cpf_write_vtu_async on `root` (option "vtu_binary" of the context): the
+ * cloud is gathered now, totalKE is returned at once, formatting and file I/O run on a worker thread of the root; one frame is
+ * in flight, the next call, cpf_shard_write_vtu_wait or cpf_shard_destroy waits for it and reports its failure. */
 int cpf_shard_write_vtu(cpf_shard* s, int root, const char* path, double* totalKE);
+int cpf_shard_write_vtu_wait(cpf_shard* s);
 typedef struct cpf_shard_stats {
     int64_t n, capacity, stepIndex;
     int64_t particleSteps, handedOff, exchanges, rebalances, grown, sendGrown;
