@@ -428,15 +428,20 @@ class GpuMachine:
     def seed_in_fluid(self, n, box, seed, cell_range=None):
         return seed_in_fluid(self.ctx, self.torch, n, box, seed, self.device, cell_range)
 
-    def spinup(self, scratch, dt, ms):
-        """Device spin-up (see --spinup-ms) on `scratch` = (x, y, z, cell) copies of the rank's seeded particles: the cloud
-        itself is untouched, the W warm-up steps and the K timed steps are the first steps it ever takes."""
+    def spinup(self, cloud, dt, ms):
+        """Device spin-up (see --spinup-ms) on a SCRATCH copy of the rank's shard as it stands (sorted): the cloud itself is
+        untouched, the W warm-up steps and the K timed steps are the first steps it ever takes."""
         torch, ctx = self.torch, self.ctx
-        if ms <= 0 or scratch is None or scratch[0].numel() <= 0:
+        a = cloud.arrays()                               # device addresses of the shard's arrays (cpf_shard_arrays)
+        ns = int(a["n"])
+        if ms <= 0 or ns <= 0:
             return None
-        sp = lambda a: a.data_ptr()   # noqa: E731
-        sx, sy, sz, sc = scratch
-        ns = int(sx.numel())
+        sp = lambda t: t.data_ptr()   # noqa: E731
+        sx, sy, sz = (torch.empty(ns, dtype=torch.float64, device=self.device) for _ in range(3))
+        sc = torch.empty(ns, dtype=torch.int32, device=self.device)
+        for dst, key, width in ((sx, "x", 8), (sy, "y", 8), (sz, "z", 8), (sc, "cell", 4)):
+            ctx._ck(ctx.lib.cpf_copy_dev(ctx.h, dst.data_ptr(), a[key], ns * width))
+        torch.cuda.synchronize()
         # (the statistics-on instantiation, like the warm-up steps: a profiler's per-kernel average of the headline
         # instantiation then covers the timed launches and nothing else)
         ctx.set_option("stats", 1)
@@ -714,7 +719,6 @@ def run(args, M):
         cloud.enable_time_balancing()
     cloud.sort_interval = 0 if args.no_sort else args.sort_interval
     cloud.set_particles(x, y, z, c, None, first_gid=rank * n_local)
-    scratch = (x, y, z, c) if args.spinup_ms > 0 else None          # the spin-up steps these copies, never the cloud
     del x, y, z, c
     dry = None
     if dist_on:
@@ -743,8 +747,7 @@ def run(args, M):
             dist.barrier()                          # (control plane: gloo)
 
     dt = 1e-4
-    spinup = M.spinup(scratch, dt, args.spinup_ms)
-    del scratch
+    spinup = M.spinup(cloud, dt, args.spinup_ms)
     ctx.set_option("stats", 1)
     counters0 = ctx.counters()
     stage("warmup")

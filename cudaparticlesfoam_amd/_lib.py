@@ -154,6 +154,7 @@ SIGNATURES = {
     "cpf_dev_memset": (_int, [_ctx, _vp, _int, C.c_size_t]),
     "cpf_copy_to_device": (_int, [_ctx, _vp, _vp, C.c_size_t]),
     "cpf_copy_to_host": (_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "cpf_copy_dev": (_int, [_ctx, _vp, _vp, C.c_size_t]),
     "cpf_stage_seed_box": (_int, [_ctx, _vp, _i64, _vp, _vp, _int]),
     "cpf_stage_locate_initial": (_int, [_ctx, _vp, _vp, _i64]),
     "cpf_stage_count_outside": (_int, [_ctx, _vp, _i64, C.POINTER(_i64)]),

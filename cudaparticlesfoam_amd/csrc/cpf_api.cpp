@@ -1069,6 +1069,13 @@ int cpf_copy_to_host(cpf_context* ctx, void* dst, const void* src, size_t bytes)
     return CPF_OK;
 }
 
+int cpf_copy_dev(cpf_context* ctx, void* dst, const void* src, size_t bytes) {
+    CPF_REQUIRE(ctx, ctx && ((dst && src) || bytes == 0), CPF_ERR_ARG, "null argument");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) CPF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CPF_OK;
+}
+
 // ---- stage-by-stage entry points (reference layouts) --------------------------------------------
 #define CPF_STAGE_PRE(name, needU)                                                                      \
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");                                                 \

@@ -214,10 +214,11 @@ class ShardedCloud:
             return C.c_void_p(t.data_ptr())
         return t.ctypes.data_as(C.c_void_p)
 
-    def set_particles(self, x, y, z, cell, gid, first_gid: int = 0):
+    def set_particles(self, x, y, z, cell, gid, first_gid: int = 0, n: Optional[int] = None):
         """x, y, z, cell (None: located here), gid (None: first_gid, first_gid + 1, ...): arrays in DEVICE memory (torch
-        tensors or raw addresses) of equal length; they are copied."""
-        n = int(x.numel()) if hasattr(x, "numel") else int(np.asarray(x).size)
+        tensors, or raw addresses with ``n``) of equal length; they are copied."""
+        if n is None:
+            n = int(x.numel()) if hasattr(x, "numel") else int(np.asarray(x).size)
         self._ck(self.lib.cpf_shard_set_particles_dev(self.h, self._p(x), self._p(y), self._p(z), self._p(cell), self._p(gid), n,
                                                       int(first_gid)))
 

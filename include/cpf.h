@@ -473,6 +473,7 @@ int cpf_dev_free(cpf_context* ctx, void* ptr);
 int cpf_dev_memset(cpf_context* ctx, void* ptr, int value, size_t bytes);
 int cpf_copy_to_device(cpf_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int cpf_copy_to_host(cpf_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int cpf_copy_dev(cpf_context* ctx, void* dst_dev, const void* src_dev, size_t bytes);    /* device to device, asynchronous on the context's stream */
 /* cudaInitParticles (cuda/particles.cu:100-108) */
 int cpf_stage_seed_box(cpf_context* ctx, double* particles, int64_t n, const double lower[3], const double upper[3],
                        int order);

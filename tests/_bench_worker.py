@@ -57,7 +57,7 @@ class CpuMachine:
         return (torch.from_numpy(p[:, 0].copy()), torch.from_numpy(p[:, 1].copy()), torch.from_numpy(p[:, 2].copy()),
                 torch.from_numpy(c.astype(np.int32)))
 
-    def spinup(self, scratch, dt, ms):
+    def spinup(self, cloud, dt, ms):
         return None
 
     def extras(self, cloud, dt, args, box):
