@@ -607,6 +607,26 @@ class GpuMachine:
         r.update({"D": Db, "sort_interval": interval, "sorts_inside": args.brownian_steady_steps // interval,
                   "kernel": ctx.step_kernel_name(Db, 0), "particles": cl.n,
                   "note": "frac = 64 B x particles / ms_per_step (sorts included); kernel_frac = the step kernel alone"})
+        # the launch the replacement advect.H issues between two frames of either tutorial (saveInterval 10: the cycles between
+        # two output points fused into one launch), on a second fresh cloud in the same state as the one above started from
+        from cudaparticlesfoam_amd import _lib as L
+        del cl
+        cl = self._fresh_cloud(cloud.n, box, 2025, sort_interval=0)
+        cl.step(dt, 10, D=Db)
+        cl.sort()
+        a = cl.arrays()
+        K, reps = 8, 6
+        ctx.step_dev(a["x"], a["y"], a["z"], a["cell"], a["gid"], None, a["n"], dt, Db, 10, K, L.STEP_FUSE_CYCLES)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for q in range(reps):
+            ctx.step_dev(a["x"], a["y"], a["z"], a["cell"], a["gid"], None, a["n"], dt, Db, 10 + K * (q + 1), K, L.STEP_FUSE_CYCLES)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - tb) / (K * reps) * 1e3
+        r["fused_8_cycles_per_launch"] = {"ms_per_cycle": round(tb, 4), "Mparticle_steps_per_s": round(a["n"] / tb / 1e3, 1),
+                                          "frac": round((ALGO_BYTES_PER_PARTICLE_STEP + 8) * a["n"] / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "note": "what the fragments launch between two frames; the fraction is taken on the per-cycle "
+                                                  "bytes of UNFUSED launches (64 B): a fused launch loads and stores once per 8 cycles"}
         del cl
         return r
 
