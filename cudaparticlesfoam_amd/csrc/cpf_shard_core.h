@@ -288,12 +288,12 @@ class ShardCore {
             CPF_SH(dev.locate(x, y, z, cell, count));
         }
         n = count;
-        if (nOutside) {
+        {   // (the count is a collective: every rank takes part whether or not it asked for the answer)
             int64_t mine = 0;
             CPF_SH(dev.countNegative(cell, n, &mine));
             double tot = (double)mine;
             CPF_SH(allReduceScalar(&tot));
-            *nOutside = (int64_t)tot;
+            if (nOutside) *nOutside = (int64_t)tot;
         }
         if (distOn()) {
             CPF_SH(recut(false));
