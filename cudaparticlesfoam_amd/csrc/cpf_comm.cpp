@@ -111,13 +111,21 @@ int rcclAllToAllV(void* self, const void* send, const int64_t* sendOff, const in
                   const int64_t* recvOff, const int64_t* recvBytes, void* stream) {
     RcclComm* c = (RcclComm*)self;
     CPF_NCCL(c, rccl().GroupStart());
-    for (int r = 0; r < c->n; ++r) {
-        if (sendBytes[r] > 0)
-            CPF_NCCL(c, rccl().Send((const char*)send + sendOff[r], (size_t)sendBytes[r], ncclInt8, r, c->comm, (hipStream_t)stream));
-        if (recvBytes[r] > 0)
-            CPF_NCCL(c, rccl().Recv((char*)recv + recvOff[r], (size_t)recvBytes[r], ncclInt8, r, c->comm, (hipStream_t)stream));
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
+    for (int r = 0; r < c->n && bad == ncclSuccess; ++r) {
+        if (sendBytes[r] > 0) {
+            bad = rccl().Send((const char*)send + sendOff[r], (size_t)sendBytes[r], ncclInt8, r, c->comm, (hipStream_t)stream);
+            what = "ncclSend";
+        }
+        if (bad == ncclSuccess && recvBytes[r] > 0) {
+            bad = rccl().Recv((char*)recv + recvOff[r], (size_t)recvBytes[r], ncclInt8, r, c->comm, (hipStream_t)stream);
+            what = "ncclRecv";
+        }
     }
-    CPF_NCCL(c, rccl().GroupEnd());
+    const ncclResult_t end = rccl().GroupEnd();               // (always: a group left open would swallow every later call)
+    if (bad != ncclSuccess) { c->err = std::string(what) + ": " + rccl().GetErrorString(bad); return CPF_ERR_HIP; }
+    if (end != ncclSuccess) { c->err = std::string("ncclGroupEnd: ") + rccl().GetErrorString(end); return CPF_ERR_HIP; }
     return CPF_OK;
 }
 void rcclDestroy(void* self) {
