@@ -20,8 +20,8 @@ __global__ void k(const uint64_t* g, double* out, uint32_t step, uint32_t seed) 
 '''
 
 
-def asm(path, flags):
-    out = path + ".s"
+def asm(path, flags, tmp=tempfile.gettempdir()):
+    out = os.path.join(tmp, os.path.basename(path) + ".budget.s")          # never next to the sources
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                     "-I" + CS, "-S", "--cuda-device-only", path, "-o", out] + flags, check=True, stderr=subprocess.DEVNULL)
     return open(out).read()
