@@ -50,49 +50,52 @@ __global__ __launch_bounds__(kBlock) void count_leavers_kernel(const int32_t* __
         }
     }
     __syncthreads();
-    if (threadIdx.x < nRanks) blockCnt[(int64_t)blockIdx.x * nRanks + threadIdx.x] = sCnt[threadIdx.x];
+    if (threadIdx.x < nRanks) blockCnt[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = sCnt[threadIdx.x];     // [rank][block]
 }
 
-// single block: exclusive scan of blockCnt over blocks per destination; totals, bases, nStay.
-// Leavers that do not fit into the send buffer abort the split HERE, on the device: *nStay = -1, holeFill[2] = 1, and
-// the three kernels after this one touch nothing -- the shard stays exactly as it was (the caller keeps stepping it),
-// counts[] say how large the buffer has to be, and the host can repeat the split (parallel.py, _finish_exchange).
-__global__ __launch_bounds__(kBlock) void scan_leavers_kernel(int32_t* __restrict__ blockCnt, int nBlocks, int nRanks,
-                                                              int64_t n, int64_t sendCapacity, int64_t* __restrict__ counts,
-                                                              int64_t* __restrict__ destBase,
-                                                              int64_t* __restrict__ nStay,
-                                                              unsigned long long* __restrict__ holeFill) {
+// Exclusive scan of blockCnt[rank][block] over the blocks, one workgroup per destination rank (the rows are contiguous: every
+// thread sums a run of blocks, the runs' sums are scanned through LDS, every thread rewrites its run); rowTotal[rank] = the
+// destination's leavers.  (Until round 5 ONE workgroup did all ranks in turn over a block-major table, thread 0 scanning 256
+// partial sums per rank: 114 us of the split's 190 at 1.25e7 particles and 8 ranks.)
+__global__ __launch_bounds__(kBlock) void scan_leavers_kernel(int32_t* __restrict__ blockCnt, int nBlocks, long long* __restrict__ rowTotal) {
     __shared__ long long sPart[kBlock];
-    __shared__ long long sTot[kMaxRanks];
-    for (int r = 0; r < nRanks; ++r) {
-        // each thread owns a contiguous chunk of blocks
-        const int per = (nBlocks + kBlock - 1) / kBlock;
-        const int b0 = threadIdx.x * per, b1 = min(nBlocks, b0 + per);
-        long long s = 0;
-        for (int b = b0; b < b1; ++b) s += blockCnt[(int64_t)b * nRanks + r];
-        sPart[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long run = 0;
-            for (int t = 0; t < kBlock; ++t) { const long long v = sPart[t]; sPart[t] = run; run += v; }
-            sTot[r] = run;
-        }
-        __syncthreads();
-        long long run = sPart[threadIdx.x];
-        for (int b = b0; b < b1; ++b) {
-            const int v = blockCnt[(int64_t)b * nRanks + r];
-            blockCnt[(int64_t)b * nRanks + r] = (int32_t)run;
-            run += v;
-        }
-        __syncthreads();
+    __shared__ long long sWaveTot[kBlock / 64];
+    int32_t* const row = blockCnt + (int64_t)blockIdx.x * nBlocks;
+    const int per = (nBlocks + kBlock - 1) / kBlock;
+    const int b0 = min(nBlocks, (int)threadIdx.x * per), b1 = min(nBlocks, b0 + per);
+    long long s = 0;
+    for (int b = b0; b < b1; ++b) s += row[b];
+    // inclusive scan of the 256 run sums: inside each wave by shuffles, across the four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int r = 0; r < nRanks; ++r) { counts[r] = sTot[r]; destBase[r] = run; run += sTot[r]; }
-        const bool fits = run <= sendCapacity;
-        *nStay = fits ? n - run : -1;
-        holeFill[0] = 0; holeFill[1] = 0; holeFill[2] = fits ? 0ull : 1ull;
-    }
+    if (lane == 63) sWaveTot[wave] = incl;
+    __syncthreads();
+    long long base = 0;
+    for (int w = 0; w < wave; ++w) base += sWaveTot[w];
+    long long run = base + incl - s;
+    for (int b = b0; b < b1; ++b) { const int v = row[b]; row[b] = (int32_t)run; run += v; }
+    if (threadIdx.x == kBlock - 1) rowTotal[blockIdx.x] = base + incl;
+    (void)sPart;
+}
+
+// totals -> counts, first record of every destination, nStay.  Leavers that do not fit into the send buffer abort the split HERE,
+// on the device: *nStay = -1, holeFill[2] = 1, and the three kernels after this one touch nothing -- the shard stays exactly as it
+// was (the caller keeps stepping it), counts[] say how large the buffer has to be, and the host can repeat the split
+// (csrc/cpf_shard_core.h, finishExchange).
+__global__ void finish_scan_kernel(const long long* __restrict__ rowTotal, int nRanks, int64_t n, int64_t sendCapacity,
+                                   int64_t* __restrict__ counts, int64_t* __restrict__ destBase, int64_t* __restrict__ nStay,
+                                   unsigned long long* __restrict__ holeFill) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long run = 0;
+    for (int r = 0; r < nRanks; ++r) { counts[r] = rowTotal[r]; destBase[r] = run; run += rowTotal[r]; }
+    const bool fits = run <= sendCapacity;
+    *nStay = fits ? n - run : -1;
+    holeFill[0] = 0; holeFill[1] = 0; holeFill[2] = fits ? 0ull : 1ull;
 }
 
 __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void write_leavers_kernel(
         if (d >= 0) {
             int off = sRun[d] + myPrefix;
             for (int w = 0; w < wave; ++w) off += sWave[w][d];
-            const int64_t slot = destBase[d] + blockOff[(int64_t)blockIdx.x * nRanks + d] + off;
+            const int64_t slot = destBase[d] + blockOff[(int64_t)d * gridDim.x + blockIdx.x] + off;
             double* rec = sendbuf + slot * CPF_HANDOFF_DOUBLES;   // slot < sendCapacity: the scan kernel checked the total
             rec[0] = x[i]; rec[1] = y[i]; rec[2] = z[i];
             rec[3] = (double)c;                                  // exact: |c| < 2^31
@@ -373,8 +376,8 @@ hipError_t cell_ranges(hipStream_t st, const double* weights, int64_t nCells, in
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 size_t handoff_scratch_bytes(int64_t n, int nRanks) {
-    const int64_t nBlocks = (n + kTile - 1) / kTile;
-    return al256((size_t)nBlocks * nRanks * 4) + al256((size_t)kMaxRanks * 8) + al256(24) + 2 * al256((size_t)n * 4);
+    const int64_t nBlocks = std::max<int64_t>(1, (n + kTile - 1) / kTile);
+    return al256((size_t)nBlocks * nRanks * 4) + 2 * al256((size_t)kMaxRanks * 8) + al256(24) + 2 * al256((size_t)n * 4);
 }
 
 hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t* cell, int64_t* gid, int64_t n,
@@ -386,14 +389,15 @@ hipError_t pack_leavers(hipStream_t st, double* x, double* y, double* z, int32_t
     char* p = (char*)scratch;
     int32_t* blockCnt = (int32_t*)p; p += al256((size_t)std::max(nBlocks, 1) * nRanks * 4);
     int64_t* destBase = (int64_t*)p; p += al256((size_t)kMaxRanks * 8);
+    long long* rowTotal = (long long*)p; p += al256((size_t)kMaxRanks * 8);
     unsigned long long* holeFill = (unsigned long long*)p; p += al256(24);
     int32_t* holes = (int32_t*)p; p += al256((size_t)n * 4);
     int32_t* fillers = (int32_t*)p;
     if (nBlocks > 0)
         hipLaunchKernelGGL(count_leavers_kernel, dim3(nBlocks), dim3(kBlock), 0, st, cell, n, cellLo, nRanks, myRank,
                            blockCnt);
-    hipLaunchKernelGGL(scan_leavers_kernel, dim3(1), dim3(kBlock), 0, st, blockCnt, nBlocks, nRanks, n, sendCapacity, counts,
-                       destBase, nStay, holeFill);
+    hipLaunchKernelGGL(scan_leavers_kernel, dim3(nRanks), dim3(kBlock), 0, st, blockCnt, nBlocks, rowTotal);
+    hipLaunchKernelGGL(finish_scan_kernel, dim3(1), dim3(64), 0, st, rowTotal, nRanks, n, sendCapacity, counts, destBase, nStay, holeFill);
     if (nBlocks > 0) {
         hipLaunchKernelGGL(write_leavers_kernel, dim3(nBlocks), dim3(kBlock), 0, st, x, y, z, cell, gid, n, cellLo,
                            nRanks, myRank, blockCnt, destBase, nStay, sendbuf, sendCapacity, holes, fillers, holeFill);
