@@ -901,7 +901,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         return CPF_OK;
     }
     if (k == "sort_method") {
-        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "sort_method must be 0 (library radix sort) or 1 (hand-written)");
+        CPF_REQUIRE(ctx, value == 0 || value == 1 || value == 2, CPF_ERR_ARG, "sort_method must be 0 (library radix sort), 1 or 2 (hand-written: wide digits / tile reorder)");
         ctx->sortMethod = (int)value;
         return CPF_OK;
     }

@@ -1300,6 +1300,172 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "sort_method" 2: the same chunked counting sort with NARROW digits (<= 8 bits: as many passes as the library's) and the elements
+// of a 4096-element tile put in digit order in LDS before they leave, so that every bin receives one contiguous run per tile
+// (16 elements = two 64-byte runs on a random digit; method 1 writes 8 bytes per line there).  A workgroup of 4 waves owns a chunk
+// of whole tiles; inside a tile wave w owns elements [1024 w, 1024 (w + 1)) and ranks them in order against private counters
+// (stable without ordering the waves), one pass over [wave][bin] turns the counters into first positions, the tile is written
+// to LDS in digit order and copied out with the bins' running global positions.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRtThreads = 256, kRtWaves = 4, kRtItems = 16, kRtTile = kRtThreads * kRtItems, kRtMaxBits = 8, kRtMaxChunks = 1024;
+static RsPlan rt_plan(int64_t n, int endBit) {
+    RsPlan p{};
+    p.passes = (endBit + kRtMaxBits - 1) / kRtMaxBits;
+    const int d = (endBit + p.passes - 1) / p.passes;
+    for (int k = 0; k < p.passes; ++k) { p.shift[k] = k * d; p.bits[k] = std::min(d, endBit - k * d); }
+    int64_t chunk = (n + kRtMaxChunks - 1) / kRtMaxChunks;
+    chunk = std::max<int64_t>(kRtTile, (chunk + kRtTile - 1) / kRtTile * kRtTile);
+    p.chunk = chunk;
+    p.nChunks = (int)((n + chunk - 1) / chunk);
+    return p;
+}
+static size_t rt_scratch_bytes(int64_t n, int endBit) {
+    const RsPlan p = rt_plan(n, endBit);
+    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(24 * (size_t)n);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ idxIn,
+                                                                uint32_t* __restrict__ keysOut, int32_t* __restrict__ idxOut, int64_t n,
+                                                                int64_t chunk, int shift, const uint32_t* __restrict__ before,
+                                                                const uint32_t* __restrict__ totals) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t sKey[kRtTile];
+    __shared__ int32_t sIdx[kRtTile];
+    __shared__ unsigned sCnt[kRtWaves][BINS];          // per tile: the waves' digit counts, then their first positions in the tile
+    __shared__ unsigned sBinStart[BINS + 1];           // per tile: first position of a bin inside the tile
+    __shared__ unsigned sGlobal[BINS];                 // running: where the bin's next element of this chunk goes
+    __shared__ unsigned sScan[kRtThreads];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t mask = (uint32_t)BINS - 1u;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // bin starts of the whole array = exclusive scan of the totals, + what the chunks before this one hold
+    {
+        constexpr int PER = (BINS + kRtThreads - 1) / kRtThreads;
+        const int b0 = min(BINS, (int)threadIdx.x * PER), b1 = min(BINS, b0 + PER);
+        unsigned mine = 0;
+        for (int b = b0; b < b1; ++b) mine += totals[b];
+        sScan[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned run = 0; for (int t = 0; t < kRtThreads; ++t) { const unsigned v = sScan[t]; sScan[t] = run; run += v; } }
+        __syncthreads();
+        unsigned run = sScan[threadIdx.x];
+        const uint32_t* row = before + (int64_t)blockIdx.x * BINS;
+        for (int b = b0; b < b1; ++b) { sGlobal[b] = run + row[b]; run += totals[b]; }
+    }
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int64_t t0 = lo; t0 < hi; t0 += kRtTile) {
+        const int tileN = (int)min<int64_t>(kRtTile, hi - t0);
+        for (int b = lane; b < BINS; b += 64) sCnt[wave][b] = 0u;
+        __syncthreads();                                   // (also: the previous tile's copy-out has left sKey / sIdx / sBinStart)
+        // ---- load the wave's 1024 elements, rank them in order against the wave's counters
+        uint32_t k[kRtItems]; int32_t v[kRtItems]; unsigned rnk[kRtItems];
+        const int sub = wave * (kRtTile / kRtWaves);
+#pragma unroll
+        for (int s = 0; s < kRtItems; ++s) {
+            const int j = sub + s * 64 + lane;
+            const int64_t i = t0 + j;
+            k[s] = j < tileN ? keysIn[i] : 0xFFFFFFFFu;
+            v[s] = j < tileN ? (idxIn ? idxIn[i] : (int32_t)i) : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < kRtItems; ++s) {
+            const int j = sub + s * 64 + lane;
+            const bool live = j < tileN;
+            const uint32_t d = (k[s] >> shift) & mask;
+            unsigned long long same = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < BITS; ++b) {
+                const unsigned long long one = __ballot(((d >> b) & 1u) != 0u);
+                same &= ((d >> b) & 1u) ? one : ~one;
+            }
+            if (live) {
+                const unsigned first = sCnt[wave][d];           // (every lane of the group reads before its first lane writes)
+                rnk[s] = first + (unsigned)__popcll(same & lt);
+                if ((same & lt) == 0ull) sCnt[wave][d] = first + (unsigned)__popcll(same);
+            } else rnk[s] = 0;
+        }
+        __syncthreads();
+        // ---- counts -> the waves' first positions inside each bin; bins' first positions inside the tile
+        unsigned binCount = 0;
+        if (threadIdx.x < BINS) {
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < kRtWaves; ++w) { const unsigned c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = run; run += c; }
+            binCount = run;
+        }
+        {   // exclusive scan of binCount over the bins (BINS <= 256 == kRtThreads)
+            unsigned incl = binCount;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+            if (lane == 63) sScan[wave] = incl;
+            __syncthreads();
+            unsigned base = 0;
+            for (int w = 0; w < wave; ++w) base += sScan[w];
+            if (threadIdx.x < BINS) sBinStart[threadIdx.x] = base + incl - binCount;
+        }
+        __syncthreads();
+        // ---- the tile in digit order in LDS
+#pragma unroll
+        for (int s = 0; s < kRtItems; ++s) {
+            const int j = sub + s * 64 + lane;
+            if (j < tileN) {
+                const uint32_t d = (k[s] >> shift) & mask;
+                const unsigned pos = sBinStart[d] + sCnt[wave][d] + rnk[s];
+                sKey[pos] = k[s]; sIdx[pos] = v[s];
+            }
+        }
+        __syncthreads();
+        // ---- out: element j of the ordered tile is the (j - start of its bin)-th of its bin in this tile
+        for (int j = threadIdx.x; j < tileN; j += kRtThreads) {
+            const uint32_t kk = sKey[j];
+            const uint32_t d = (kk >> shift) & mask;
+            const unsigned g = sGlobal[d] + ((unsigned)j - sBinStart[d]);
+            if (keysOut) keysOut[g] = kk;
+            idxOut[g] = sIdx[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < BINS) sGlobal[threadIdx.x] += binCount;
+    }
+}
+
+static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+                                const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
+                                char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
+    const RsPlan p = rt_plan(n, endBit);
+    uint32_t* kA = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    uint32_t* kB = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    int32_t* iA = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    int32_t* iB = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
+    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4);
+    uint32_t* totals = (uint32_t*)scratch;
+    const uint32_t* kin = kA; const int32_t* iin = nullptr;
+    for (int k = 0; k < p.passes; ++k) {
+        const int bins = 1 << p.bits[k];
+        if (k == 0)
+            hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
+                               nSub, kA, n, p.chunk, p.bits[0], counts);
+        else
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
+        hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
+        const bool last = k == p.passes - 1;
+        uint32_t* kout = (kin == kA) ? kB : kA;
+        int32_t* iout = (iin == iA) ? iB : iA;
+        uint32_t* ko = (last && !keepKeys) ? nullptr : kout;
+#define CPF_RT_LAUNCH(B) hipLaunchKernelGGL(rt_scatter_kernel<B>, dim3(p.nChunks), dim3(kRtThreads), 0, st, kin, iin, ko, iout, n, p.chunk, p.shift[k], counts, totals)
+        switch (p.bits[k]) {
+            case 1: CPF_RT_LAUNCH(1); break; case 2: CPF_RT_LAUNCH(2); break; case 3: CPF_RT_LAUNCH(3); break; case 4: CPF_RT_LAUNCH(4); break;
+            case 5: CPF_RT_LAUNCH(5); break; case 6: CPF_RT_LAUNCH(6); break; case 7: CPF_RT_LAUNCH(7); break; default: CPF_RT_LAUNCH(8); break;
+        }
+#undef CPF_RT_LAUNCH
+        kin = kout; iin = iout;
+    }
+    *keysSorted = keepKeys ? kin : nullptr;
+    *perm = iin;
+    return hipGetLastError();
+}
+
 static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
                                 const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
                                 char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
@@ -1345,7 +1511,7 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
     // keys in + keys out + iota + perm + one staging array (24 bytes per particle: also serves the velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return std::max(al(tmp) + al(4 * (size_t)n) * 4 + al(24 * (size_t)n), rs_scratch_bytes(n, endBit));
+    return std::max({al(tmp) + al(4 * (size_t)n) * 4 + al(24 * (size_t)n), rs_scratch_bytes(n, endBit), rt_scratch_bytes(n, endBit)});
 }
 
 // Out arrays (ox ... ogid) given: the sorted cloud is written there and the input arrays are left alone -- no staging,
@@ -1381,11 +1547,13 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     if (method != 0) {
         // ---- the hand-written key sort (see rs_sort_pairs); the same gathers as the library path below
-        if (rs_scratch_bytes(n, endBit) > scratchBytes) return hipErrorInvalidValue;
+        const size_t need = method == 2 ? rt_scratch_bytes(n, endBit) : rs_scratch_bytes(n, endBit);
+        if (need > scratchBytes) return hipErrorInvalidValue;
         const uint32_t* keysSorted = nullptr; const int32_t* perm = nullptr;
-        hipError_t e = rs_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm);
+        hipError_t e = method == 2 ? rt_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm)
+                                   : rs_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm);
         if (e != hipSuccess) return e;
-        double* stage = (double*)((char*)scratch + rs_scratch_bytes(n, endBit) - rs_al(24 * (size_t)n));
+        double* stage = (double*)((char*)scratch + need - rs_al(24 * (size_t)n));
         if (occupied != nullptr) {
             e = hipMemsetAsync(occupied, 0, 16, st);
             if (e != hipSuccess) return e;

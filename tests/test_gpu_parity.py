@@ -1360,7 +1360,7 @@ def test_hand_written_key_sort_gives_the_library_sort_order(case, setup, gpu_ctx
         ctx.locate_initial_dev(p(base[0]), p(base[1]), p(base[2]), p(c0), n)
         g0 = torch.arange(n, dtype=torch.int64, device=dev) * 3 + 1
         res = {}
-        for method in (0, 1):
+        for method in (0, 1, 2):
             ctx.set_option("sort_method", method)
             x, y, z, c, g = (t.clone() for t in (*base, c0, g0))
             out = [torch.zeros_like(t) for t in (x, y, z, c, g)]
@@ -1369,8 +1369,9 @@ def test_hand_written_key_sort_gives_the_library_sort_order(case, setup, gpu_ctx
             torch.cuda.synchronize()
             assert all(torch.equal(a, b) for a, b in zip(out, (x, y, z, c, g)))
             res[method] = [t.cpu().numpy() for t in (x, y, z, c, g)]
-        for a, b in zip(res[0], res[1]):
-            assert np.array_equal(a, b)
+        for m in (1, 2):
+            for a, b in zip(res[0], res[m]):
+                assert np.array_equal(a, b), (m, n)
         cs = res[1][3]
         k = int((cs >= 0).sum())
         assert (cs[:k] >= 0).all() and (cs[k:] < 0).all()

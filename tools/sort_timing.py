@@ -25,7 +25,7 @@ def main():
         torch.cuda.synchronize()
         out = [torch.empty_like(t) for t in (x, y, z, c, g)]
         row = {"case": case, "particles": n, "cells": mesh.n_cells, "age_steps": a.age, "D": a.D}
-        for method in (0, 1, 0, 1):
+        for method in (0, 1, 2, 0, 1, 2):
             ctx.set_option("sort_method", method)
             ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), *(p(t) for t in out), n); torch.cuda.synchronize()
             t0 = time.perf_counter()
