@@ -1026,16 +1026,25 @@ hipError_t launch_count_negative(hipStream_t st, const int32_t* cell, int64_t n,
 // (bits per axis, axis significance) is chosen at mesh ingest (cpf_mesh.cpp): 4 x 4 x 4 for 3-D meshes, 4 x 32 for
 // a 2-D case like pitzDaily.  Measured on the bench cloud: rounds per wave 2.68 (cell only) -> 2.31 -> 2.23.
 struct SubKey { int bits[3]; int order[3]; };
-__global__ void sort_keys_kernel(const double* __restrict__ x, const double* __restrict__ y,
-                                 const double* __restrict__ z, const int32_t* __restrict__ cell,
-                                 const float* __restrict__ cellBox, const int32_t* __restrict__ rank, SubKey sk, int subBits,
-                                 uint32_t* __restrict__ keys, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int32_t c = cell[i];
-    if (c < 0) { keys[i] = 0xFFFFFFFFu; return; }            // lost / frozen particles go to the tail
+// (aos != nullptr: the particle's (x, y, z, id) also goes out as ONE 32-byte record, which the sort's gather then fetches with one
+// L2 transaction instead of four -- see sort_by_cell)
+#ifndef CPF_SORT_AOS
+#define CPF_SORT_AOS 1
+#endif
+#ifndef CPF_SORT_XCD
+#define CPF_SORT_XCD 1
+#endif
+struct __attribute__((aligned(16))) Pair64 { double a, b; };
+__device__ __forceinline__ void put_aos(double* __restrict__ aos, int64_t i, double px, double py, double pz, const int64_t* __restrict__ gid) {
+    Pair64* rec = reinterpret_cast<Pair64*>(aos) + 2 * i;
+    rec[0] = Pair64{px, py};
+    rec[1] = Pair64{pz, __longlong_as_double(gid ? gid[i] : 0ll)};
+}
+__device__ __forceinline__ uint32_t sort_key_of(double px, double py, double pz, int32_t c, const float* __restrict__ cellBox,
+                                                const int32_t* __restrict__ rank, const SubKey& sk, int subBits) {
+    if (c < 0) return 0xFFFFFFFFu;                          // lost / frozen particles go to the tail
     const float* b = cellBox + 6 * (int64_t)c;              // lo.xyz, 2^bits / extent.xyz
-    const float r[3] = {((float)x[i] - b[0]) * b[3], ((float)y[i] - b[1]) * b[4], ((float)z[i] - b[2]) * b[5]};
+    const float r[3] = {((float)px - b[0]) * b[3], ((float)py - b[1]) * b[4], ((float)pz - b[2]) * b[5]};
     uint32_t sub = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1044,7 +1053,46 @@ __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __r
         sub = (sub << sk.bits[a]) | (uint32_t)q;
     }
     // (rank: the cell's place along the mesh layer's Morton curve instead of its id -- sparse clouds, see sort_by_cell)
-    keys[i] = ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
+    return ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
+}
+__global__ void sort_keys_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                 const double* __restrict__ z, const int32_t* __restrict__ cell,
+                                 const float* __restrict__ cellBox, const int32_t* __restrict__ rank, SubKey sk, int subBits,
+                                 uint32_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ gid, double* __restrict__ aos) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double px = x[i], py = y[i], pz = z[i];
+    if (aos) put_aos(aos, i, px, py, pz, gid);
+    keys[i] = sort_key_of(px, py, pz, cell[i], cellBox, rank, sk, subBits);
+}
+// the gather out of the 32-byte records: positions and id with one transaction; the cell out of the sorted key, or fetched
+__global__ __launch_bounds__(kBlock) void gather_aos_kernel(const double* __restrict__ aos, const int32_t* __restrict__ cell,
+                                                            double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
+                                                            int32_t* __restrict__ ocell, int64_t* __restrict__ ogid,
+                                                            const int32_t* __restrict__ perm, const uint32_t* __restrict__ keys, int nSub, int64_t n,
+                                                            bool cellFromKey) {
+    // (workgroups go to the 8 XCDs in turn: give every XCD one contiguous eighth of the destinations, so that the records of
+    //  a 128-byte source line -- whose destinations are neighbours -- are fetched into ONE L2; the grid is 8 * ceil(blocks / 8))
+#if CPF_SORT_XCD
+    const int64_t per = gridDim.x >> 3;
+    const int64_t i = (((int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock) + threadIdx.x;
+#else
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+#endif
+    if (i >= n) return;
+    const int64_t j = perm[i];
+    const uint32_t k = cellFromKey ? keys[i] : 0xFFFFFFFFu;
+    const Pair64* rec = reinterpret_cast<const Pair64*>(aos) + 2 * j;
+    const Pair64 lo = rec[0], hi = rec[1];
+    const int32_t cc = (cellFromKey && k != 0xFFFFFFFFu) ? (int32_t)(k >> nSub) : cell[j];
+    ox[i] = lo.a; oy[i] = lo.b; oz[i] = hi.a;
+    ocell[i] = cc;
+    if (ogid) ogid[i] = __double_as_longlong(hi.b);
+}
+static inline dim3 grid8_for(int64_t n) { const int64_t b = (n + kBlock - 1) / kBlock; return dim3((unsigned)((b + 7) / 8 * 8)); }
+__global__ void copy_cells_kernel(int32_t* __restrict__ cell, const int32_t* __restrict__ sc, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) cell[i] = sc[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,23 +1141,7 @@ static size_t rs_scratch_bytes(int64_t n, int endBit) {
     const RsPlan p = rs_plan(n, endBit);
     const int maxBits = *std::max_element(p.bits, p.bits + p.passes);
     // two (key, index) buffers for the ping-pong, the count matrix, the bin totals, one staging array (in-place form)
-    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4) + rs_al(((size_t)1 << maxBits) * 4) + rs_al(24 * (size_t)n);
-}
-
-// a lane's sort key (see sort_keys_kernel)
-__device__ __forceinline__ uint32_t sort_key_of(double px, double py, double pz, int32_t c, const float* __restrict__ cellBox,
-                                                const int32_t* __restrict__ rank, const SubKey& sk, int subBits) {
-    if (c < 0) return 0xFFFFFFFFu;
-    const float* b = cellBox + 6 * (int64_t)c;
-    const float r[3] = {((float)px - b[0]) * b[3], ((float)py - b[1]) * b[4], ((float)pz - b[2]) * b[5]};
-    uint32_t sub = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int a = sk.order[k];
-        const int q = min((1 << sk.bits[a]) - 1, max(0, (int)(a == 0 ? r[0] : (a == 1 ? r[1] : r[2]))));
-        sub = (sub << sk.bits[a]) | (uint32_t)q;
-    }
-    return ((uint32_t)(rank ? rank[c] : c) << subBits) | sub;
+    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4) + rs_al(((size_t)1 << maxBits) * 4) + rs_al(32 * (size_t)n);
 }
 
 // keys of chunk blockIdx.x + its counts of the FIRST pass's digit: counts[chunk][bin]
@@ -1117,7 +1149,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_keys_hist_kernel(const double* 
                                                                   const double* __restrict__ z, const int32_t* __restrict__ cell,
                                                                   const float* __restrict__ cellBox, const int32_t* __restrict__ rank,
                                                                   SubKey sk, int subBits, uint32_t* __restrict__ keys, int64_t n,
-                                                                  int64_t chunk, int bits, uint32_t* __restrict__ counts) {
+                                                                  int64_t chunk, int bits, uint32_t* __restrict__ counts,
+                                                                  const int64_t* __restrict__ gid, double* __restrict__ aos) {
     extern __shared__ unsigned sHist[];
     const int bins = 1 << bits;
     for (int b = threadIdx.x; b < bins; b += kRsThreads) sHist[b] = 0u;
@@ -1139,6 +1172,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_keys_hist_kernel(const double* 
             if (i < hi) {
                 const uint32_t k = sort_key_of(px[u], py[u], pz[u], pc[u], cellBox, rank, sk, subBits);
                 keys[i] = k;
+                if (aos) put_aos(aos, i, px[u], py[u], pz[u], gid);
                 atomicAdd(&sHist[k & mask], 1u);
             }
         }
@@ -1322,7 +1356,7 @@ static RsPlan rt_plan(int64_t n, int endBit) {
 }
 static size_t rt_scratch_bytes(int64_t n, int endBit) {
     const RsPlan p = rt_plan(n, endBit);
-    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(24 * (size_t)n);
+    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(32 * (size_t)n);
 }
 
 template <int BITS>
@@ -1430,7 +1464,7 @@ __global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* 
     }
 }
 
-static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell, const int64_t* gid, double* aos,
                                 const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
                                 char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
     const RsPlan p = rt_plan(n, endBit);
@@ -1445,7 +1479,7 @@ static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y
         const int bins = 1 << p.bits[k];
         if (k == 0)
             hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
-                               nSub, kA, n, p.chunk, p.bits[0], counts);
+                               nSub, kA, n, p.chunk, p.bits[0], counts, gid, aos);
         else
             hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
         hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
@@ -1466,7 +1500,7 @@ static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y
     return hipGetLastError();
 }
 
-static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell,
+static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell, const int64_t* gid, double* aos,
                                 const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
                                 char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
     const RsPlan p = rs_plan(n, endBit);
@@ -1489,7 +1523,7 @@ static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y
         const int bins = 1 << p.bits[k];
         if (k == 0)
             hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
-                               nSub, kA, n, p.chunk, p.bits[0], counts);
+                               nSub, kA, n, p.chunk, p.bits[0], counts, gid, aos);
         else
             hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
         hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
@@ -1509,9 +1543,10 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, endBit);
-    // keys in + keys out + iota + perm + one staging array (24 bytes per particle: also serves the velocity triples)
+    // keys in + keys out + iota + perm + one staging array (32 bytes per particle: the (x, y, z, id) records; also serves the
+    // velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return std::max({al(tmp) + al(4 * (size_t)n) * 4 + al(24 * (size_t)n), rs_scratch_bytes(n, endBit), rt_scratch_bytes(n, endBit)});
+    return std::max({al(tmp) + al(4 * (size_t)n) * 4 + al(32 * (size_t)n), rs_scratch_bytes(n, endBit), rt_scratch_bytes(n, endBit)});
 }
 
 // Out arrays (ox ... ogid) given: the sorted cloud is written there and the input arrays are left alone -- no staging,
@@ -1549,19 +1584,33 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
         // ---- the hand-written key sort (see rs_sort_pairs); the same gathers as the library path below
         const size_t need = method == 2 ? rt_scratch_bytes(n, endBit) : rs_scratch_bytes(n, endBit);
         if (need > scratchBytes) return hipErrorInvalidValue;
+        double* stage = (double*)((char*)scratch + need - rs_al(32 * (size_t)n));
+        double* aos = CPF_SORT_AOS ? stage : nullptr;
+        const bool cellFromKey = rank == nullptr && endBit < 32;
+        const bool keepKeys = occupied != nullptr || (aos && cellFromKey);
         const uint32_t* keysSorted = nullptr; const int32_t* perm = nullptr;
-        hipError_t e = method == 2 ? rt_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm)
-                                   : rs_sort_pairs(st, x, y, z, cell, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, occupied != nullptr, &keysSorted, &perm);
+        hipError_t e = method == 2 ? rt_sort_pairs(st, x, y, z, cell, gid, aos, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, keepKeys, &keysSorted, &perm)
+                                   : rs_sort_pairs(st, x, y, z, cell, gid, aos, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, keepKeys, &keysSorted, &perm);
         if (e != hipSuccess) return e;
-        double* stage = (double*)((char*)scratch + need - rs_al(24 * (size_t)n));
         if (occupied != nullptr) {
             e = hipMemsetAsync(occupied, 0, 16, st);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(count_cell_runs_kernel, grid_for(n), dim3(kBlock), 0, st, keysSorted, n, nSub, 0xFFFFFFFFu, occupied);
         }
         if (ox != nullptr) {
-            hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm,
-                               (const uint32_t*)nullptr, nSub, n, false);
+            if (aos)
+                hipLaunchKernelGGL(gather_aos_kernel, grid8_for(n), dim3(kBlock), 0, st, aos, cell, ox, oy, oz, ocell, gid ? ogid : nullptr, perm,
+                                   keysSorted, nSub, n, cellFromKey);
+            else
+                hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm,
+                                   (const uint32_t*)nullptr, nSub, n, false);
+        } else if (aos) {
+            // (the index buffer the last pass did not write is free)
+            int32_t* iA = (int32_t*)((char*)scratch + 2 * rs_al(4 * (size_t)n));
+            int32_t* iB = (int32_t*)((char*)iA + rs_al(4 * (size_t)n));
+            int32_t* spare = perm == iA ? iB : iA;
+            hipLaunchKernelGGL(gather_aos_kernel, grid8_for(n), dim3(kBlock), 0, st, aos, cell, x, y, z, spare, gid, perm, keysSorted, nSub, n, cellFromKey);
+            hipLaunchKernelGGL(copy_cells_kernel, grid_for(n), dim3(kBlock), 0, st, cell, spare, n);
         } else {
             double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;
             hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, perm, n);
@@ -1587,10 +1636,11 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     uint32_t* keysOut = (uint32_t*)p; p += al(4 * (size_t)n);
     int32_t* idx = (int32_t*)p; p += al(4 * (size_t)n);
     int32_t* perm = (int32_t*)p; p += al(4 * (size_t)n);
-    double* stage = (double*)p; p += al(24 * (size_t)n);
+    double* stage = (double*)p; p += al(32 * (size_t)n);
     if ((size_t)(p - (char*)scratch) > scratchBytes) return hipErrorInvalidValue;
+    double* aos = CPF_SORT_AOS ? stage : nullptr;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(kBlock), 0, st, idx, n);
-    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, rank, sk, nSub, keysIn, n);
+    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, rank, sk, nSub, keysIn, n, gid, aos);
     // endBit covers the cell bits + sub-cell bits; the all-ones key of lost/frozen particles sorts last
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keysIn, keysOut, idx, perm, (int)n, 0, endBit, st);
     if (e != hipSuccess) return e;
@@ -1599,15 +1649,19 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(count_cell_runs_kernel, grid_for(n), dim3(kBlock), 0, st, keysOut, n, nSub, 0xFFFFFFFFu, occupied);    // (sort_keys_kernel's lost key)
     }
+    // (a live particle's cell out of its sorted key: only where no cell bit was shifted out of the 32-bit key)
+    const bool cellFromKey = rank == nullptr && endBit < 32;
     if (ox != nullptr) {
-#ifdef CPF_SORT_SPLIT_GATHERS
-        hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, ox, oy, oz, perm, n);
-        hipLaunchKernelGGL(gather_ids_kernel, grid_for(n), dim3(kBlock), 0, st, cell, gid, ocell, ogid, perm, n);
-#else
-        // (a live particle's cell out of its sorted key: only where no cell bit was shifted out of the 32-bit key)
-        hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n,
-                           rank == nullptr && endBit < 32);
-#endif
+        if (aos)
+            hipLaunchKernelGGL(gather_aos_kernel, grid8_for(n), dim3(kBlock), 0, st, aos, cell, ox, oy, oz, ocell, gid ? ogid : nullptr, perm, keysOut,
+                               nSub, n, cellFromKey);
+        else
+            hipLaunchKernelGGL(gather_all_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, gid, ox, oy, oz, ocell, ogid, perm, keysOut, nSub, n,
+                               cellFromKey);
+    } else if (aos) {
+        // in place: the records ARE the copy -- positions and ids go straight back; the cells pass through the spent index array
+        hipLaunchKernelGGL(gather_aos_kernel, grid8_for(n), dim3(kBlock), 0, st, aos, cell, x, y, z, idx, gid, perm, keysOut, nSub, n, cellFromKey);
+        hipLaunchKernelGGL(copy_cells_kernel, grid_for(n), dim3(kBlock), 0, st, cell, idx, n);
     } else {
         double* sx = stage; double* sy = stage + n; double* sz = stage + 2 * n;          // the 24n-byte staging area
         hipLaunchKernelGGL(gather_xyz_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, sx, sy, sz, perm, n);

@@ -263,10 +263,10 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
  *   "sort_method"   (0) the (key, index) sort behind cpf_sort_by_cell*: 0 = hipcub::DeviceRadixSort (three 8-bit passes over
  *                   pitzDaily's 21 key bits), 1 = this library's own stable radix sort with 11-bit digits (two passes; csrc/
- *                   cpf_kernels.hip, rs_sort_pairs).  The same order either way, particle for particle (tests).  Measured, round 5,
- *                   1e7 particles sorted 25 cycles of diffusion ago: 0.70 ms either way -- 0.32 ms of it is the gather of the five
- *                   particle arrays, which both share; on TJunction's 24 key bits (three passes) the library is faster, 0.29 / 0.37 ms;
- *                   2 = own radix sort with 8-bit digits and an LDS tile reorder (rt_sort_pairs): 0.69 / 0.32 ms, same order
+ *                   cpf_kernels.hip, rs_sort_pairs), 2 = the same with 8-bit digits and an LDS tile reorder (rt_sort_pairs).  The
+ *                   same order whichever, particle for particle (tests).  Measured, round 5, 1e7 particles sorted 25 cycles of
+ *                   diffusion ago: 0.62 / 0.65 / 0.65 ms -- 0.24 ms of it the gather of the particle records, which all share; on
+ *                   TJunction's 24 key bits (4e6 particles) 0.27 / 0.40 / 0.32 ms
  *   "sort_curve"    (-1) the sort's major key: 0 = the cell id, 1 = the cell's rank along a Morton curve through the cell centres
  *                   (built at cpf_set_mesh), -1 = the rank for sparse clouds (fewer than 8 particles per cell: the step kernel is
  *                   bound by record traffic there and a cell's neighbours in all three directions should be close by in the
