@@ -1110,13 +1110,11 @@ __global__ void copy_cells_kernel(int32_t* __restrict__ cell, const int32_t* __r
 //     where it reads the position).
 // Traffic per particle for two passes: 28 + 4 (keys) + 4 + 8 (pass 1) + 4 + 8 + 4 (pass 2) + 4 + 36 + 36 (gather) = 136 B
 // against ~190 B with three library passes, an index fill and keys carried to the end.
-// MEASURED (rocprofv3 kernel trace, one box, 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago; profiles/
-// r05_sort_kernel_trace.csv): keys + counts 67 us, column scans 2 x 14.5, pass 1 (the low digit is the sub-cell position: every
-// lane of a wave writes to a different bin, 8 bytes per 64-byte line) 183, counts 26, pass 2 (the high digit is the cell: long
-// runs, coalesced) 58, gather 323 -- 0.69 ms, the library path's 0.70 (index fill 12, keys 64, three passes of 90, gather 323).
-// The wide first pass loses to write amplification what it saves in passes; the gather of five arrays through a scrambled
-// permutation (one 64-byte L2 transaction per 8-byte element) is half of either total and is what a faster re-sort would have
-// to remove.  Three 8-bit passes on TJunction's 24 key bits: 0.37 ms against the library's 0.29 -- hence not the default.
+// MEASURED (profiles/r05_sort_breakdown.json; 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago): pass 1 (the low digit
+// is the sub-cell position: every lane of a wave writes to a different bin, 8 bytes per 64-byte line) 190 us, pass 2 (the high
+// digit is the cell: long runs, coalesced) 75 -- 0.65 ms per sort against the library path's 0.62.  The wide first pass loses to
+// write amplification what it saves in passes.  Three 8-bit passes on TJunction's 24 key bits: 0.40 ms against the library's
+// 0.27 -- hence not the default.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRsThreads = 512, kRsWaves = kRsThreads / 64, kRsMaxChunks = 512, kRsMaxBits = 11;
 struct RsPlan {
