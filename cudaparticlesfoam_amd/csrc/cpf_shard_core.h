@@ -82,6 +82,7 @@ class ShardCore {
                                           // what the ranks asked for in the last table, so that every rank completes a hand-off at
                                           // the same step (an overflow re-split "at the current step" is then current everywhere)
     bool haveCost = false, costWaited = false;
+    int64_t launchesIssued = 0, cyclesIssued = 0;   // timed step launches and their cycles since the last cost reading
     double costPerParticle = 1.0;
     double hostWorkMs = 0.5;              // running mean of the host's own work per hand-off, without the wait
 
@@ -331,7 +332,7 @@ class ShardCore {
             CPF_SH(finishExchange());                     // the catch-up replays the window with ONE set of arguments
         argDt = dt; argD = D; argFlags = flags; haveArgs = true;
         const bool dist = distOn();
-        const bool storeVel = (flags & CPF_STEP_STORE_VEL) != 0;
+        const bool storeVel = (flags & CPF_STEP_STORE_VEL) != 0, fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
         if (storeVel && !vel) CPF_SH(dev.alloc((void**)&vel, (size_t)cap * 24));
         // what fell due on the last cycle of a call that stored velocities runs now (the frame has been written)
         if (deferSort || deferRecut || deferExchange) {
@@ -345,13 +346,27 @@ class ShardCore {
         // file, out-of-domain particles frozen; src/initCuda.H:184-201) and not a step of the run -- like cpf_step, the
         // counter-based Brownian stream and the cadences do not see it
         const bool frameZero = dt == 0.0 && D == 0.0;
-        for (int c = 0; c < nCycles; ++c) {
+        for (int c = 0; c < nCycles;) {
             if (pending.on && (int64_t)stepIndex - (int64_t)pending.step >= overlapDepth()) CPF_SH(finishExchange());
-            CPF_SH(dev.step(x, y, z, cell, gid, storeVel ? vel : nullptr, n, dt, D, stepIndex, 1, flags));
+            // CPF_STEP_FUSE_CYCLES: the cycles up to the next thing that falls due -- the end of the call, a sort, a hand-off or
+            // re-cut, the completion of the hand-off in flight -- run inside ONE launch (U is frozen during the call;
+            // bit-identical to single launches)
+            int64_t run = 1;
+            if (fuse && !frameZero && !storeVel) {
+                run = nCycles - c;
+                if (pending.on) run = std::min<int64_t>(run, (int64_t)overlapDepth() - ((int64_t)stepIndex - (int64_t)pending.step));
+                if (sortInterval) run = std::min<int64_t>(run, sortInterval - (int64_t)(stepIndex % (uint32_t)sortInterval));
+                if (dist && rebalanceInterval) run = std::min<int64_t>(run, rebalanceInterval - (int64_t)(stepIndex % (uint32_t)rebalanceInterval));
+                if (dist && exchangeInterval) run = std::min<int64_t>(run, exchangeInterval - (int64_t)(stepIndex % (uint32_t)exchangeInterval));
+                run = std::max<int64_t>(run, 1);
+            }
+            CPF_SH(dev.step(x, y, z, cell, gid, storeVel ? vel : nullptr, n, dt, D, stepIndex, (int)run, flags));
+            c += (int)run;
             if (frameZero) continue;
-            ++stepIndex;
-            particleSteps += n;
-            const bool hold = storeVel && c == nCycles - 1;           // velocities must stay aligned with the particles
+            stepIndex += (uint32_t)run;
+            particleSteps += n * run;
+            ++launchesIssued; cyclesIssued += run;
+            const bool hold = storeVel && c == nCycles;               // velocities must stay aligned with the particles
             if (sortInterval && stepIndex % (uint32_t)sortInterval == 0) {
                 if (hold) deferSort = true;
                 else if (!pending.on) CPF_SH(sort());
@@ -555,8 +570,11 @@ class ShardCore {
         if (wait) costWaited = true;
         CPF_SH(dev.timingRead(wait, &launches, &ms));
         kernelMs += ms; kernelLaunches += launches;
+        // (a launch may hold several cycles: the mean number per launch since the last reading)
+        const double cyclesPerLaunch = launchesIssued > 0 ? (double)cyclesIssued / (double)launchesIssued : 1.0;
+        launchesIssued = 0; cyclesIssued = 0;
         if (launches > 0 && n > 0) {
-            const double c = std::min(4.0, std::max(0.25, ms / (double)launches / (double)n / kCostUnitMs));
+            const double c = std::min(4.0, std::max(0.25, ms / ((double)launches * cyclesPerLaunch) / (double)n / kCostUnitMs));
             costPerParticle = first ? c : 0.5 * (costPerParticle + c);
             haveCost = true;
         }

@@ -416,7 +416,9 @@ int cpf_shard_seed_box(cpf_shard* s, int64_t nTotal, const double lower[3], cons
 /* nCycles Lagrangian cycles of this rank's particles (cpf_step's contract), with the hand-offs, re-cuts and sorts
  * that fall due in between.  COLLECTIVE: every rank calls it with the same arguments.  With CPF_STEP_STORE_VEL the
  * velocities of the last cycle stay aligned with the particles until the next call (whatever falls due on that
- * cycle runs at the start of the next call instead). */
+ * cycle runs at the start of the next call instead).  With CPF_STEP_FUSE_CYCLES the cycles up to the next thing that
+ * falls due (a sort, a hand-off, a re-cut, the completion of the hand-off in flight, the end of the call) run inside
+ * one launch, as in cpf_step; without it every cycle is a launch.  Same results either way, bit for bit. */
 int cpf_shard_step(cpf_shard* s, double dt, double D, int nCycles, unsigned flags);
 int cpf_shard_flush(cpf_shard* s);       /* completes a hand-off still in flight (arrivals appended and caught up) */
 int cpf_shard_exchange(cpf_shard* s);    /* one synchronous hand-off with the current ranges */

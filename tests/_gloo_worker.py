@@ -24,6 +24,7 @@ def main():
     u_step = int(sys.argv[7]) if len(sys.argv) > 7 else 0                # > 0: the velocity field changes after that many steps
     send_fraction = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0    # small: the send buffer overflows and must grow
     slices = int(sys.argv[9]) if len(sys.argv) > 9 else 0               # 1: the new field arrives as per-rank slices; + the collective gather
+    flags = int(os.environ.get("CPF_TEST_STEP_FLAGS", "0"))             # 4 = CPF_STEP_FUSE_CYCLES: one launch up to the next trigger
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m0 = box_mesh(12, 5, 4)
@@ -53,7 +54,7 @@ def main():
     if slow_rank0:
         cloud.enable_time_balancing()
     if u_step:
-        cloud.step(0.2, u_step)
+        cloud.step(0.2, u_step, flags=flags)
         U2 = U[::-1].copy() * 0.5                          # a transient solver's new field, mid hand-off window
         if slices:
             # every rank hands over ITS slice only (the cells of its piece of a decomposed mesh, here an uneven cut); the
@@ -62,9 +63,9 @@ def main():
             cloud.set_velocity_slice(U2[cut[rank]:cut[rank + 1]])
         else:
             cloud.set_velocity(U2)
-        cloud.step(0.2, 30 - u_step)
+        cloud.step(0.2, 30 - u_step, flags=flags)
     else:
-        cloud.step(0.2, 30)
+        cloud.step(0.2, 30, flags=flags)
     if interval > 1:
         cloud.exchange()
     total1 = cloud.global_count()
@@ -76,7 +77,7 @@ def main():
         np.savez(out_path + ".whole.npz", xyzw=whole[0], cell=whole[1])
     np.savez(out_path + ".rank%d.npz" % rank, gid=g, x=x, y=y, z=z, cell=c, owned_ok=owned_ok, owned_ok2=owned_ok2,
              total0=total0, total1=total1, handed=cloud.handed_off, exchanges=cloud.exchanges, rebalances=cloud.rebalances,
-             n_local=cloud.n, grown=cloud.grown, send_grown=cloud.send_grown, cell_lo=np.asarray(cell_lo))
+             n_local=cloud.n, launches=case.step_launches() if hasattr(case, 'step_launches') else -1, grown=cloud.grown, send_grown=cloud.send_grown, cell_lo=np.asarray(cell_lo))
     cloud.close()
     dist.barrier()
     dist.destroy_process_group()

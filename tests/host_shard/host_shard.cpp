@@ -33,6 +33,7 @@ struct cpf_host_case {
     uint32_t seed = 0;
     bool timing = false;
     int64_t launches = 0;
+    int64_t stepLaunches = 0;      // every step launch ever (the fused-cycles test counts them)
     double ms = 0.0;
 };
 
@@ -67,7 +68,8 @@ struct HostDev {
 
     int step(double* x, double* y, double* z, int32_t* cell, const int64_t* gid, double* vel, int64_t n, double dt, double D,
              uint32_t step0, int nCycles, unsigned) {
-        if (hc->timing) { hc->launches += 1; hc->ms += (double)n * hc->fakeMsPerParticle; }
+        hc->stepLaunches += 1;
+        if (hc->timing) { hc->launches += 1; hc->ms += (double)n * (double)nCycles * hc->fakeMsPerParticle; }   // (a real launch takes as long as its cycles)
         std::vector<double> v4;                                  // the checker writes [n][4] velocities, the shard keeps [n][3]
         if (vel) v4.assign((size_t)n * 4, 0.0);
         cw_step(x, y, z, cell, vel ? v4.data() : nullptr, (int)n, dt, nCycles, hc->cellOff.data(), hc->planes.data(), hc->nbr.data(),
@@ -220,6 +222,7 @@ cpf_host_case* cpf_host_case_create(const int32_t* cellOff, const double* planes
 }
 void cpf_host_case_destroy(cpf_host_case* h) { delete h; }
 void cpf_host_case_timing(cpf_host_case* h, int on) { h->timing = on != 0; }
+int64_t cpf_host_case_step_launches(const cpf_host_case* h) { return h->stepLaunches; }
 void cpf_host_case_timing_read(cpf_host_case* h, int64_t* launches, double* ms) { *launches = h->launches; *ms = h->ms; h->launches = 0; h->ms = 0.0; }
 
 }  // extern "C"

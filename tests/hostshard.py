@@ -74,6 +74,11 @@ class HostCase:
         self.lib.cpf_host_case_timing_read(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def step_launches(self):
+        self.lib.cpf_host_case_step_launches.restype = C.c_int64
+        self.lib.cpf_host_case_step_launches.argtypes = [C.c_void_p]
+        return int(self.lib.cpf_host_case_step_launches(self.h))
+
     def step_kernel_name(self, D=0.0, flags=0):
         return "tests/host_shard (CPU checker stand-in)"
 

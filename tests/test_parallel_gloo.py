@@ -39,8 +39,8 @@ def _single_process_answer(oracle_libs, u_step=0):
     return x, y, z, c
 
 
-def _run_workers(world, out, *args):
-    env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+def _run_workers(world, out, *args, step_flags=0):
+    env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT, CPF_TEST_STEP_FLAGS=str(step_flags))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(HERE, "_gloo_worker.py"), out] + [str(a) for a in args]
@@ -114,6 +114,23 @@ def test_velocity_slices_and_the_collective_gather(world, tmp_path, oracle_libs)
         d = np.load(out + ".rank%d.npz" % r)
         g = d["gid"]
         assert np.array_equal(d["x"], x[g]) and np.array_equal(d["cell"], c[g])
+
+
+@pytest.mark.parametrize("world,interval,rebalance,overlap,u_step", [(2, 4, 0, 0, 0), (2, 4, 10, 3, 0), (3, 0, 5, 2, 13), (2, 0, 6, -1, 0)])
+def test_fused_cycles_between_the_triggers(world, interval, rebalance, overlap, u_step, tmp_path, oracle_libs):
+    """CPF_STEP_FUSE_CYCLES on cpf_shard_step: the cycles up to the next sort / hand-off / re-cut / completion of the hand-off in
+    flight run inside one launch -- fewer launches than cycles, the same particles bit for bit (fixed and derived overlap depth,
+    a field that changes between two calls)."""
+    out = str(tmp_path / "fused")
+    _run_workers(world, out, interval, rebalance, 0, overlap, 0, u_step, step_flags=4)
+    x, y, z, c = _single_process_answer(oracle_libs, u_step=u_step) if u_step else _single_process_answer(oracle_libs)
+    ds = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
+    assert sum(int(d["n_local"]) for d in ds) == 6000
+    for d in ds:
+        g = d["gid"]
+        assert np.array_equal(d["x"], x[g]) and np.array_equal(d["y"], y[g]) and np.array_equal(d["z"], z[g])
+        assert np.array_equal(d["cell"], c[g]) and bool(d["owned_ok2"])
+        assert 0 < int(d["launches"]) <= 24        # (30 cycles; unfused: 30 launches + the catch-up replays)
 
 
 def test_time_balancing_gives_the_slow_rank_fewer_particles(tmp_path, oracle_libs):

@@ -13,6 +13,8 @@ def main():
     ap.add_argument("--D", type=float, default=1.5e-5); ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--set", action="append", default=[], help="k=v[,k=v...] one variant per --set ('' = defaults)")
     ap.add_argument("--intervals", default="25")
+    ap.add_argument("--chunk", type=int, default=0, help="also: the same run through cpf_shard_step in calls of this many cycles "
+                    "(what the parallel fragments do between two frames; the shard fuses the cycles up to the next sort)")
     a = ap.parse_args()
     import torch
     from _cases import make_case
@@ -50,6 +52,22 @@ def main():
             print(json.dumps({"case": a.case, "particles": n, "D": a.D, "options": variant, "sort_interval": interval, "steps": a.steps,
                               "ms_per_step": round(per, 4), "frac": round(64 * n / (per * 1e-3) / 8e12, 4),
                               "kernel": ctx.step_kernel_name(a.D, 0)}), flush=True)
+            if a.chunk > 0:
+                from cudaparticlesfoam_amd.parallel import ShardedCloud
+                ctx.use_own_stream()
+                cloud = ShardedCloud(ctx, None, n + 4096)
+                cloud.sort_interval = interval
+                cloud.set_particles(*cur)
+                cloud.step(1e-4, a.chunk, D=a.D, flags=4); cloud.arrays(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s in range(0, a.steps, a.chunk):
+                    cloud.step(1e-4, min(a.chunk, a.steps - s), D=a.D, flags=4)        # CPF_STEP_FUSE_CYCLES
+                cloud.arrays(); ctx.synchronize()
+                per = (time.perf_counter() - t0) / a.steps * 1e3
+                print(json.dumps({"case": a.case, "particles": n, "D": a.D, "options": variant, "sort_interval": interval, "steps": a.steps,
+                                  "through": "cpf_shard_step, %d cycles per call" % a.chunk, "ms_per_step": round(per, 4),
+                                  "frac": round(64 * n / (per * 1e-3) / 8e12, 4)}), flush=True)
+                cloud.close()
             ctx.close()
 
 
