@@ -593,6 +593,23 @@ class GpuMachine:
                 "frac": round(bytes_per * cl.n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel_frac": round(bytes_per * cl.n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k > 0 else None}
 
+    @staticmethod
+    def _fragment_calls(torch, cl, dt, steps, D, bytes_per, chunk=10):
+        """The same cycles the way the replacement advect.H issues them between two frames of either tutorial (saveInterval 10):
+        cpf_shard_step(chunk cycles, CPF_STEP_FUSE_CYCLES) -- one launch up to the next sort -- sorts inside the clock."""
+        from cudaparticlesfoam_amd import _lib as L
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(0, steps, chunk):
+            cl.step(dt, min(chunk, steps - s_), D=D, flags=L.STEP_FUSE_CYCLES)
+        cl.arrays()
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / steps * 1e3
+        return {"cycles_per_call": chunk, "ms_per_cycle": round(per, 4), "Mparticle_steps_per_s": round(cl.n / per / 1e3, 1),
+                "frac": round(bytes_per * cl.n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "cpf_shard_step with CPF_STEP_FUSE_CYCLES, sorts included; the fraction is taken on the per-cycle bytes of "
+                        "UNFUSED launches: a fused launch loads and stores once per run of cycles"}
+
     def _brownian_steady(self, cloud, dt, args, box):
         """Sustained rate with the tutorial's diffusion: a fresh cloud, the fragments' sort interval for diffusing clouds
         (compat/src/initCuda.H: 25), the sorts inside the clock (pitzDaily/system/cudaParticlesDict:17-29)."""
@@ -627,6 +644,11 @@ class GpuMachine:
                                           "frac": round((ALGO_BYTES_PER_PARTICLE_STEP + 8) * a["n"] / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "what the fragments launch between two frames; the fraction is taken on the per-cycle "
                                                   "bytes of UNFUSED launches (64 B): a fused launch loads and stores once per 8 cycles"}
+        del cl
+        cl = self._fresh_cloud(cloud.n, box, 2025, sort_interval=interval)
+        cl.step(dt, 10, D=Db)
+        cl.sort(); cl.step_index = 0
+        r["fragment_calls"] = self._fragment_calls(torch, cl, dt, args.brownian_steady_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
         del cl
         return r
 
@@ -684,6 +706,8 @@ class GpuMachine:
                                                                max(1, c1["particle_steps"] - c0["particle_steps"]), 3),
                       "seeding_box": [list(d["seedingBox"][0]), list(d["seedingBox"][1])],
                       "field": "closed-form split flow, u0 = 3 m/s at t = 0.5 s (stand-in for pimpleFoam's U)"})
+            cl.sort(); cl.step_index = 0
+            r["fragment_calls"] = self._fragment_calls(torch, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
             del cl
         finally:
             ctx2.close()

@@ -19,7 +19,7 @@ os.environ.setdefault("CPF_COMM_TIMEOUT", "180")      # a rank that died must no
 
 
 def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, overlap, balance_by_time, capacity,
-                   dt=1e-4, world=2, send_fraction=1.0):
+                   dt=1e-4, world=2, send_fraction=1.0, step_flags=0):
     import torch
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -55,7 +55,7 @@ def _run_two_ranks(pitz, oracle_libs, *, n_total, steps, rebalance, exchange, ov
             torch.cuda.synchronize()
             cloud.set_particles(tx, ty, tz, None, tg)
             cloud.exchange()
-            cloud.step(dt, steps)
+            cloud.step(dt, steps, flags=step_flags)
             cloud.flush()
             g, gx, gy, gz, gc = cloud.gather_to_numpy()
             total = cloud.global_count()
@@ -125,6 +125,17 @@ def test_two_ranks_overlap_depth_derived_per_rank(pitz, oracle_libs):
     the counts table (csrc/cpf_shard_core.h, depthNext), and every particle still equals the one-process run bit for bit."""
     out, cell = _run_two_ranks(pitz, oracle_libs, n_total=400_000, steps=32, rebalance=8, exchange=0, overlap=-1,
                                balance_by_time=True, capacity=400_000 + 64)
+    assert all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
+    assert sum(o["n"] for o in out) == 400_000
+
+
+def test_two_ranks_fused_cycles_between_the_triggers(pitz, oracle_libs):
+    """CPF_STEP_FUSE_CYCLES through cpf_shard_step (what the parallel fragments pass between two frames): the cycles up to the next
+    sort (every 5), re-cut (every 8) or completion of the hand-off in flight (derived depth) share a launch; the particles still
+    equal the one-process run bit for bit."""
+    from cudaparticlesfoam_amd import _lib as L
+    out, cell = _run_two_ranks(pitz, oracle_libs, n_total=400_000, steps=32, rebalance=8, exchange=0, overlap=-1,
+                               balance_by_time=True, capacity=400_000 + 64, step_flags=L.STEP_FUSE_CYCLES)
     assert all(o["rebalances"] == 4 for o in out) and sum(o["handed"] for o in out) > 10_000
     assert sum(o["n"] for o in out) == 400_000
 
