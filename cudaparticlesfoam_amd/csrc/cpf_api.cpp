@@ -40,7 +40,8 @@ struct cpf_context {
     int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_curveRank = nullptr; // per-cell rank along the Morton curve: the sort's major key for sparse clouds ("sort_curve")
-    int sortMethod = 0;             // "sort_method": 0 = hipcub's radix sort for the (key, index) pairs, 1 = this library's own wide-digit one (cpf_kernels.hip, rs_sort_pairs: measured no faster, see there)
+    int sortMethod = 2;             // "sort_method": the (key, index) sort: 2 = this library's tile-reorder radix sort (cpf_kernels.hip, rt_sort_pairs),
+                                    // 1 = its wide-digit one (rs_sort_pairs), 0 = hipcub's; the same order all three
     int sortCurve = -1;             // "sort_curve": -1 = Morton rank when the cloud has fewer than 8 particles per cell, 0 = cell id, 1 = Morton rank
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;

@@ -1339,8 +1339,22 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 // of whole tiles; inside a tile wave w owns elements [1024 w, 1024 (w + 1)) and ranks them in order against private counters
 // (stable without ordering the waves), one pass over [wave][bin] turns the counters into first positions, the tile is written
 // to LDS in digit order and copied out with the bins' running global positions.
+// Per pass: rt_hist_kernel (per-chunk digit counts, bin-major: 16-byte loads, a tile's worth in flight per thread), rt_scan_kernel
+// (one wave per bin over the chunks), rt_scatter_kernel.  THE DEFAULT since round 5.  MEASURED (profiles/r05_sort_breakdown.json;
+// 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago): counts 10 us, scan 5, scatter 56 per pass -- 0.54 ms per sort
+// against 0.64 with the library's onesweep passes (88 us each); TJunction, 4e6 particles, 24 key bits: 0.25 against 0.27.  The
+// scatter is bound by its own ranking arithmetic (8 ballots and ~65 vector instructions per element: coalesced stores instead of
+// the scatter, or no loads at all, change its time by < 7 %); 256 x 16, 256 x 8, 512 x 8 and 512 x 16 threads x items tie.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRtThreads = 256, kRtWaves = 4, kRtItems = 16, kRtTile = kRtThreads * kRtItems, kRtMaxBits = 8, kRtMaxChunks = 1024;
+#ifndef CPF_RT_STHREADS
+#define CPF_RT_STHREADS 256
+#endif
+#ifndef CPF_RT_SITEMS
+#define CPF_RT_SITEMS 16
+#endif
+constexpr int kRtThreads = 256, kRtWaves = 4, kRtMaxBits = 8, kRtMaxChunks = 1024;        // the counting and scanning kernels
+constexpr int kRtSThreads = CPF_RT_STHREADS, kRtSWaves = kRtSThreads / 64, kRtItems = CPF_RT_SITEMS, kRtTile = kRtSThreads * kRtItems;   // the scatter
+static_assert(kRtTile % (kRtThreads * 4) == 0, "a tile is whole batches of the counting kernel's 16-byte loads");
 static RsPlan rt_plan(int64_t n, int endBit) {
     RsPlan p{};
     p.passes = (endBit + kRtMaxBits - 1) / kRtMaxBits;
@@ -1354,37 +1368,107 @@ static RsPlan rt_plan(int64_t n, int endBit) {
 }
 static size_t rt_scratch_bytes(int64_t n, int endBit) {
     const RsPlan p = rt_plan(n, endBit);
-    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(32 * (size_t)n);
+    (void)p;
+    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(32 * (size_t)n);
+}
+
+// counts of one digit per chunk, BIN-major: counts[bin * stride + chunk].  A chunk is whole tiles of 4096 keys, the key buffers
+// are 256-byte aligned: every thread has its 16-byte loads of a tile in flight at once (one memory latency per tile, not one per
+// key), counts in per-wave private LDS histograms; a wave whose 64 x 4 keys share a digit (the high digits of an almost sorted
+// cloud) adds them with one atomic.
+constexpr int kRtHistBatch = 4;       // uint4 loads in flight per thread: 4 x 4 x 256 = 4096 keys
+__global__ __launch_bounds__(kRtThreads) void rt_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t chunk, int shift, int bits,
+                                                             uint32_t* __restrict__ counts, int stride) {
+    extern __shared__ unsigned sH[];                    // [kRtWaves][bins]
+    const int bins = 1 << bits;
+    const int wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < kRtWaves * bins; b += kRtThreads) sH[b] = 0u;
+    __syncthreads();
+    unsigned* mine = sH + wave * bins;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)kRtHistBatch * 4 * kRtThreads) {
+        uint4 v[kRtHistBatch];
+#pragma unroll
+        for (int u = 0; u < kRtHistBatch; ++u) {
+            const int64_t i = t0 + ((int64_t)u * kRtThreads + threadIdx.x) * 4;
+            if (i + 3 < hi) v[u] = *reinterpret_cast<const uint4*>(keys + i);
+            else {
+                v[u].x = i < hi ? keys[i] : 0u; v[u].y = i + 1 < hi ? keys[i + 1] : 0u; v[u].z = i + 2 < hi ? keys[i + 2] : 0u; v[u].w = 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRtHistBatch; ++u) {
+            const int64_t i = t0 + ((int64_t)u * kRtThreads + threadIdx.x) * 4;
+            const int live = (int)max<int64_t>(0, min<int64_t>(4, hi - i));
+            const uint32_t d0 = (v[u].x >> shift) & mask, d1 = (v[u].y >> shift) & mask, d2 = (v[u].z >> shift) & mask, d3 = (v[u].w >> shift) & mask;
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
+            const bool same = live == 4 && d0 == first && d1 == first && d2 == first && d3 == first;
+            if (__ballot(same) == ~0ull) {
+                if ((threadIdx.x & 63) == 0) atomicAdd(&mine[first], 256u);
+            } else {
+                if (live > 0) atomicAdd(&mine[d0], 1u);
+                if (live > 1) atomicAdd(&mine[d1], 1u);
+                if (live > 2) atomicAdd(&mine[d2], 1u);
+                if (live > 3) atomicAdd(&mine[d3], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += kRtThreads) {
+        unsigned c = 0;
+#pragma unroll
+        for (int w = 0; w < kRtWaves; ++w) c += sH[w * bins + b];
+        counts[(int64_t)b * stride + blockIdx.x] = c;
+    }
+}
+// counts[bin][chunk] -> the bin's elements in the chunks BEFORE this one (in place); totals[bin] = the bin's size.  One wave per
+// bin: a lane sums its run of consecutive chunks, one shuffle scan across the lanes, the run is written back.
+__global__ __launch_bounds__(kRtThreads) void rt_scan_kernel(uint32_t* __restrict__ counts, int nChunks, int stride, int bins,
+                                                             uint32_t* __restrict__ totals) {
+    const int bin = blockIdx.x * kRtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (bin >= bins) return;
+    constexpr int PER = kRtMaxChunks / 64;               // 16
+    uint32_t* row = counts + (int64_t)bin * stride;
+    uint32_t v[PER]; uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int c = lane * PER + k; v[k] = c < nChunks ? row[c] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int c = lane * PER + k; if (c < nChunks) row[c] = run; run += v[k]; }
+    if (lane == 63) totals[bin] = incl;
 }
 
 template <int BITS>
-__global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ idxIn,
+__global__ __launch_bounds__(kRtSThreads) void rt_scatter_kernel(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ idxIn,
                                                                 uint32_t* __restrict__ keysOut, int32_t* __restrict__ idxOut, int64_t n,
-                                                                int64_t chunk, int shift, const uint32_t* __restrict__ before,
+                                                                int64_t chunk, int shift, const uint32_t* __restrict__ before, int stride,
                                                                 const uint32_t* __restrict__ totals) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t sKey[kRtTile];
     __shared__ int32_t sIdx[kRtTile];
-    __shared__ unsigned sCnt[kRtWaves][BINS];          // per tile: the waves' digit counts, then their first positions in the tile
+    __shared__ unsigned sCnt[kRtSWaves][BINS];          // per tile: the waves' digit counts, then their first positions in the tile
     __shared__ unsigned sBinStart[BINS + 1];           // per tile: first position of a bin inside the tile
     __shared__ unsigned sGlobal[BINS];                 // running: where the bin's next element of this chunk goes
-    __shared__ unsigned sScan[kRtThreads];
+    __shared__ unsigned sScan[kRtSThreads];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t mask = (uint32_t)BINS - 1u;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-    // bin starts of the whole array = exclusive scan of the totals, + what the chunks before this one hold
+    // bin starts of the whole array = exclusive scan of the totals (BINS <= 256 == kRtThreads), + what the chunks before this one hold
     {
-        constexpr int PER = (BINS + kRtThreads - 1) / kRtThreads;
-        const int b0 = min(BINS, (int)threadIdx.x * PER), b1 = min(BINS, b0 + PER);
-        unsigned mine = 0;
-        for (int b = b0; b < b1; ++b) mine += totals[b];
-        sScan[threadIdx.x] = mine;
+        const unsigned tot = threadIdx.x < BINS ? totals[threadIdx.x] : 0u;
+        unsigned incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+        if (lane == 63) sScan[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) { unsigned run = 0; for (int t = 0; t < kRtThreads; ++t) { const unsigned v = sScan[t]; sScan[t] = run; run += v; } }
-        __syncthreads();
-        unsigned run = sScan[threadIdx.x];
-        const uint32_t* row = before + (int64_t)blockIdx.x * BINS;
-        for (int b = b0; b < b1; ++b) { sGlobal[b] = run + row[b]; run += totals[b]; }
+        unsigned base = 0;
+        for (int w = 0; w < wave; ++w) base += sScan[w];
+        if (threadIdx.x < BINS) sGlobal[threadIdx.x] = base + incl - tot + before[(int64_t)threadIdx.x * stride + blockIdx.x];
+        __syncthreads();                                   // (sScan is used again by the first tile)
     }
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
     for (int64_t t0 = lo; t0 < hi; t0 += kRtTile) {
@@ -1393,7 +1477,7 @@ __global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* 
         __syncthreads();                                   // (also: the previous tile's copy-out has left sKey / sIdx / sBinStart)
         // ---- load the wave's 1024 elements, rank them in order against the wave's counters
         uint32_t k[kRtItems]; int32_t v[kRtItems]; unsigned rnk[kRtItems];
-        const int sub = wave * (kRtTile / kRtWaves);
+        const int sub = wave * (kRtTile / kRtSWaves);
 #pragma unroll
         for (int s = 0; s < kRtItems; ++s) {
             const int j = sub + s * 64 + lane;
@@ -1424,7 +1508,7 @@ __global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* 
         if (threadIdx.x < BINS) {
             unsigned run = 0;
 #pragma unroll
-            for (int w = 0; w < kRtWaves; ++w) { const unsigned c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = run; run += c; }
+            for (int w = 0; w < kRtSWaves; ++w) { const unsigned c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = run; run += c; }
             binCount = run;
         }
         {   // exclusive scan of binCount over the bins (BINS <= 256 == kRtThreads)
@@ -1450,7 +1534,7 @@ __global__ __launch_bounds__(kRtThreads) void rt_scatter_kernel(const uint32_t* 
         }
         __syncthreads();
         // ---- out: element j of the ordered tile is the (j - start of its bin)-th of its bin in this tile
-        for (int j = threadIdx.x; j < tileN; j += kRtThreads) {
+        for (int j = threadIdx.x; j < tileN; j += kRtSThreads) {
             const uint32_t kk = sKey[j];
             const uint32_t d = (kk >> shift) & mask;
             const unsigned g = sGlobal[d] + ((unsigned)j - sBinStart[d]);
@@ -1470,22 +1554,21 @@ static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y
     uint32_t* kB = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
     int32_t* iA = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
     int32_t* iB = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)p.nChunks * (1u << kRtMaxBits) * 4);
+    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4);
     uint32_t* totals = (uint32_t*)scratch;
+    const int stride = kRtMaxChunks;
+    hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, rank, sk, nSub, kA, n, gid, aos);
     const uint32_t* kin = kA; const int32_t* iin = nullptr;
     for (int k = 0; k < p.passes; ++k) {
         const int bins = 1 << p.bits[k];
-        if (k == 0)
-            hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
-                               nSub, kA, n, p.chunk, p.bits[0], counts, gid, aos);
-        else
-            hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
-        hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
+        hipLaunchKernelGGL(rt_hist_kernel, dim3(p.nChunks), dim3(kRtThreads), (size_t)kRtWaves * bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k],
+                           counts, stride);
+        hipLaunchKernelGGL(rt_scan_kernel, dim3((bins + kRtWaves - 1) / kRtWaves), dim3(kRtThreads), 0, st, counts, p.nChunks, stride, bins, totals);
         const bool last = k == p.passes - 1;
         uint32_t* kout = (kin == kA) ? kB : kA;
         int32_t* iout = (iin == iA) ? iB : iA;
         uint32_t* ko = (last && !keepKeys) ? nullptr : kout;
-#define CPF_RT_LAUNCH(B) hipLaunchKernelGGL(rt_scatter_kernel<B>, dim3(p.nChunks), dim3(kRtThreads), 0, st, kin, iin, ko, iout, n, p.chunk, p.shift[k], counts, totals)
+#define CPF_RT_LAUNCH(B) hipLaunchKernelGGL(rt_scatter_kernel<B>, dim3(p.nChunks), dim3(kRtSThreads), 0, st, kin, iin, ko, iout, n, p.chunk, p.shift[k], counts, stride, totals)
         switch (p.bits[k]) {
             case 1: CPF_RT_LAUNCH(1); break; case 2: CPF_RT_LAUNCH(2); break; case 3: CPF_RT_LAUNCH(3); break; case 4: CPF_RT_LAUNCH(4); break;
             case 5: CPF_RT_LAUNCH(5); break; case 6: CPF_RT_LAUNCH(6); break; case 7: CPF_RT_LAUNCH(7); break; default: CPF_RT_LAUNCH(8); break;
