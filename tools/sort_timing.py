@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): time of one re-sort of a cloud that was sorted `--age` steps ago, library key sort ("sort_method"
-0) against the hand-written one (1), on pitzDaily (1e7 particles, two 11-bit passes) and TJunction (4e6, three 8-bit passes).
+"""Developer tool (GPU box): time of one re-sort of a cloud that was sorted `--age` steps ago with each key sort ("sort_method"
+0 = library, 1 = wide digits, 2 = tile reorder, the default), on pitzDaily (1e7 particles, 21 key bits) and TJunction (4e6, 24).
   python tools/sort_timing.py [--age 25] [--D 1.5e-5]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,6 @@ def main():
                 ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), *(p(t) for t in out), n)
             torch.cuda.synchronize()
             row.setdefault("ms_method%d" % method, []).append(round((time.perf_counter() - t0) / 10 * 1e3, 4))
-        row["bytes_per_particle_at_8TBs_frac"] = None
         print(json.dumps(row), flush=True)
         ctx.close()
 
