@@ -1065,7 +1065,14 @@ __global__ void sort_keys_kernel(const double* __restrict__ x, const double* __r
     if (aos) put_aos(aos, i, px, py, pz, gid);
     keys[i] = sort_key_of(px, py, pz, cell[i], cellBox, rank, sk, subBits);
 }
-// the gather out of the 32-byte records: positions and id with one transaction; the cell out of the sorted key, or fetched
+// the gather out of the 32-byte records: positions and id with one transaction; the cell out of the sorted key, or fetched.
+// kGatherItems destinations per thread, all their record loads in flight at once: the chain permutation -> record -> store is
+// two memory latencies long.  MEASURED: 1 / 2 / 4 / 8 destinations per thread: 0.58 / 0.54 / 0.53-0.54 / 0.53-0.55 ms per sort of 1e7
+// (pitzDaily), 0.26-0.27 / 0.244-0.248 / 0.255 / 0.258 of 4e6 (TJunction).
+#ifndef CPF_GATHER_ITEMS
+#define CPF_GATHER_ITEMS 2
+#endif
+constexpr int kGatherItems = CPF_GATHER_ITEMS;
 __global__ __launch_bounds__(kBlock) void gather_aos_kernel(const double* __restrict__ aos, const int32_t* __restrict__ cell,
                                                             double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
                                                             int32_t* __restrict__ ocell, int64_t* __restrict__ ogid,
@@ -1075,21 +1082,35 @@ __global__ __launch_bounds__(kBlock) void gather_aos_kernel(const double* __rest
     //  a 128-byte source line -- whose destinations are neighbours -- are fetched into ONE L2; the grid is 8 * ceil(blocks / 8))
 #if CPF_SORT_XCD
     const int64_t per = gridDim.x >> 3;
-    const int64_t i = (((int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock) + threadIdx.x;
+    const int64_t i0 = (((int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock * kGatherItems) + threadIdx.x;
 #else
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock * kGatherItems + threadIdx.x;
 #endif
-    if (i >= n) return;
-    const int64_t j = perm[i];
-    const uint32_t k = cellFromKey ? keys[i] : 0xFFFFFFFFu;
-    const Pair64* rec = reinterpret_cast<const Pair64*>(aos) + 2 * j;
-    const Pair64 lo = rec[0], hi = rec[1];
-    const int32_t cc = (cellFromKey && k != 0xFFFFFFFFu) ? (int32_t)(k >> nSub) : cell[j];
-    ox[i] = lo.a; oy[i] = lo.b; oz[i] = hi.a;
-    ocell[i] = cc;
-    if (ogid) ogid[i] = __double_as_longlong(hi.b);
+    int64_t j[kGatherItems]; uint32_t k[kGatherItems];
+#pragma unroll
+    for (int u = 0; u < kGatherItems; ++u) {
+        const int64_t i = i0 + (int64_t)u * kBlock;
+        j[u] = i < n ? perm[i] : 0;
+        k[u] = (cellFromKey && i < n) ? keys[i] : 0xFFFFFFFFu;
+    }
+    Pair64 lo[kGatherItems], hi[kGatherItems]; int32_t cc[kGatherItems];
+#pragma unroll
+    for (int u = 0; u < kGatherItems; ++u) {
+        const Pair64* rec = reinterpret_cast<const Pair64*>(aos) + 2 * j[u];
+        lo[u] = rec[0]; hi[u] = rec[1];
+        cc[u] = (cellFromKey && k[u] != 0xFFFFFFFFu) ? (int32_t)(k[u] >> nSub) : cell[j[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kGatherItems; ++u) {
+        const int64_t i = i0 + (int64_t)u * kBlock;
+        if (i < n) {
+            ox[i] = lo[u].a; oy[i] = lo[u].b; oz[i] = hi[u].a;
+            ocell[i] = cc[u];
+            if (ogid) ogid[i] = __double_as_longlong(hi[u].b);
+        }
+    }
 }
-static inline dim3 grid8_for(int64_t n) { const int64_t b = (n + kBlock - 1) / kBlock; return dim3((unsigned)((b + 7) / 8 * 8)); }
+static inline dim3 grid8_for(int64_t n) { const int64_t b = (n + kBlock * kGatherItems - 1) / (kBlock * kGatherItems); return dim3((unsigned)((b + 7) / 8 * 8)); }
 __global__ void copy_cells_kernel(int32_t* __restrict__ cell, const int32_t* __restrict__ sc, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) cell[i] = sc[i];
