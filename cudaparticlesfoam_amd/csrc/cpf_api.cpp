@@ -40,8 +40,8 @@ struct cpf_context {
     int64_t nSecondRecords = 0;     // second records (cells with 7..12 slots), behind the nCells first ones
     float* d_cellBox = nullptr;     // per-cell boxes for the sort key
     int32_t* d_curveRank = nullptr; // per-cell rank along the Morton curve: the sort's major key for sparse clouds ("sort_curve")
-    int sortMethod = 2;             // "sort_method": the (key, index) sort: 2 = this library's tile-reorder radix sort (cpf_kernels.hip, rt_sort_pairs),
-                                    // 1 = its wide-digit one (rs_sort_pairs), 0 = hipcub's; the same order all three
+    int sortMethod = 2;             // "sort_method": the (key, index) sort: 2 = this library's radix sort (cpf_kernels.hip, rt_sort_pairs), 0 = hipcub's;
+                                    // the same order either way
     int sortCurve = -1;             // "sort_curve": -1 = Morton rank when the cloud has fewer than 8 particles per cell, 0 = cell id, 1 = Morton rank
     int32_t* d_binOff = nullptr;
     int32_t* d_binCells = nullptr;
@@ -902,7 +902,7 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         return CPF_OK;
     }
     if (k == "sort_method") {
-        CPF_REQUIRE(ctx, value == 0 || value == 1 || value == 2, CPF_ERR_ARG, "sort_method must be 0 (library radix sort), 1 or 2 (hand-written: wide digits / tile reorder)");
+        CPF_REQUIRE(ctx, value == 0 || value == 2, CPF_ERR_ARG, "sort_method must be 2 (this library's radix sort) or 0 (hipcub's)");
         ctx->sortMethod = (int)value;
         return CPF_OK;
     }

@@ -1117,256 +1117,30 @@ __global__ void copy_cells_kernel(int32_t* __restrict__ cell, const int32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// The key sort, hand-written (round 5, option "sort_method" 1; the default stays hipcub::DeviceRadixSort, see MEASURED below):
-// a stable LSD radix sort of (key, index) pairs with WIDE digits -- ceil(endBit / 11) passes,
-// i.e. two for pitzDaily's 21 key bits where the library's 8-bit digits need three -- as chunked counting sorts:
-//   * the cloud is cut into up to 512 contiguous chunks, one workgroup (8 waves) each, every wave owning a contiguous eighth
-//     of its chunk: stability then needs no ordering BETWEEN waves -- wave w's elements simply rank behind those of the waves
-//     before it, through private per-wave counters in LDS ([8][2^bits] words: 64 KB at 11 bits);
-//   * per pass: per-chunk digit counts (pass 1: by the kernel that builds the keys, no extra read), one column scan over the
-//     [chunks][2^bits] matrix, one scatter kernel -- wave histogram, base = bin start + chunks before + waves before, then
-//     the wave walks its elements again in order: lanes with equal digits find each other with one ballot per digit bit,
-//     rank = base + lanes of the group before me, the group's first lane advances the wave's counter;
-//   * the first pass reads no index array (the index is the position), the last writes no keys (the gather reads the cell
-//     where it reads the position).
-// Traffic per particle for two passes: 28 + 4 (keys) + 4 + 8 (pass 1) + 4 + 8 + 4 (pass 2) + 4 + 36 + 36 (gather) = 136 B
-// against ~190 B with three library passes, an index fill and keys carried to the end.
-// MEASURED (profiles/r05_sort_breakdown.json; 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago): pass 1 (the low digit
-// is the sub-cell position: every lane of a wave writes to a different bin, 8 bytes per 64-byte line) 190 us, pass 2 (the high
-// digit is the cell: long runs, coalesced) 75 -- 0.65 ms per sort against the library path's 0.62.  The wide first pass loses to
-// write amplification what it saves in passes.  Three 8-bit passes on TJunction's 24 key bits: 0.40 ms against the library's
-// 0.27 -- hence not the default.
+// The key sort, hand-written (round 5; option "sort_method" 2, the default; 0 = hipcub::DeviceRadixSort): a stable LSD radix sort
+// of (key, index) pairs with digits of <= 8 bits (as many passes as the library's) as chunked counting sorts.
+//   * The cloud is cut into up to 1024 contiguous chunks of whole 4096-element tiles, one workgroup (4 waves) each.  Inside a tile
+//     wave w owns elements [1024 w, 1024 (w + 1)) and ranks them in order against private per-wave counters in LDS: stability then
+//     needs no ordering BETWEEN waves -- wave w's elements rank behind those of the waves before it.  Lanes with equal digits find
+//     each other with one ballot per digit bit; rank = the counter + the peers before me; the group's first lane advances the counter.
+//   * One pass over [wave][bin] turns the counters into first positions; the tile is written to LDS in digit order and copied out
+//     with the bins' running global positions, so that every bin receives ONE contiguous run per tile (a first version with
+//     11-bit digits and no reorder wrote 8 bytes per 64-byte line on a random digit: 0.65 ms per 1e7; docs/experiments.md).
+//   * Per pass: rt_hist_kernel (per-chunk digit counts, bin-major: 16-byte loads, a tile's worth in flight per thread),
+//     rt_scan_kernel (one wave per bin over the chunks), rt_scatter_kernel.  The first pass reads no index array (the index is the
+//     position), the last writes no keys unless the gather wants the cell from them.
+// MEASURED (profiles/r05_sort_breakdown.json; 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago): counts 10-13 us, scan
+// 5, scatter 56 per pass -- 0.54 ms per sort against 0.64 with the library's onesweep passes (88 us each); TJunction, 4e6 particles,
+// 24 key bits: 0.24 against 0.27.  The scatter is bound by its own ranking arithmetic (8 ballots and ~65 vector instructions per
+// element: coalesced stores instead of the scatter, or no loads at all, change its time by < 7 %); 256 x 16, 256 x 8, 512 x 8 and
+// 512 x 16 threads x items tie.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRsThreads = 512, kRsWaves = kRsThreads / 64, kRsMaxChunks = 512, kRsMaxBits = 11;
-struct RsPlan {
+struct SortPlan {
     int passes, bits[4], shift[4];
     int nChunks;
-    int64_t chunk;       // elements per chunk: a multiple of 64 * kRsWaves
+    int64_t chunk;       // elements per chunk: whole tiles
 };
-static RsPlan rs_plan(int64_t n, int endBit) {
-    RsPlan p{};
-    p.passes = (endBit + kRsMaxBits - 1) / kRsMaxBits;
-    const int d = (endBit + p.passes - 1) / p.passes;
-    for (int k = 0; k < p.passes; ++k) { p.shift[k] = k * d; p.bits[k] = std::min(d, endBit - k * d); }
-    const int64_t unit = 64 * kRsWaves;
-    int64_t chunk = (n + kRsMaxChunks - 1) / kRsMaxChunks;
-    chunk = std::max<int64_t>(unit * 4, (chunk + unit - 1) / unit * unit);       // at least 4 wave-steps per wave
-    p.chunk = chunk;
-    p.nChunks = (int)((n + chunk - 1) / chunk);
-    return p;
-}
-static inline size_t rs_al(size_t b) { return (b + 255) & ~(size_t)255; }
-static size_t rs_scratch_bytes(int64_t n, int endBit) {
-    const RsPlan p = rs_plan(n, endBit);
-    const int maxBits = *std::max_element(p.bits, p.bits + p.passes);
-    // two (key, index) buffers for the ping-pong, the count matrix, the bin totals, one staging array (in-place form)
-    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4) + rs_al(((size_t)1 << maxBits) * 4) + rs_al(32 * (size_t)n);
-}
-
-// keys of chunk blockIdx.x + its counts of the FIRST pass's digit: counts[chunk][bin]
-__global__ __launch_bounds__(kRsThreads) void rs_keys_hist_kernel(const double* __restrict__ x, const double* __restrict__ y,
-                                                                  const double* __restrict__ z, const int32_t* __restrict__ cell,
-                                                                  const float* __restrict__ cellBox, const int32_t* __restrict__ rank,
-                                                                  SubKey sk, int subBits, uint32_t* __restrict__ keys, int64_t n,
-                                                                  int64_t chunk, int bits, uint32_t* __restrict__ counts,
-                                                                  const int64_t* __restrict__ gid, double* __restrict__ aos) {
-    extern __shared__ unsigned sHist[];
-    const int bins = 1 << bits;
-    for (int b = threadIdx.x; b < bins; b += kRsThreads) sHist[b] = 0u;
-    __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    const uint32_t mask = (uint32_t)bins - 1u;
-    constexpr int U = 4;
-    for (int64_t base = lo; base < hi; base += (int64_t)U * kRsThreads) {
-        double px[U], py[U], pz[U]; int32_t pc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = base + (int64_t)u * kRsThreads + threadIdx.x;
-            pc[u] = -1; px[u] = py[u] = pz[u] = 0.0;
-            if (i < hi) { px[u] = x[i]; py[u] = y[i]; pz[u] = z[i]; pc[u] = cell[i]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = base + (int64_t)u * kRsThreads + threadIdx.x;
-            if (i < hi) {
-                const uint32_t k = sort_key_of(px[u], py[u], pz[u], pc[u], cellBox, rank, sk, subBits);
-                keys[i] = k;
-                if (aos) put_aos(aos, i, px[u], py[u], pz[u], gid);
-                atomicAdd(&sHist[k & mask], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t* row = counts + (int64_t)blockIdx.x * bins;
-    for (int b = threadIdx.x; b < bins; b += kRsThreads) row[b] = sHist[b];
-}
-
-// counts[chunk][bin] of a later pass's digit.  The keys are sorted by the lower digits by then and the cloud is kept almost
-// sorted: long runs of equal digits -- one LDS atomic per run of a wave instead of one per lane
-__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t chunk, int shift,
-                                                             int bits, uint32_t* __restrict__ counts) {
-    extern __shared__ unsigned sHist[];
-    const int bins = 1 << bits;
-    for (int b = threadIdx.x; b < bins; b += kRsThreads) sHist[b] = 0u;
-    __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    const uint32_t mask = (uint32_t)bins - 1u;
-    const int lane = threadIdx.x & 63;
-    constexpr int B = 4;
-    for (int64_t base0 = lo; base0 < hi; base0 += (int64_t)B * kRsThreads) {     // (wave-uniform trip counts: chunk is a multiple of the block)
-        uint32_t kk[B];
-#pragma unroll
-        for (int u = 0; u < B; ++u) { const int64_t i = base0 + (int64_t)u * kRsThreads + threadIdx.x; kk[u] = i < hi ? keys[i] : 0u; }
-#pragma unroll
-        for (int u = 0; u < B; ++u) {
-            const int64_t i = base0 + (int64_t)u * kRsThreads + threadIdx.x;
-            const bool live = i < hi;
-            const uint32_t d = (kk[u] >> shift) & mask;
-            bool todo = live;
-#pragma unroll 1
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long m = __ballot(todo);
-                if (m == 0ull) break;
-                const int leader = __ffsll((long long)m) - 1;
-                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
-                const unsigned long long same = __ballot(todo && d == dl);
-                if (lane == leader) atomicAdd(&sHist[dl], (unsigned)__popcll(same));
-                if (d == dl) todo = false;
-            }
-            if (todo) atomicAdd(&sHist[d], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t* row = counts + (int64_t)blockIdx.x * bins;
-    for (int b = threadIdx.x; b < bins; b += kRsThreads) row[b] = sHist[b];
-}
-
-// counts[chunk][bin] -> number of the bin's elements in the chunks BEFORE this one (in place); totals[bin] = the bin's size.
-// A block takes 64 bins; its 16 row groups split the chunks (lane = bin: every row read is one 256-byte segment).
-constexpr int kRsScanGroups = 16;
-__global__ __launch_bounds__(64 * kRsScanGroups) void rs_colscan_kernel(uint32_t* __restrict__ counts, int nChunks, int bins,
-                                                                       uint32_t* __restrict__ totals) {
-    __shared__ uint32_t sSum[kRsScanGroups][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int bin = blockIdx.x * 64 + lane;
-    const int per = (nChunks + kRsScanGroups - 1) / kRsScanGroups;
-    const int r0 = min(nChunks, grp * per), r1 = min(nChunks, r0 + per);
-    uint32_t s = 0;
-    if (bin < bins)
-        for (int r = r0; r < r1; ++r) s += counts[(int64_t)r * bins + bin];
-    sSum[grp][lane] = s;
-    __syncthreads();
-    uint32_t run = 0;
-    for (int g = 0; g < grp; ++g) run += sSum[g][lane];
-    if (bin < bins) {
-        for (int r = r0; r < r1; ++r) {
-            const uint32_t v = counts[(int64_t)r * bins + bin];
-            counts[(int64_t)r * bins + bin] = run;
-            run += v;
-        }
-        if (grp == kRsScanGroups - 1) totals[bin] = run;
-    }
-}
-
-// One pass: every element of chunk blockIdx.x goes to (start of its bin) + (the bin's elements in earlier chunks) + (in the
-// earlier waves of this chunk) + (earlier in this wave).  idxIn == nullptr: the element's index is its position (first
-// pass); keysOut == nullptr: the keys are not needed any more (last pass).
-__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ idxIn,
-                                                                uint32_t* __restrict__ keysOut, int32_t* __restrict__ idxOut, int64_t n,
-                                                                int64_t chunk, int shift, int bits, const uint32_t* __restrict__ before,
-                                                                const uint32_t* __restrict__ totals) {
-    extern __shared__ unsigned sMem[];                          // [kRsWaves][bins] wave counters | [bins] bin starts
-    const int bins = 1 << bits;
-    unsigned* const sCnt = sMem;
-    unsigned* const sStart = sMem + kRsWaves * bins;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t mask = (uint32_t)bins - 1u;
-    for (int b = threadIdx.x; b < kRsWaves * bins; b += kRsThreads) sCnt[b] = 0u;
-    // bin starts = exclusive scan of the totals: every thread sums a run of bins, the runs' sums are scanned by thread 0's wave
-    __shared__ unsigned sRun[kRsThreads];
-    const int perT = (bins + kRsThreads - 1) / kRsThreads;
-    const int b0 = min(bins, (int)threadIdx.x * perT), b1 = min(bins, b0 + perT);
-    unsigned mine = 0;
-    for (int b = b0; b < b1; ++b) mine += totals[b];
-    sRun[threadIdx.x] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int t = 0; t < kRsThreads; ++t) { const unsigned v = sRun[t]; sRun[t] = run; run += v; }
-    }
-    __syncthreads();
-    {
-        unsigned run = sRun[threadIdx.x];
-        for (int b = b0; b < b1; ++b) { sStart[b] = run; run += totals[b]; }
-    }
-    // phase 1: the wave's own digit counts over its eighth of the chunk
-    const int64_t sub = chunk / kRsWaves;
-    const int64_t lo = (int64_t)blockIdx.x * chunk + (int64_t)wave * sub, hi = min(n, lo + sub);
-    unsigned* const myCnt = sCnt + wave * bins;
-    __syncthreads();
-    constexpr int B = 8;                                        // independent loads in flight per lane
-    for (int64_t base = lo; base < hi; base += 64 * B) {
-        uint32_t kk[B];
-#pragma unroll
-        for (int u = 0; u < B; ++u) { const int64_t i = base + 64 * u + lane; kk[u] = i < hi ? keysIn[i] : 0u; }
-#pragma unroll
-        for (int u = 0; u < B; ++u) { const int64_t i = base + 64 * u + lane; if (i < hi) atomicAdd(&myCnt[(kk[u] >> shift) & mask], 1u); }
-    }
-    __syncthreads();
-    // phase 2: counts -> first position of (wave, bin)
-    const uint32_t* const row = before + (int64_t)blockIdx.x * bins;
-    for (int b = threadIdx.x; b < bins; b += kRsThreads) {
-        unsigned run = sStart[b] + row[b];
-#pragma unroll
-        for (int w = 0; w < kRsWaves; ++w) { const unsigned v = sCnt[w * bins + b]; sCnt[w * bins + b] = run; run += v; }
-    }
-    __syncthreads();
-    // phase 3: the wave walks its elements again, in order
-    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (int64_t base0 = lo; base0 < hi; base0 += 64 * B) {
-        uint32_t kk[B]; int32_t ss[B];
-#pragma unroll
-        for (int u = 0; u < B; ++u) {
-            const int64_t i = base0 + 64 * u + lane;
-            kk[u] = i < hi ? keysIn[i] : 0u;
-            ss[u] = (i < hi && idxIn) ? idxIn[i] : (int32_t)i;
-        }
-#pragma unroll
-        for (int u = 0; u < B; ++u) {
-            const int64_t i = base0 + 64 * u + lane;
-            const bool live = i < hi;
-            const uint32_t k = kk[u];
-            const uint32_t d = (k >> shift) & mask;
-            unsigned long long same = __ballot(live);           // lanes with my digit: one ballot per digit bit
-            for (int b = 0; b < bits; ++b) {
-                const unsigned long long one = __ballot(((d >> b) & 1u) != 0u);
-                same &= ((d >> b) & 1u) ? one : ~one;
-            }
-            if (live) {
-                const unsigned first = myCnt[d];                 // (every lane of the group reads it before its first lane writes)
-                const unsigned pos = first + (unsigned)__popcll(same & lt);
-                if ((same & lt) == 0ull) myCnt[d] = first + (unsigned)__popcll(same);
-                if (keysOut) keysOut[pos] = k;
-                idxOut[pos] = ss[u];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// "sort_method" 2: the same chunked counting sort with NARROW digits (<= 8 bits: as many passes as the library's) and the elements
-// of a 4096-element tile put in digit order in LDS before they leave, so that every bin receives one contiguous run per tile
-// (16 elements = two 64-byte runs on a random digit; method 1 writes 8 bytes per line there).  A workgroup of 4 waves owns a chunk
-// of whole tiles; inside a tile wave w owns elements [1024 w, 1024 (w + 1)) and ranks them in order against private counters
-// (stable without ordering the waves), one pass over [wave][bin] turns the counters into first positions, the tile is written
-// to LDS in digit order and copied out with the bins' running global positions.
-// Per pass: rt_hist_kernel (per-chunk digit counts, bin-major: 16-byte loads, a tile's worth in flight per thread), rt_scan_kernel
-// (one wave per bin over the chunks), rt_scatter_kernel.  THE DEFAULT since round 5.  MEASURED (profiles/r05_sort_breakdown.json;
-// 1e7 particles on pitzDaily sorted 25 cycles of D = 1.5e-5 ago): counts 10 us, scan 5, scatter 56 per pass -- 0.54 ms per sort
-// against 0.64 with the library's onesweep passes (88 us each); TJunction, 4e6 particles, 24 key bits: 0.25 against 0.27.  The
-// scatter is bound by its own ranking arithmetic (8 ballots and ~65 vector instructions per element: coalesced stores instead of
-// the scatter, or no loads at all, change its time by < 7 %); 256 x 16, 256 x 8, 512 x 8 and 512 x 16 threads x items tie.
-// ------------------------------------------------------------------------------------------------
+static inline size_t sort_al(size_t b) { return (b + 255) & ~(size_t)255; }
 #ifndef CPF_RT_STHREADS
 #define CPF_RT_STHREADS 256
 #endif
@@ -1376,8 +1150,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 constexpr int kRtThreads = 256, kRtWaves = 4, kRtMaxBits = 8, kRtMaxChunks = 1024;        // the counting and scanning kernels
 constexpr int kRtSThreads = CPF_RT_STHREADS, kRtSWaves = kRtSThreads / 64, kRtItems = CPF_RT_SITEMS, kRtTile = kRtSThreads * kRtItems;   // the scatter
 static_assert(kRtTile % (kRtThreads * 4) == 0, "a tile is whole batches of the counting kernel's 16-byte loads");
-static RsPlan rt_plan(int64_t n, int endBit) {
-    RsPlan p{};
+static SortPlan rt_plan(int64_t n, int endBit) {
+    SortPlan p{};
     p.passes = (endBit + kRtMaxBits - 1) / kRtMaxBits;
     const int d = (endBit + p.passes - 1) / p.passes;
     for (int k = 0; k < p.passes; ++k) { p.shift[k] = k * d; p.bits[k] = std::min(d, endBit - k * d); }
@@ -1388,9 +1162,9 @@ static RsPlan rt_plan(int64_t n, int endBit) {
     return p;
 }
 static size_t rt_scratch_bytes(int64_t n, int endBit) {
-    const RsPlan p = rt_plan(n, endBit);
+    const SortPlan p = rt_plan(n, endBit);
     (void)p;
-    return rs_al(4 * (size_t)n) * 4 + rs_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4) + rs_al((1u << kRtMaxBits) * 4) + rs_al(32 * (size_t)n);
+    return sort_al(4 * (size_t)n) * 4 + sort_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4) + sort_al((1u << kRtMaxBits) * 4) + sort_al(32 * (size_t)n);
 }
 
 // counts of one digit per chunk, BIN-major: counts[bin * stride + chunk].  A chunk is whole tiles of 4096 keys, the key buffers
@@ -1570,12 +1344,12 @@ __global__ __launch_bounds__(kRtSThreads) void rt_scatter_kernel(const uint32_t*
 static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell, const int64_t* gid, double* aos,
                                 const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
                                 char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
-    const RsPlan p = rt_plan(n, endBit);
-    uint32_t* kA = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    uint32_t* kB = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    int32_t* iA = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    int32_t* iB = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4);
+    const SortPlan p = rt_plan(n, endBit);
+    uint32_t* kA = (uint32_t*)scratch; scratch += sort_al(4 * (size_t)n);
+    uint32_t* kB = (uint32_t*)scratch; scratch += sort_al(4 * (size_t)n);
+    int32_t* iA = (int32_t*)scratch; scratch += sort_al(4 * (size_t)n);
+    int32_t* iB = (int32_t*)scratch; scratch += sort_al(4 * (size_t)n);
+    uint32_t* counts = (uint32_t*)scratch; scratch += sort_al((size_t)kRtMaxChunks * (1u << kRtMaxBits) * 4);
     uint32_t* totals = (uint32_t*)scratch;
     const int stride = kRtMaxChunks;
     hipLaunchKernelGGL(sort_keys_kernel, grid_for(n), dim3(kBlock), 0, st, x, y, z, cell, cellBox, rank, sk, nSub, kA, n, gid, aos);
@@ -1602,45 +1376,6 @@ static hipError_t rt_sort_pairs(hipStream_t st, const double* x, const double* y
     return hipGetLastError();
 }
 
-static hipError_t rs_sort_pairs(hipStream_t st, const double* x, const double* y, const double* z, const int32_t* cell, const int64_t* gid, double* aos,
-                                const float* cellBox, const int32_t* rank, const SubKey& sk, int nSub, int64_t n, int endBit,
-                                char* scratch, bool keepKeys, const uint32_t** keysSorted, const int32_t** perm) {
-    const RsPlan p = rs_plan(n, endBit);
-    const int maxBits = *std::max_element(p.bits, p.bits + p.passes);
-    uint32_t* kA = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    uint32_t* kB = (uint32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    int32_t* iA = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    int32_t* iB = (int32_t*)scratch; scratch += rs_al(4 * (size_t)n);
-    uint32_t* counts = (uint32_t*)scratch; scratch += rs_al((size_t)p.nChunks * ((size_t)1 << maxBits) * 4);
-    uint32_t* totals = (uint32_t*)scratch;
-    static bool attrSet = false;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rs_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (kRsWaves + 1) * (1 << kRsMaxBits) * 4);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
-    const uint32_t* kin = kA; const int32_t* iin = nullptr;
-    for (int k = 0; k < p.passes; ++k) {
-        const int bins = 1 << p.bits[k];
-        if (k == 0)
-            hipLaunchKernelGGL(rs_keys_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, x, y, z, cell, cellBox, rank, sk,
-                               nSub, kA, n, p.chunk, p.bits[0], counts, gid, aos);
-        else
-            hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)bins * 4, st, kin, n, p.chunk, p.shift[k], p.bits[k], counts);
-        hipLaunchKernelGGL(rs_colscan_kernel, dim3((bins + 63) / 64), dim3(64 * kRsScanGroups), 0, st, counts, p.nChunks, bins, totals);
-        const bool last = k == p.passes - 1;
-        uint32_t* kout = (kin == kA) ? kB : kA;
-        int32_t* iout = (iin == iA) ? iB : iA;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(p.nChunks), dim3(kRsThreads), (size_t)(kRsWaves + 1) * bins * 4, st, kin, iin,
-                           (last && !keepKeys) ? nullptr : kout, iout, n, p.chunk, p.shift[k], p.bits[k], counts, totals);
-        kin = kout; iin = iout;
-    }
-    *keysSorted = keepKeys ? kin : nullptr;
-    *perm = iin;
-    return hipGetLastError();
-}
-
 size_t sort_scratch_bytes(int64_t n, int endBit) {
     size_t tmp = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
@@ -1648,7 +1383,7 @@ size_t sort_scratch_bytes(int64_t n, int endBit) {
     // keys in + keys out + iota + perm + one staging array (32 bytes per particle: the (x, y, z, id) records; also serves the
     // velocity triples)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return std::max({al(tmp) + al(4 * (size_t)n) * 4 + al(32 * (size_t)n), rs_scratch_bytes(n, endBit), rt_scratch_bytes(n, endBit)});
+    return std::max(al(tmp) + al(4 * (size_t)n) * 4 + al(32 * (size_t)n), rt_scratch_bytes(n, endBit));
 }
 
 // Out arrays (ox ... ogid) given: the sorted cloud is written there and the input arrays are left alone -- no staging,
@@ -1683,16 +1418,15 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
     const int nSub = subBits[0] + subBits[1] + subBits[2];
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     if (method != 0) {
-        // ---- the hand-written key sort (see rs_sort_pairs); the same gathers as the library path below
-        const size_t need = method == 2 ? rt_scratch_bytes(n, endBit) : rs_scratch_bytes(n, endBit);
+        // ---- the hand-written key sort (rt_sort_pairs); the same gathers as the library path below
+        const size_t need = rt_scratch_bytes(n, endBit);
         if (need > scratchBytes) return hipErrorInvalidValue;
-        double* stage = (double*)((char*)scratch + need - rs_al(32 * (size_t)n));
+        double* stage = (double*)((char*)scratch + need - sort_al(32 * (size_t)n));
         double* aos = CPF_SORT_AOS ? stage : nullptr;
         const bool cellFromKey = rank == nullptr && endBit < 32;
         const bool keepKeys = occupied != nullptr || (aos && cellFromKey);
         const uint32_t* keysSorted = nullptr; const int32_t* perm = nullptr;
-        hipError_t e = method == 2 ? rt_sort_pairs(st, x, y, z, cell, gid, aos, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, keepKeys, &keysSorted, &perm)
-                                   : rs_sort_pairs(st, x, y, z, cell, gid, aos, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, keepKeys, &keysSorted, &perm);
+        hipError_t e = rt_sort_pairs(st, x, y, z, cell, gid, aos, cellBox, rank, sk, nSub, n, endBit, (char*)scratch, keepKeys, &keysSorted, &perm);
         if (e != hipSuccess) return e;
         if (occupied != nullptr) {
             e = hipMemsetAsync(occupied, 0, 16, st);
@@ -1708,8 +1442,8 @@ hipError_t sort_by_cell(hipStream_t st, double* x, double* y, double* z, int32_t
                                    (const uint32_t*)nullptr, nSub, n, false);
         } else if (aos) {
             // (the index buffer the last pass did not write is free)
-            int32_t* iA = (int32_t*)((char*)scratch + 2 * rs_al(4 * (size_t)n));
-            int32_t* iB = (int32_t*)((char*)iA + rs_al(4 * (size_t)n));
+            int32_t* iA = (int32_t*)((char*)scratch + 2 * sort_al(4 * (size_t)n));
+            int32_t* iB = (int32_t*)((char*)iA + sort_al(4 * (size_t)n));
             int32_t* spare = perm == iA ? iB : iA;
             hipLaunchKernelGGL(gather_aos_kernel, grid8_for(n), dim3(kBlock), 0, st, aos, cell, x, y, z, spare, gid, perm, keysSorted, nSub, n, cellFromKey);
             hipLaunchKernelGGL(copy_cells_kernel, grid_for(n), dim3(kBlock), 0, st, cell, spare, n);

@@ -262,11 +262,10 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "coop_max_cells" test hook: kernel 3 addresses cell records with 32-bit byte offsets and is not used for meshes of
  *                   more than 2^24 cells (kernel 4 runs instead); a smaller limit exercises that switch on small meshes
  *   "sort_method"   (2) the (key, index) sort behind cpf_sort_by_cell*: 2 = this library's stable radix sort with 8-bit digits and an
- *                   LDS tile reorder (csrc/cpf_kernels.hip, rt_sort_pairs), 1 = its first version with 11-bit digits (two passes over
- *                   pitzDaily's 21 key bits; rs_sort_pairs), 0 = hipcub::DeviceRadixSort.  The same order whichever, particle for
- *                   particle (tests).  Measured, round 5, 1e7 particles sorted 25 cycles of diffusion ago: 0.54 / 0.67 / 0.64 ms per
- *                   sort -- 0.30 ms of it building the keys and gathering the particle records, which all share; on TJunction's 24
- *                   key bits (4e6 particles) 0.24 / 0.40 / 0.27 ms
+ *                   LDS tile reorder (csrc/cpf_kernels.hip, rt_sort_pairs), 0 = hipcub::DeviceRadixSort.  The same order either way,
+ *                   particle for particle (tests).  Measured, round 5, 1e7 particles sorted 25 cycles of diffusion ago: 0.54 / 0.64
+ *                   ms per sort -- 0.30 ms of it building the keys and gathering the particle records, which both share; on
+ *                   TJunction's 24 key bits (4e6 particles) 0.24 / 0.27 ms
  *   "sort_curve"    (-1) the sort's major key: 0 = the cell id, 1 = the cell's rank along a Morton curve through the cell centres
  *                   (built at cpf_set_mesh), -1 = the rank for sparse clouds (fewer than 8 particles per cell: the step kernel is
  *                   bound by record traffic there and a cell's neighbours in all three directions should be close by in the

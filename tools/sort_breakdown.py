@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses a rocprofv3 kernel trace of tools/sort_timing.py into profiles/rNN_sort_breakdown.json: the kernels of one re-sort
-in launch order, averaged over every sort of each kind (library / wide digits / tile reorder) and case.
+in launch order, averaged over every sort of each kind (library / hand-written) and case.
   rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python3 tools/sort_timing.py
   python tools/sort_breakdown.py /tmp/prof/.../*_kernel_trace.csv profiles/r05_sort_breakdown.json"""
 import collections, csv, json, re, sys
@@ -33,7 +33,7 @@ def main():
             if not seq or (seq[-1][2] > 9e6) != case.startswith("pitz"):
                 continue
             kind = "0 (hipcub)" if any("rocprim" in c[0] for c in seq) else ("2 (tile reorder)" if any("rt_scatter" in c[0] for c in seq)
-                                                                             else "1 (wide digits)")
+                                                                             else "1 (wide digits, removed)")
             acc.setdefault("%s, sort_method %s" % (case, kind), []).append([(a, b) for a, b, _ in seq])
     cases = {}
     for k, seqs in acc.items():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): time of one re-sort of a cloud that was sorted `--age` steps ago with each key sort ("sort_method"
-0 = library, 1 = wide digits, 2 = tile reorder, the default), on pitzDaily (1e7 particles, 21 key bits) and TJunction (4e6, 24).
+0 = library, 2 = this library's own, the default), on pitzDaily (1e7 particles, 21 key bits) and TJunction (4e6, 24).
   python tools/sort_timing.py [--age 25] [--D 1.5e-5]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ def main():
         torch.cuda.synchronize()
         out = [torch.empty_like(t) for t in (x, y, z, c, g)]
         row = {"case": case, "particles": n, "cells": mesh.n_cells, "age_steps": a.age, "D": a.D}
-        for method in (0, 1, 2, 0, 1, 2):
+        for method in (0, 2, 0, 2):
             ctx.set_option("sort_method", method)
             ctx.sort_by_cell_dev_to(p(x), p(y), p(z), p(c), p(g), *(p(t) for t in out), n); torch.cuda.synchronize()
             t0 = time.perf_counter()
