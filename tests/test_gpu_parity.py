@@ -1377,3 +1377,45 @@ def test_hand_written_key_sort_gives_the_library_sort_order(case, setup, gpu_ctx
         if case != "box3d_curve" and n >= 8 * mesh.n_cells:                 # (sparser clouds are ordered along the Morton curve)
             assert (np.diff(cs[:k].astype(np.int64)) >= 0).all()
     ctx.use_own_stream()
+
+
+@pytest.mark.parametrize("key_bits", [-1, 0, 1, 10, 21, 111, 222, 322, 444])
+def test_hand_written_key_sort_over_digit_widths_and_ragged_sizes(key_bits, gpu_ctx_factory):
+    """The same comparison (this library's radix sort == hipcub's, particle for particle) across every digit width the pass plan
+    produces: the sub-cell key layout ("sort_key_bits" bx by bz) moves the key's length from 8 to 20 bits on a 60-cell box, i.e.
+    1 to 3 passes with last digits of 1 to 8 bits; sizes sit on and around tile (4096) and chunk boundaries; a fifth of the
+    particles are lost (all-ones key: the tail)."""
+    import torch
+    from cudaparticlesfoam_amd.cases import box_mesh
+    dev = torch.device("cuda", 0)
+    mesh = box_mesh(5, 4, 3) if key_bits >= 0 else box_mesh(1, 1, 1)       # (-1: one cell, no sub-cell bits: a 2-bit key)
+    ctx = gpu_ctx_factory(); ctx.set_mesh(mesh)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("sort_key_bits", max(key_bits, 0))
+    p = lambda t: t.data_ptr()   # noqa: E731
+    rng = np.random.default_rng(key_bits + 1)
+    sizes = [3, 4095, 4096, 4097, 8193, 12288, 12289, 65537] + [int(v) for v in rng.integers(2, 300_000, size=4)]
+    for n in sizes:
+        xyz = rng.uniform([-0.6, 0, 0], [5, 4, 3] if key_bits >= 0 else [1, 1, 1], size=(n, 3))   # x < 0: outside the box
+        base = [torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3)]
+        c0 = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx.locate_initial_dev(p(base[0]), p(base[1]), p(base[2]), p(c0), n)
+        g0 = torch.from_numpy(rng.permutation(n).astype(np.int64)).to(dev)
+        res = {}
+        for method in (0, 2):
+            ctx.set_option("sort_method", method)
+            out = [torch.zeros_like(t) for t in (*base, c0, g0)]
+            ctx.sort_by_cell_dev_to(p(base[0]), p(base[1]), p(base[2]), p(c0), p(g0), *(p(t) for t in out), n)
+            torch.cuda.synchronize()
+            res[method] = [t.cpu().numpy() for t in out]
+        for a, b in zip(res[0], res[2]):
+            assert np.array_equal(a, b), (key_bits, n)
+        cs = res[2][3]
+        k = int((cs >= 0).sum())
+        assert 0 < k < n or n < 10
+        assert (cs[:k] >= 0).all() and (cs[k:] < 0).all()
+        if n >= 8 * mesh.n_cells:                                              # (sparser clouds are ordered along the Morton curve)
+            assert (np.diff(cs[:k].astype(np.int64)) >= 0).all()
+        assert np.array_equal(np.sort(res[2][4]), np.arange(n))               # a permutation: nobody lost, nobody twice
+    ctx.use_own_stream()
+
