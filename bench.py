@@ -94,6 +94,9 @@ def parse(argv=None):
     ap.add_argument("--brownian-extra", type=int, default=20,
                     help="after the timed region (N = 1): that many launches with the tutorial's D = 1.5e-5, reported "
                          "as config.brownian; 0 = skip")
+    ap.add_argument("--no-fused-tutorial", action="store_true",
+                    help="leave the fused launches (fused_8_cycles_per_launch, fragment_calls) out of brownian_steady / tjunction_as_run: "
+                         "a profile of the run then holds that kernel's single-cycle launches only")
     ap.add_argument("--brownian-steady-steps", type=int, default=100,
                     help="after the timed region (N = 1): a freshly seeded cloud of the same size stepped that many times with "
                          "the tutorial's D = 1.5e-5 and the fragments' own sort interval for diffusing clouds (25), sorts "
@@ -628,6 +631,8 @@ class GpuMachine:
         # two output points fused into one launch), on a second fresh cloud in the same state as the one above started from
         from cudaparticlesfoam_amd import _lib as L
         del cl
+        if args.no_fused_tutorial:
+            return r
         cl = self._fresh_cloud(cloud.n, box, 2025, sort_interval=0)
         cl.step(dt, 10, D=Db)
         cl.sort()
@@ -706,8 +711,9 @@ class GpuMachine:
                                                                max(1, c1["particle_steps"] - c0["particle_steps"]), 3),
                       "seeding_box": [list(d["seedingBox"][0]), list(d["seedingBox"][1])],
                       "field": "closed-form split flow, u0 = 3 m/s at t = 0.5 s (stand-in for pimpleFoam's U)"})
-            cl.sort(); cl.step_index = 0
-            r["fragment_calls"] = self._fragment_calls(torch, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
+            if not args.no_fused_tutorial:
+                cl.sort(); cl.step_index = 0
+                r["fragment_calls"] = self._fragment_calls(torch, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
             del cl
         finally:
             ctx2.close()

@@ -4,7 +4,9 @@
   profiles/<label>_kernel_stats.csv      rocprofv3's own stats table
   profiles/<label>_pmc_hbm.json          the step kernels: calls, average duration, HBM bytes per launch (PMC, corrected)
 and, with --bench (the run was `bench.py`'s timed region), profiles/pmc_latest.json, which bench.py replays as
-roofline.traffic.  python tools/condense_profile.py LABEL [--bench] [--algo-bytes N]"""
+roofline.traffic.  python tools/condense_profile.py LABEL [--bench] [--algo-bytes N [--match SUBSTRING]]
+(--algo-bytes annotates the step kernels whose name contains SUBSTRING -- all of them without --match -- with the algorithmic bytes
+of one launch: particles x 56, or x 64 with the kick)"""
 import glob
 import json
 import os
@@ -14,11 +16,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 label = sys.argv[1]
 algo = int(sys.argv[sys.argv.index("--algo-bytes") + 1]) if "--algo-bytes" in sys.argv else None
+match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else ""
 d = json.load(open(os.path.join(ROOT, "gpurun_out", label + "_summary.json")))
 P = os.path.join(ROOT, "profiles")
 steps = d.get("step_kernels", [])
 for k in steps:
-    if algo:
+    if algo and match in k["kernel"]:
         k["algorithmic_bytes_per_launch"] = algo
         k["traffic_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / algo, 4)
         k["achieved_GBs"] = round(algo / (k["avg_us"] * 1e-6) / 1e9, 1)
