@@ -149,6 +149,77 @@ class GlooComm:
         self.ptr = C.pointer(self.struct)
 
 
+class ThreadGroup:
+    """What the ranks of a `ThreadComm` share: a barrier and one slot per rank."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def abort(self):
+        self.barrier.abort()
+
+
+class ThreadComm:
+    """A `cpf_comm` whose ranks are THREADS of this process over host memory (a barrier and per-rank slots): the randomised
+    test of the shard logic plays many worlds in one process this way, without a process group per case."""
+
+    def __init__(self, group, rank):
+        self.group, self.rank, self.world = group, rank, group.world
+        self._err = b""
+        g = group
+
+        def fail(e):
+            self._err = repr(e).encode()
+            g.abort()
+            return L.CPF_ERR_STATE
+
+        def all_gather(_self, send, recv, nbytes, _stream):
+            try:
+                g.slots[rank] = _view(send, nbytes).copy()
+                g.barrier.wait()
+                _view(recv, nbytes * g.world)[:] = np.concatenate([g.slots[r] for r in range(g.world)]) if nbytes else 0
+                g.barrier.wait()
+                return L.CPF_OK
+            except Exception as e:                      # noqa: BLE001
+                return fail(e)
+
+        def all_reduce(_self, buf, count, _stream):
+            try:
+                g.slots[rank] = _view(buf, count * 8, np.float64).copy()
+                g.barrier.wait()
+                acc = g.slots[0].copy()
+                for r in range(1, g.world):
+                    acc += g.slots[r]                   # (rank order: the same sum on every rank)
+                g.barrier.wait()
+                _view(buf, count * 8, np.float64)[:] = acc
+                return L.CPF_OK
+            except Exception as e:                      # noqa: BLE001
+                return fail(e)
+
+        def all_to_all_v(_self, send, s_off, s_bytes, recv, r_off, r_bytes, _stream):
+            try:
+                W = g.world
+                g.slots[rank] = [_view(send + s_off[r], s_bytes[r]).copy() if s_bytes[r] else None for r in range(W)]
+                g.barrier.wait()
+                for r in range(W):
+                    if r_bytes[r]:
+                        part = g.slots[r][rank]
+                        assert part is not None and part.size == r_bytes[r], "send and receive sizes disagree"
+                        _view(recv + r_off[r], r_bytes[r])[:] = part
+                g.barrier.wait()
+                return L.CPF_OK
+            except Exception as e:                      # noqa: BLE001
+                return fail(e)
+
+        self._keep = (L.ALL_GATHER_FN(all_gather), L.ALL_REDUCE_FN(all_reduce), L.ALL_TO_ALL_V_FN(all_to_all_v),
+                      L.COMM_ERROR_FN(lambda _self: self._err))
+        self.struct = L.Comm(None, rank, g.world, self._keep[0], self._keep[1], self._keep[2], L.COMM_DESTROY_FN(), self._keep[3])
+        self.ptr = C.pointer(self.struct)
+
+
 def cloud(case, cell_lo, capacity, comm=None, **kw):
     from cudaparticlesfoam_amd.parallel import ShardedCloud
     return ShardedCloud(case, cell_lo, capacity, comm, lib=load(), **kw)
