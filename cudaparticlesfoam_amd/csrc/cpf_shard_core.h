@@ -218,18 +218,22 @@ class ShardCore {
         CPF_SH(dev.alloc((void**)&nx, (size_t)c * 8)); CPF_SH(dev.alloc((void**)&ny, (size_t)c * 8));
         CPF_SH(dev.alloc((void**)&nz, (size_t)c * 8)); CPF_SH(dev.alloc((void**)&nc, (size_t)c * 4));
         CPF_SH(dev.alloc((void**)&ng, (size_t)c * 8));
+        // the velocities of a frame that is due (CPF_STEP_STORE_VEL: the arrivals' catch-up replay fills in theirs) move along
+        double* nv = nullptr;
+        if (vel) CPF_SH(dev.alloc((void**)&nv, (size_t)c * 24));
         Stream s = dev.compute();
         CPF_SH(dev.fill(nc, 0xFF, (size_t)c * 4, s));
         if (nKeep > 0) {
             CPF_SH(dev.copy(nx, x, (size_t)nKeep * 8, s)); CPF_SH(dev.copy(ny, y, (size_t)nKeep * 8, s));
             CPF_SH(dev.copy(nz, z, (size_t)nKeep * 8, s)); CPF_SH(dev.copy(nc, cell, (size_t)nKeep * 4, s));
             CPF_SH(dev.copy(ng, gid, (size_t)nKeep * 8, s));
+            if (nv) CPF_SH(dev.copy(nv, vel, (size_t)nKeep * 24, s));
         }
         CPF_SH(dev.streamSync(s));
         for (void* p : {(void*)x, (void*)y, (void*)z, (void*)cell, (void*)gid, (void*)vel, (void*)ax, (void*)ay, (void*)az, (void*)acell, (void*)agid})
             if (p) dev.release(p);
         x = nx; y = ny; z = nz; cell = nc; gid = ng;
-        vel = nullptr; ax = ay = az = nullptr; acell = nullptr; agid = nullptr;     // (re-made on demand at the new size)
+        vel = nv; ax = ay = az = nullptr; acell = nullptr; agid = nullptr;          // (the sort's second set: re-made on demand at the new size)
         const bool wholeShard = sendCap >= cap;                                      // "a send buffer as large as the shard" stays so
         cap = c;
         ++grown;
@@ -348,6 +352,10 @@ class ShardCore {
         const bool frameZero = dt == 0.0 && D == 0.0;
         for (int c = 0; c < nCycles;) {
             if (pending.on && (int64_t)stepIndex - (int64_t)pending.step >= overlapDepth()) CPF_SH(finishExchange());
+            // the cycle whose velocities are kept runs on a settled shard: a hand-off in flight completes BEFORE it (its arrivals,
+            // an overflow's second split and a sort that was waiting for it would otherwise reorder the particles under the
+            // stored velocities, or leave arrivals without any)
+            if (storeVel && c == nCycles - 1 && pending.on) CPF_SH(finishExchange());
             // CPF_STEP_FUSE_CYCLES: the cycles up to the next thing that falls due -- the end of the call, a sort, a hand-off or
             // re-cut, the completion of the hand-off in flight -- run inside ONE launch (U is frozen during the call;
             // bit-identical to single launches)
@@ -532,8 +540,9 @@ class ShardCore {
         const bool timing = dev.timingEnabled();
         if (timing) CPF_SH(dev.timingEnable(false));
         const bool storeVel = (argFlags & CPF_STEP_STORE_VEL) != 0 && vel != nullptr;
+        const unsigned fl = (storeVel ? argFlags : (argFlags & ~CPF_STEP_STORE_VEL)) | CPF_STEP_FUSE_CYCLES;
         const int r = dev.step(x + first, y + first, z + first, cell + first, gid + first, storeVel ? vel + 3 * first : nullptr, count, argDt,
-                               argD, step0, nCycles, argFlags | CPF_STEP_FUSE_CYCLES);
+                               argD, step0, nCycles, fl);
         if (timing) CPF_SH(dev.timingEnable(true));
         if (r != CPF_OK) return note(r);
         particleSteps += count * nCycles;

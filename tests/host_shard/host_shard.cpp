@@ -70,11 +70,9 @@ struct HostDev {
              uint32_t step0, int nCycles, unsigned) {
         hc->stepLaunches += 1;
         if (hc->timing) { hc->launches += 1; hc->ms += (double)n * (double)nCycles * hc->fakeMsPerParticle; }   // (a real launch takes as long as its cycles)
-        std::vector<double> v4;                                  // the checker writes [n][4] velocities, the shard keeps [n][3]
-        if (vel) v4.assign((size_t)n * 4, 0.0);
-        cw_step(x, y, z, cell, vel ? v4.data() : nullptr, (int)n, dt, nCycles, hc->cellOff.data(), hc->planes.data(), hc->nbr.data(),
+        // (the checker writes the velocities of the last cycle as [n][3], the layout the shard keeps)
+        cw_step(x, y, z, cell, vel, (int)n, dt, nCycles, hc->cellOff.data(), hc->planes.data(), hc->nbr.data(),
                 hc->groupOff.data(), hc->groupNbr.data(), hc->U.data(), 1, nullptr, D, gid, step0, hc->seed);
-        if (vel) for (int64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) vel[3 * i + k] = v4[(size_t)(4 * i + k)];
         return CPF_OK;
     }
     static int ownerOf(int c, const int32_t* lo, int W) { int r = 0; for (int q = 1; q < W; ++q) r += c >= lo[q]; return r; }

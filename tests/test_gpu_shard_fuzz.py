@@ -1,0 +1,149 @@
+"""GPU: the randomised differential test of tests/test_shard_fuzz.py through the PRODUCT -- HIP split / unpack / histogram / cut
+kernels, the streaming step kernel, the in-process communicator -- with the ranks as threads on the one GPU: every case must end
+with every particle bit-identical to one process of the CPU checker."""
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import numpy as np
+import pytest
+
+from test_shard_fuzz import CYCLES, DT, STORE_VEL, _draw, _fields
+
+pytestmark = pytest.mark.gpu
+N_TOTAL = 40_000
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_worlds_on_the_gpu(block, oracle_libs):
+    import torch
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.api import Context
+    from cudaparticlesfoam_amd.cases import box_mesh
+    from cudaparticlesfoam_amd.parallel import Communicator, ShardedCloud, slab_cell_ranges, unique_id, x_slab_renumbering
+    m0 = box_mesh(10, 4, 3)
+    c0, _ = m0.cell_centres_volumes()
+    mesh = m0.renumber_cells(x_slab_renumbering(c0))
+    _, vols = mesh.cell_centres_volumes()
+    cw = oracle_libs.CellWalk(); t = cw.build(mesh)
+    dev = torch.device("cuda", 0)
+    tally = dict(handed=0, exchanges=0, grown=0, send_grown=0)
+    for case_no in range(12):
+        seed = 77_000 + 1000 * block + case_no
+        rng = np.random.default_rng(seed)
+        cfg = _draw(rng)
+        W = cfg["world"]
+        fields = _fields(mesh.n_cells, 1 + sum(c["new_u"] for c in cfg["calls"]), rng)
+        xyz = rng.uniform([0, 0, 0], [10, 4, 3], size=(N_TOTAL, 3))
+        # ---- ONE context on the GPU: the same kernels on the whole cloud (the counter-based kicks make the answer independent of
+        # who holds a particle; with D = 0 it is also the CPU checker's, bit for bit)
+        p = lambda t_: t_.data_ptr()   # noqa: E731
+        one = Context(0); one.set_mesh(mesh); one.set_velocity(fields[0]); one.set_seed(0)
+        one.set_stream(torch.cuda.current_stream().cuda_stream)
+        tx, ty, tz = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+        tc = torch.empty(N_TOTAL, dtype=torch.int32, device=dev)
+        tg = torch.arange(N_TOTAL, dtype=torch.int64, device=dev)
+        tv = torch.zeros(N_TOTAL, 3, dtype=torch.float64, device=dev)
+        one.locate_initial_dev(p(tx), p(ty), p(tz), p(tc), N_TOTAL)
+        step0, fi, frames = 0, 0, []
+        for call in cfg["calls"]:
+            if call["new_u"]:
+                fi += 1
+                one.set_velocity(fields[fi])
+            k = call["cycles"]
+            if call["flags"] & STORE_VEL:                     # the frame: the state and the velocities of the call's last cycle
+                if k > 1:
+                    one.step_dev(p(tx), p(ty), p(tz), p(tc), p(tg), None, N_TOTAL, DT, cfg["D"], step0, k - 1, 0)
+                one.step_dev(p(tx), p(ty), p(tz), p(tc), p(tg), p(tv), N_TOTAL, DT, cfg["D"], step0 + k - 1, 1, STORE_VEL)
+                torch.cuda.synchronize()
+                frames.append(tuple(a_.cpu().numpy().copy() for a_ in (tx, ty, tz, tc, tv)))
+            else:
+                one.step_dev(p(tx), p(ty), p(tz), p(tc), p(tg), None, N_TOTAL, DT, cfg["D"], step0, k, 0)
+            step0 += k
+        torch.cuda.synchronize()
+        x, y, z, c = (a_.cpu().numpy() for a_ in (tx, ty, tz, tc))
+        one.use_own_stream(); one.close()
+        if cfg["D"] == 0.0:
+            hx, hy, hz = (xyz[:, k].copy() for k in range(3))
+            hc = cw.locate_initial(hx, hy, hz, t, nthreads=cw.max_threads)
+            fi = 0
+            for call in cfg["calls"]:
+                if call["new_u"]:
+                    fi += 1
+                cw.step(hx, hy, hz, hc, DT, call["cycles"], t, fields[fi], nthreads=cw.max_threads)
+            assert np.array_equal(hx, x) and np.array_equal(hy, y) and np.array_equal(hz, z) and np.array_equal(hc, c), (seed, cfg)
+        token = unique_id(L.COMM_INPROCESS)
+        cell_lo = slab_cell_ranges(vols, W)
+        out, errors = [None] * W, []
+        cut = [0] + [int(mesh.n_cells * (r + 1) ** 2 / W ** 2) for r in range(W)]
+
+        def rank_main(rank):
+            try:
+                ctx = Context(0)
+                ctx.set_mesh(mesh); ctx.set_velocity(fields[0]); ctx.set_seed(0)
+                comm = Communicator(token, rank, W, 0)
+                cap = (N_TOTAL // W + 2000) if cfg["small_capacity"] else N_TOTAL + 16
+                cloud = ShardedCloud(ctx, cell_lo, cap, comm, send_fraction=cfg["send_fraction"], exchange_interval=cfg["exchange"])
+                mine = np.arange(rank, N_TOTAL, W)
+                tx, ty, tz = (torch.from_numpy(xyz[mine, k].copy()).to(dev) for k in range(3))
+                tg = torch.from_numpy(mine.astype(np.int64)).to(dev)
+                torch.cuda.synchronize()
+                cloud.set_particles(tx, ty, tz, None, tg)
+                cloud.exchange()
+                cloud.rebalance_interval = cfg["rebalance"]
+                cloud.overlap_steps = cfg["overlap"]
+                cloud.sort_interval = cfg["sort"]
+                if cfg["by_time"]:
+                    cloud.enable_time_balancing()
+                if cfg["frame0"]:
+                    cloud.step(0.0, 1, D=0.0, flags=STORE_VEL)
+                fi, nframe = 0, 0
+                for call in cfg["calls"]:
+                    if call["new_u"]:
+                        fi += 1
+                        if call["slices"]:
+                            cloud.set_velocity_slice(fields[fi][cut[rank]:cut[rank + 1]])
+                        else:
+                            cloud.set_velocity(fields[fi])
+                    cloud.step(DT, call["cycles"], D=cfg["D"], flags=call["flags"])
+                    if call["flags"] & STORE_VEL:
+                        fx, fy, fz, fc, fv = frames[nframe]; nframe += 1
+                        xyzw, wc, wv = cloud.gather(0, want_vel=True)          # what cpf_shard_write_vtu formats
+                        if rank == 0:
+                            assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
+                            assert np.array_equal(wc, fc) and np.array_equal(wv[:, :3], fv), "frame velocities"
+                    if call["gather"]:
+                        whole = cloud.gather(0)
+                        assert (whole[0] is not None) == (rank == 0)
+                cloud.flush()
+                total = cloud.global_count()
+                g, gx, gy, gz, gc = cloud.gather_to_numpy()
+                out[rank] = dict(g=g, x=gx, y=gy, z=gz, c=gc, total=total, lo=cloud.cell_lo.copy(), step=cloud.step_index,
+                                 handed=cloud.handed_off, exchanges=cloud.exchanges, grown=cloud.grown, send_grown=cloud.send_grown)
+                cloud.close(); comm.close(); ctx.close()
+            except BaseException as e:                       # noqa: BLE001 -- reported by the main thread
+                import traceback
+                errors.append((rank, repr(e), traceback.format_exc()))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(W)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=600)
+        assert not errors, (seed, cfg, errors[:1])
+        assert all(o is not None for o in out), (seed, cfg)
+        seen = np.zeros(N_TOTAL, bool)
+        for o in out:
+            g = o["g"]
+            assert not seen[g].any(), (seed, cfg)
+            seen[g] = True
+            assert o["total"] == N_TOTAL and o["step"] == CYCLES, (seed, cfg)
+            ok = np.array_equal(o["x"], x[g]) and np.array_equal(o["y"], y[g]) and np.array_equal(o["z"], z[g]) and np.array_equal(o["c"], c[g])
+            assert ok, (seed, cfg)
+            assert np.array_equal(o["lo"], out[0]["lo"]), (seed, cfg)
+        assert seen.all(), (seed, cfg)
+        for k in tally:
+            tally[k] += sum(int(o[k]) for o in out)
+    assert tally["handed"] > 1000 and tally["exchanges"] > 10, tally

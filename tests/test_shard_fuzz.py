@@ -63,12 +63,20 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
         # ---- one process
         x, y, z = (xyz[:, k].copy() for k in range(3))
         c = cw.locate_initial(x, y, z, t)
-        step0, fi = 0, 0
+        step0, fi, frames = 0, 0, []
         for call in cfg["calls"]:
             if call["new_u"]:
                 fi += 1
-            cw.step(x, y, z, c, DT, call["cycles"], t, fields[fi], D=cfg["D"], gid=gid_all, step0=step0, seed=0)
-            step0 += call["cycles"]
+            k = call["cycles"]
+            if call["flags"] & STORE_VEL:                     # the frame: the state and the velocities of the call's last cycle
+                if k > 1:
+                    cw.step(x, y, z, c, DT, k - 1, t, fields[fi], D=cfg["D"], gid=gid_all, step0=step0, seed=0)
+                v = np.zeros((N_TOTAL, 3))
+                cw.step(x, y, z, c, DT, 1, t, fields[fi], vel_out=v, D=cfg["D"], gid=gid_all, step0=step0 + k - 1, seed=0)
+                frames.append((x.copy(), y.copy(), z.copy(), c.copy(), v))
+            else:
+                cw.step(x, y, z, c, DT, k, t, fields[fi], D=cfg["D"], gid=gid_all, step0=step0, seed=0)
+            step0 += k
         # ---- the same cloud over W rank threads
         group = H.ThreadGroup(W)
         cell_lo = slab_cell_ranges(vols, W)
@@ -91,7 +99,7 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
                     cloud.enable_time_balancing()
                 if cfg["frame0"]:
                     cloud.step(0.0, 1, D=0.0, flags=STORE_VEL)                         # the frame-0 idiom: not a cycle of the run
-                fi = 0
+                fi, nframe = 0, 0
                 for call in cfg["calls"]:
                     if call["new_u"]:
                         fi += 1
@@ -100,6 +108,13 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
                         else:
                             cloud.set_velocity(fields[fi])
                     cloud.step(DT, call["cycles"], D=cfg["D"], flags=call["flags"])
+                    if call["flags"] & STORE_VEL:
+                        fx, fy, fz, fc, fv = frames[nframe]; nframe += 1
+                        xyzw, wc, wv = cloud.gather(0, want_vel=True)          # what cpf_shard_write_vtu formats
+                        if rank == 0:
+                            assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
+                            bad = np.flatnonzero((wv[:, :3] != fv).any(axis=1))
+                            assert np.array_equal(wc, fc) and bad.size == 0, ("frame velocities", bad.size, bad[:5], wv[bad[:3]], fv[bad[:3]], wc[bad[:5]])
                     if call["gather"]:
                         whole = cloud.gather(0)
                         assert (whole[0] is not None) == (rank == 0)
