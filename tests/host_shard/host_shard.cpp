@@ -181,9 +181,9 @@ struct HostDev {
         return CPF_OK;
     }
     int setVelocityDev(const double* U, int64_t cells) { return setVelocityHost(U, cells); }
-    int writeVtuArrays(const char*, int64_t, const double*, const int32_t*, const double*, double*) {
-        err = "the host test device writes no frames";
-        return CPF_ERR_STATE;
+    // (the product's own writer, csrc/cpf_io.cpp, compiled into this library: frames of the sharded cloud are compared byte for byte)
+    int writeVtuArrays(const char* path, int64_t n, const double* xyzw, const int32_t* cell, const double* vel, double* ke) {
+        return cpf_write_vtu_arrays(path, n, xyzw, cell, vel, ke);
     }
 };
 
@@ -224,3 +224,8 @@ int64_t cpf_host_case_step_launches(const cpf_host_case* h) { return h->stepLaun
 void cpf_host_case_timing_read(cpf_host_case* h, int64_t* launches, double* ms) { *launches = h->launches; *ms = h->ms; h->launches = 0; h->ms = 0.0; }
 
 }  // extern "C"
+
+// csrc/cpf_io.cpp also holds the context-level writers; what they call of the product is not in this library and never runs here
+namespace cpf { bool vtu_binary(const cpf_context*) { return false; } }
+extern "C" int cpf_get_particles(cpf_context*, double*, int32_t*, double*) { return CPF_ERR_STATE; }
+extern "C" int cpf_num_particles(const cpf_context*, int64_t* n) { if (n) *n = 0; return CPF_ERR_STATE; }

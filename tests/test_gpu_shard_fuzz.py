@@ -1,6 +1,7 @@
 """GPU: the randomised differential test of tests/test_shard_fuzz.py through the PRODUCT -- HIP split / unpack / histogram / cut
 kernels, the streaming step kernel, the in-process communicator -- with the ranks as threads on the one GPU: every case must end
 with every particle bit-identical to one process of the CPU checker."""
+import ctypes as C
 import os
 import sys
 import threading
@@ -17,7 +18,7 @@ N_TOTAL = 40_000
 
 
 @pytest.mark.parametrize("block", range(6))
-def test_random_worlds_on_the_gpu(block, oracle_libs):
+def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
     import torch
     from cudaparticlesfoam_amd import _lib as L
     from cudaparticlesfoam_amd.api import Context
@@ -29,6 +30,7 @@ def test_random_worlds_on_the_gpu(block, oracle_libs):
     _, vols = mesh.cell_centres_volumes()
     cw = oracle_libs.CellWalk(); t = cw.build(mesh)
     dev = torch.device("cuda", 0)
+    tmp = str(tmp_path)
     tally = dict(handed=0, exchanges=0, grown=0, send_grown=0)
     for case_no in range(12):
         seed = 77_000 + 1000 * block + case_no
@@ -111,7 +113,18 @@ def test_random_worlds_on_the_gpu(block, oracle_libs):
                     if call["flags"] & STORE_VEL:
                         fx, fy, fz, fc, fv = frames[nframe]; nframe += 1
                         xyzw, wc, wv = cloud.gather(0, want_vel=True)          # what cpf_shard_write_vtu formats
+                        path = os.path.join(tmp, "f%d_%d.vtu" % (seed, nframe))
+                        cloud.write_vtu(path)                                   # collective; formatted on the root's worker thread
+                        assert cloud.lib.cpf_shard_write_vtu_wait(cloud.h) == 0
                         if rank == 0:
+                            ref = path + ".ref"
+                            fxyzw = np.column_stack([fx, fy, fz, np.ones(N_TOTAL)]); fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
+                            ke = C.c_double()
+                            assert cloud.lib.cpf_write_vtu_arrays(ref.encode(), N_TOTAL, fxyzw.ctypes.data_as(C.c_void_p),
+                                                                  fc.ctypes.data_as(C.c_void_p), fvel.ctypes.data_as(C.c_void_p), C.byref(ke)) == 0
+                            got = open(path, "rb").read()
+                            assert len(got) > 100 * N_TOTAL and got == open(ref, "rb").read(), "frame file"
+                            os.remove(path); os.remove(ref)
                             assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
                             assert np.array_equal(wc, fc) and np.array_equal(wv[:, :3], fv), "frame velocities"
                     if call["gather"]:

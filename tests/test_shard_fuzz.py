@@ -2,6 +2,7 @@
 tests/host_shard) against ONE process of the CPU checker.  The ranks are threads, the collectives a barrier and slots
 (tests/hostshard.py ThreadComm): dozens of worlds, cadences, buffer sizes and call patterns per second, every one required to
 end with every particle bit-identical to the single-process run -- positions, cells, and nobody lost or doubled."""
+import ctypes as C
 import os
 import sys
 import threading
@@ -42,7 +43,7 @@ def _fields(n_cells, count, rng):
 
 
 @pytest.mark.parametrize("block", range(int(os.environ.get("CPF_FUZZ_BLOCKS", "8"))))      # (a longer campaign: CPF_FUZZ_BLOCKS=200)
-def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
+def test_random_worlds_cadences_and_call_patterns(block, oracle_libs, tmp_path):
     import hostshard as H
     from cudaparticlesfoam_amd.cases import box_mesh
     from cudaparticlesfoam_amd.parallel import slab_cell_ranges, x_slab_renumbering
@@ -51,6 +52,7 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
     mesh = m0.renumber_cells(x_slab_renumbering(c0))
     _, vols = mesh.cell_centres_volumes()
     cw = oracle_libs.CellWalk(); t = cw.build(mesh)
+    tmp = str(tmp_path)
     tally = dict(handed=0, exchanges=0, grown=0, send_grown=0, launches=0)
     for case_no in range(CASES_PER_BLOCK):
         seed = 1000 * block + case_no
@@ -111,7 +113,20 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs):
                     if call["flags"] & STORE_VEL:
                         fx, fy, fz, fc, fv = frames[nframe]; nframe += 1
                         xyzw, wc, wv = cloud.gather(0, want_vel=True)          # what cpf_shard_write_vtu formats
+                        # the frame as the fragments write it (collective; formatted on the root's worker thread) == the product's
+                        # writer on the one-process arrays, byte for byte
+                        path = os.path.join(tmp, "f%d_%d.vtu" % (seed, nframe))
+                        cloud.write_vtu(path)
+                        assert cloud.lib.cpf_shard_write_vtu_wait(cloud.h) == 0
                         if rank == 0:
+                            ref = path + ".ref"
+                            fxyzw = np.column_stack([fx, fy, fz, np.ones(N_TOTAL)]); fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
+                            ke = C.c_double()
+                            assert cloud.lib.cpf_write_vtu_arrays(ref.encode(), N_TOTAL, fxyzw.ctypes.data_as(C.c_void_p),
+                                                                  fc.ctypes.data_as(C.c_void_p), fvel.ctypes.data_as(C.c_void_p), C.byref(ke)) == 0
+                            got = open(path, "rb").read()
+                            assert len(got) > 100 * N_TOTAL and got == open(ref, "rb").read(), "frame file"
+                            os.remove(path); os.remove(ref)
                             assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
                             bad = np.flatnonzero((wv[:, :3] != fv).any(axis=1))
                             assert np.array_equal(wc, fc) and bad.size == 0, ("frame velocities", bad.size, bad[:5], wv[bad[:3]], fv[bad[:3]], wc[bad[:5]])
