@@ -415,7 +415,8 @@ int cpf_shard_seed_box(cpf_shard* s, int64_t nTotal, const double lower[3], cons
 /* nCycles Lagrangian cycles of this rank's particles (cpf_step's contract), with the hand-offs, re-cuts and sorts
  * that fall due in between.  COLLECTIVE: every rank calls it with the same arguments.  With CPF_STEP_STORE_VEL the
  * velocities of the last cycle stay aligned with the particles until the next call (whatever falls due on that
- * cycle runs at the start of the next call instead).  With CPF_STEP_FUSE_CYCLES the cycles up to the next thing that
+ * cycle runs at the start of the next call instead; a particle that is not stepped -- lost or frozen -- has velocity 0 in
+ * such a frame, where the single-context path keeps the one of its last frame).  With CPF_STEP_FUSE_CYCLES the cycles up to the next thing that
  * falls due (a sort, a hand-off, a re-cut, the completion of the hand-off in flight, the end of the call) run inside
  * one launch, as in cpf_step; without it every cycle is a launch.  Same results either way, bit for bit. */
 int cpf_shard_step(cpf_shard* s, double dt, double D, int nCycles, unsigned flags);

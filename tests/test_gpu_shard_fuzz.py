@@ -39,16 +39,25 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
         W = cfg["world"]
         fields = _fields(mesh.n_cells, 1 + sum(c["new_u"] for c in cfg["calls"]), rng)
         xyz = rng.uniform([0, 0, 0], [10, 4, 3], size=(N_TOTAL, 3))
+        # a third of the cases: the cloud is SEEDED by the shards (cpf_shard_seed_box: every rank draws its share of the one LCG
+        # stream, the ranges are cut, everybody goes to its owner) from a box that sticks out of the domain
+        seeded = bool(rng.integers(0, 3) == 0)
+        box_lo, box_hi = np.array([-0.7, 0.2, 0.1]), np.array([9.0, 3.9, 2.8])
         # ---- ONE context on the GPU: the same kernels on the whole cloud (the counter-based kicks make the answer independent of
         # who holds a particle; with D = 0 it is also the CPU checker's, bit for bit)
         p = lambda t_: t_.data_ptr()   # noqa: E731
         one = Context(0); one.set_mesh(mesh); one.set_velocity(fields[0]); one.set_seed(0)
         one.set_stream(torch.cuda.current_stream().cuda_stream)
         tx, ty, tz = (torch.from_numpy(xyz[:, k].copy()).to(dev) for k in range(3))
+        if seeded:
+            one.seed_box_dev(p(tx), p(ty), p(tz), 0, N_TOTAL, box_lo, box_hi, 1)
         tc = torch.empty(N_TOTAL, dtype=torch.int32, device=dev)
         tg = torch.arange(N_TOTAL, dtype=torch.int64, device=dev)
         tv = torch.zeros(N_TOTAL, 3, dtype=torch.float64, device=dev)
         one.locate_initial_dev(p(tx), p(ty), p(tz), p(tc), N_TOTAL)
+        torch.cuda.synchronize()
+        lost0 = int((tc < 0).sum())
+        assert (lost0 > 0) == seeded
         step0, fi, frames = 0, 0, []
         for call in cfg["calls"]:
             if call["new_u"]:
@@ -58,6 +67,7 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
             if call["flags"] & STORE_VEL:                     # the frame: the state and the velocities of the call's last cycle
                 if k > 1:
                     one.step_dev(p(tx), p(ty), p(tz), p(tc), p(tg), None, N_TOTAL, DT, cfg["D"], step0, k - 1, 0)
+                tv.zero_()                                    # (a sharded frame: no velocity for particles that are not stepped)
                 one.step_dev(p(tx), p(ty), p(tz), p(tc), p(tg), p(tv), N_TOTAL, DT, cfg["D"], step0 + k - 1, 1, STORE_VEL)
                 torch.cuda.synchronize()
                 frames.append(tuple(a_.cpu().numpy().copy() for a_ in (tx, ty, tz, tc, tv)))
@@ -67,7 +77,7 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
         torch.cuda.synchronize()
         x, y, z, c = (a_.cpu().numpy() for a_ in (tx, ty, tz, tc))
         one.use_own_stream(); one.close()
-        if cfg["D"] == 0.0:
+        if cfg["D"] == 0.0 and not seeded:
             hx, hy, hz = (xyz[:, k].copy() for k in range(3))
             hc = cw.locate_initial(hx, hy, hz, t, nthreads=cw.max_threads)
             fi = 0
@@ -88,12 +98,16 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
                 comm = Communicator(token, rank, W, 0)
                 cap = (N_TOTAL // W + 2000) if cfg["small_capacity"] else N_TOTAL + 16
                 cloud = ShardedCloud(ctx, cell_lo, cap, comm, send_fraction=cfg["send_fraction"], exchange_interval=cfg["exchange"])
-                mine = np.arange(rank, N_TOTAL, W)
-                tx, ty, tz = (torch.from_numpy(xyz[mine, k].copy()).to(dev) for k in range(3))
-                tg = torch.from_numpy(mine.astype(np.int64)).to(dev)
-                torch.cuda.synchronize()
-                cloud.set_particles(tx, ty, tz, None, tg)
-                cloud.exchange()
+                if seeded:
+                    n_out = cloud.seed_box(N_TOTAL, box_lo, box_hi)
+                    assert n_out == lost0, (n_out, lost0)
+                else:
+                    mine = np.arange(rank, N_TOTAL, W)
+                    tx, ty, tz = (torch.from_numpy(xyz[mine, k].copy()).to(dev) for k in range(3))
+                    tg = torch.from_numpy(mine.astype(np.int64)).to(dev)
+                    torch.cuda.synchronize()
+                    cloud.set_particles(tx, ty, tz, None, tg)
+                    cloud.exchange()
                 cloud.rebalance_interval = cfg["rebalance"]
                 cloud.overlap_steps = cfg["overlap"]
                 cloud.sort_interval = cfg["sort"]
@@ -113,20 +127,27 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
                     if call["flags"] & STORE_VEL:
                         fx, fy, fz, fc, fv = frames[nframe]; nframe += 1
                         xyzw, wc, wv = cloud.gather(0, want_vel=True)          # what cpf_shard_write_vtu formats
+                        if rank == 0:
+                            badc = np.flatnonzero(wc != fc)
+                            assert badc.size == 0, ("frame cells", badc.size, badc[:5], wc[badc[:5]], fc[badc[:5]])
+                            badv = np.flatnonzero((wv[:, :3] != fv).any(axis=1))
+                            assert badv.size == 0, ("frame velocities", badv.size, badv[:5], wv[badv[:3]], fv[badv[:3]], fc[badv[:5]])
+                            badw = np.flatnonzero(xyzw[:, 3] != np.where(fc == -2, 0.0, 1.0))
+                            assert badw.size == 0, ("frame w", badw.size, xyzw[badw[:5], 3], fc[badw[:5]])
+                            assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
                         path = os.path.join(tmp, "f%d_%d.vtu" % (seed, nframe))
                         cloud.write_vtu(path)                                   # collective; formatted on the root's worker thread
                         assert cloud.lib.cpf_shard_write_vtu_wait(cloud.h) == 0
                         if rank == 0:
                             ref = path + ".ref"
-                            fxyzw = np.column_stack([fx, fy, fz, np.ones(N_TOTAL)]); fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
+                            fxyzw = np.column_stack([fx, fy, fz, np.where(fc == -2, 0.0, 1.0)])       # (w = 0: frozen, CPF_CELL_FROZEN)
+                            fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
                             ke = C.c_double()
                             assert cloud.lib.cpf_write_vtu_arrays(ref.encode(), N_TOTAL, fxyzw.ctypes.data_as(C.c_void_p),
                                                                   fc.ctypes.data_as(C.c_void_p), fvel.ctypes.data_as(C.c_void_p), C.byref(ke)) == 0
                             got = open(path, "rb").read()
                             assert len(got) > 100 * N_TOTAL and got == open(ref, "rb").read(), "frame file"
                             os.remove(path); os.remove(ref)
-                            assert np.array_equal(xyzw[:, 0], fx) and np.array_equal(xyzw[:, 1], fy) and np.array_equal(xyzw[:, 2], fz)
-                            assert np.array_equal(wc, fc) and np.array_equal(wv[:, :3], fv), "frame velocities"
                     if call["gather"]:
                         whole = cloud.gather(0)
                         assert (whole[0] is not None) == (rank == 0)

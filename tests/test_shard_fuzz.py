@@ -120,7 +120,8 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs, tmp_path):
                         assert cloud.lib.cpf_shard_write_vtu_wait(cloud.h) == 0
                         if rank == 0:
                             ref = path + ".ref"
-                            fxyzw = np.column_stack([fx, fy, fz, np.ones(N_TOTAL)]); fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
+                            fxyzw = np.column_stack([fx, fy, fz, np.where(fc == -2, 0.0, 1.0)])       # (w = 0: frozen, CPF_CELL_FROZEN)
+                            fvel = np.column_stack([fv, -np.ones(N_TOTAL)])
                             ke = C.c_double()
                             assert cloud.lib.cpf_write_vtu_arrays(ref.encode(), N_TOTAL, fxyzw.ctypes.data_as(C.c_void_p),
                                                                   fc.ctypes.data_as(C.c_void_p), fvel.ctypes.data_as(C.c_void_p), C.byref(ke)) == 0
