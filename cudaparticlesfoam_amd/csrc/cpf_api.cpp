@@ -678,6 +678,13 @@ int cpf_step(cpf_context* ctx, double dt, double D, int nCycles, unsigned flags)
     CPF_REQUIRE(ctx, ctx, CPF_ERR_ARG, "null context");
     CPF_REQUIRE(ctx, ctx->n > 0, CPF_ERR_STATE, "cpf_step: no particles");
     CPF_REQUIRE(ctx, ctx->located, CPF_ERR_STATE, "cpf_step: particles have no cells yet (call cpf_locate_initial)");
+    // a frame holds the velocities of the particles this call steps; one that is not stepped -- lost, frozen -- has none (the
+    // reference's array keeps the velocity of such a particle's last advect, cuda/particles.cu:316-373; with the velocities stored
+    // on frame cycles only that would be the one of its last FRAME, and a sharded cloud does not carry it along at all)
+    if ((flags & CPF_STEP_STORE_VEL) && ctx->vel) {
+        CPF_HIP(ctx, hipSetDevice(ctx->device));
+        CPF_HIP(ctx, hipMemsetAsync(ctx->vel, 0, (size_t)ctx->n * 24, ctx->stream));
+    }
     int r = cpf_step_dev(ctx, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel, ctx->n, dt, D, ctx->stepCounter,
                          nCycles, flags);
     if (r != CPF_OK) return r;

@@ -356,8 +356,8 @@ class ShardCore {
             // an overflow's second split and a sort that was waiting for it would otherwise reorder the particles under the
             // stored velocities, or leave arrivals without any)
             if (storeVel && c == nCycles - 1 && pending.on) CPF_SH(finishExchange());
-            // (a particle that is not stepped -- lost, frozen -- has no velocity in the frame: the slots are not the ones its
-            //  last velocity was written to, the shard having been compacted, sorted or grown since)
+            // (a particle that is not stepped -- lost, frozen -- has no velocity in the frame, as with cpf_step; the slots are not
+            //  even the ones its last velocity was written to: the shard has been compacted, sorted or grown since)
             if (storeVel && c == nCycles - 1 && n > 0) CPF_SH(dev.fill(vel, 0, (size_t)n * 24, dev.compute()));
             // CPF_STEP_FUSE_CYCLES: the cycles up to the next thing that falls due -- the end of the call, a sort, a hand-off or
             // re-cut, the completion of the hand-off in flight -- run inside ONE launch (U is frozen during the call;

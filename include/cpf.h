@@ -49,7 +49,9 @@ typedef enum cpf_status {
 /* flags for cpf_step / cpf_step_device */
 #define CPF_STEP_DEFAULT 0u
 #define CPF_STEP_NO_REFLECT 1u    /* reflectWall=false (src/initCuda.H:67): wall hit => CPF_CELL_LOST */
-#define CPF_STEP_STORE_VEL 2u     /* also write per-particle velocity (d_particle_vels, for the VTU writer) */
+#define CPF_STEP_STORE_VEL 2u     /* also write per-particle velocity (d_particle_vels, for the VTU writer); a particle the call
+                                     does not step (lost, frozen) has velocity 0 in that frame -- the reference's array keeps
+                                     the velocity of its last advect */
 #define CPF_STEP_FUSE_CYCLES 4u   /* run all nCycles inside ONE launch, particle state kept in registers
                                      (legal because U is frozen during the loop, src/advect.H:86) */
 #define CPF_STEP_VERTEX_VELOCITY 8u /* advect with the velocity INTERPOLATED at the particle's position from vertex velocities
@@ -416,7 +418,7 @@ int cpf_shard_seed_box(cpf_shard* s, int64_t nTotal, const double lower[3], cons
  * that fall due in between.  COLLECTIVE: every rank calls it with the same arguments.  With CPF_STEP_STORE_VEL the
  * velocities of the last cycle stay aligned with the particles until the next call (whatever falls due on that
  * cycle runs at the start of the next call instead; a particle that is not stepped -- lost or frozen -- has velocity 0 in
- * such a frame, where the single-context path keeps the one of its last frame).  With CPF_STEP_FUSE_CYCLES the cycles up to the next thing that
+ * such a frame, as with cpf_step).  With CPF_STEP_FUSE_CYCLES the cycles up to the next thing that
  * falls due (a sort, a hand-off, a re-cut, the completion of the hand-off in flight, the end of the call) run inside
  * one launch, as in cpf_step; without it every cycle is a launch.  Same results either way, bit for bit. */
 int cpf_shard_step(cpf_shard* s, double dt, double D, int nCycles, unsigned flags);
