@@ -157,6 +157,41 @@ def test_parallel_fragments_transient_field_with_diffusion(tmp_path, pitz, n_pro
     assert head.startswith("# vtk DataFile Version 4.1") and "POINTS" in head
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CPF_FUZZ_DICTS", "6"))))        # (a longer campaign: CPF_FUZZ_DICTS=80)
+def test_random_dictionaries_parallel_equals_serial(tmp_path, pitz, seed):
+    """Random cudaParticlesDict entries (particle count, diffusion on / off, output cadence, a seeding box that may stick out of
+    the domain, ASCII or binary frames, trajectories), cycles per Eulerian step, Eulerian steps and rank counts: the rank-per-GPU
+    run of the replacement fragments (ranks as threads on the one GPU) equals the serial run -- final particles, every frame and
+    the trajectory file byte for byte.  The cycles between two frames go through cpf_shard_step with CPF_STEP_FUSE_CYCLES, with the
+    fragments' own cadences (re-cut every 32 cycles by measured time, derived overlap depth, sorts every 25 / 50)."""
+    from case_dump import dump_case
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    rng = np.random.default_rng(4200 + seed)
+    mesh, U = pitz["mesh"], pitz["U_analytic"]
+    n_procs = int(rng.integers(2, 6))
+    cycles, esteps = int(rng.integers(5, 70)), int(rng.integers(1, 4))
+    box = DICT["seedingBox"] if rng.integers(0, 2) else ((-0.025, -0.03, -0.0003), (0.05, 0.03, 0.0003))    # partly outside
+    d = dict(DICT, numParticles=int(rng.integers(3000, 40000)), diffusionCoeff=float(rng.choice([0.0, 1.5e-5])),
+             saveInterval=int(rng.integers(1, 15)), seedingBox=box, binaryFrames=int(rng.integers(0, 2)),
+             saveStreamline=int(rng.integers(0, 3) == 0))
+    case = str(tmp_path / "case")
+    dump_case(case, mesh, U, d, 1.0, cycles * 1e-4)
+    ser = tmp_path / "serial"; ser.mkdir()
+    xs, cs, outs = _run("mockUncoupledFoam", case, str(ser), n=d["numParticles"], extra=[str(esteps)])
+    first = 0
+    for r, part in enumerate(split_into_parts(mesh, n_procs)):
+        dump_case(os.path.join(case, "processor%d" % r), part, U[first:first + part.n_cells], d, 1.0, cycles * 1e-4)
+        first += part.n_cells
+    par = tmp_path / "parallel"; par.mkdir()
+    xp, cp, outp = _run("mockParallelFoam", case, str(par), n=d["numParticles"], extra=[str(n_procs), str(esteps)])
+    assert np.array_equal(xp, xs) and np.array_equal(cp, cs), (seed, d, n_procs, cycles, esteps)
+    assert outp.count("nCycles: ") == esteps and outs.count("nCycles: ") == esteps       # (deltaT / dt may round up by one cycle)
+    frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
+    assert frames == sorted(os.path.basename(p) for p in glob.glob(str(ser / "particle_*.vtu"))) and len(frames) >= 2
+    for f in frames + (["Streamline.vtk"] if d["saveStreamline"] else []):
+        assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), (f, seed, d, n_procs, cycles, esteps)
+
+
 def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
     """cudaAdvect -> cudaBrownianMotion -> convexTetQuery -> convexWallReflect -> cudaMoveParticles on the
     reference's AoS arrays == the fused kernel, bit for bit (D = 0 and D > 0: same counter-based stream).  The stages
