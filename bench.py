@@ -627,6 +627,19 @@ class GpuMachine:
         r.update({"D": Db, "sort_interval": interval, "sorts_inside": args.brownian_steady_steps // interval,
                   "kernel": ctx.step_kernel_name(Db, 0), "particles": cl.n,
                   "note": "frac = 64 B x particles / ms_per_step (sorts included); kernel_frac = the step kernel alone"})
+        # one re-sort of that cloud by itself, three times: 25 cycles of diffusion without a sort, then the sort between two syncs
+        cl.sort_interval = 0
+        sorts = []
+        for _ in range(3):
+            cl.step(dt, interval, D=Db)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cl.sort()
+            torch.cuda.synchronize()
+            sorts.append((time.perf_counter() - t0) * 1e3)
+        r["resort"] = {"ms": round(sorted(sorts)[1], 4), "after_cycles": interval, "particles": cl.n,
+                       "key_sort": "this library's radix sort (option sort_method 2, the default)",
+                       "note": "keys + 32-byte records, (key, index) radix sort, one gather; median of 3, host-timed between two syncs"}
         # the launch the replacement advect.H issues between two frames of either tutorial (saveInterval 10: the cycles between
         # two output points fused into one launch), on a second fresh cloud in the same state as the one above started from
         from cudaparticlesfoam_amd import _lib as L

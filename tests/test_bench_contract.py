@@ -195,6 +195,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert bs["D"] == 1.5e-5 and bs["sort_interval"] == 25 and bs["sorts_inside"] == 1 and bs["steps"] == 30 and 0 < bs["frac"] < 1
         assert bs["kernel"] == b["kernel"] and bs["frac"] <= bs["kernel_frac"] * 1.02
         assert bs["fused_8_cycles_per_launch"]["ms_per_cycle"] > 0 and 0 < bs["fused_8_cycles_per_launch"]["frac"] < 1
+        assert bs["resort"]["ms"] > 0 and bs["resort"]["after_cycles"] == 25
         for blk in (bs, tj):            # the cycles as the fragments issue them: cpf_shard_step(10, CPF_STEP_FUSE_CYCLES), sorts inside
             assert blk["fragment_calls"]["cycles_per_call"] == 10 and blk["fragment_calls"]["ms_per_cycle"] > 0
         assert af["steps"] == 4 and af["kernel"] == d["roofline"]["kernel"] and 0 < af["frac"] < 1 and af["cells_visited_per_particle_step"] > 1
