@@ -212,32 +212,44 @@ def build_polymesh_from_cells(points: np.ndarray, cell_face_loops: List[List[Tup
                     nei_a[order_int].astype(np.int32), len(cell_face_loops), patches)
 
 
-def split_into_parts(mesh: "PolyMesh", n_parts: int) -> List["PolyMesh"]:
-    """What ``decomposePar`` hands the ranks, for contiguous cell ranges: piece p gets the cells
-    ``[p*nC/n_parts, (p+1)*nC/n_parts)`` with local cell ids, its own point list, its interior faces, then its
-    boundary faces -- the physical ones AND the faces cut by the decomposition (processor patches, oriented
-    outward from the piece like any boundary face).  Input of the rank-direct ingest (cpf_merge_mesh_parts)."""
+def split_into_parts(mesh: "PolyMesh", n_parts: int, cell_part=None) -> List["PolyMesh"]:
+    """What ``decomposePar`` hands the ranks: piece p gets its cells with local cell ids (in the order of their global
+    ids), its own point list, its interior faces, then its boundary faces -- the physical ones AND the faces cut by the
+    decomposition (processor patches, oriented outward from the piece like any boundary face).  Input of the rank-direct
+    ingest (cpf_merge_mesh_parts).  ``cell_part`` (optional, [n_cells] part ids): an arbitrary decomposition (what scotch
+    gives); default: contiguous ranges ``[p*nC/n_parts, (p+1)*nC/n_parts)`` ("simple")."""
     nC = mesh.n_cells
-    cuts = [(p * nC) // n_parts for p in range(n_parts + 1)]
+    if cell_part is None:
+        cuts = [(p * nC) // n_parts for p in range(n_parts + 1)]
+        cell_part = np.zeros(nC, dtype=np.int64)
+        for p in range(n_parts):
+            cell_part[cuts[p]:cuts[p + 1]] = p
+    cell_part = np.asarray(cell_part, dtype=np.int64)
+    assert cell_part.shape == (nC,) and cell_part.min() >= 0 and cell_part.max() < n_parts
+    local_cell = np.zeros(nC, dtype=np.int64)
+    for p in range(n_parts):
+        mine = np.nonzero(cell_part == p)[0]
+        local_cell[mine] = np.arange(mine.size)
     own = np.asarray(mesh.owner, dtype=np.int64)
     nei = np.full(own.shape[0], -1, dtype=np.int64)
     nei[: mesh.n_internal] = np.asarray(mesh.neighbour, dtype=np.int64)
+    own_part = cell_part[own]
+    nei_part = np.where(nei >= 0, cell_part[np.maximum(nei, 0)], -1)
     fo = np.asarray(mesh.face_offsets, dtype=np.int64); fv = np.asarray(mesh.face_verts, dtype=np.int64)
     parts = []
     for p in range(n_parts):
-        lo, hi = cuts[p], cuts[p + 1]
-        o_in = (own >= lo) & (own < hi)
-        n_in = (nei >= lo) & (nei < hi)
+        o_in = own_part == p
+        n_in = nei_part == p
         interior = np.nonzero(o_in & n_in)[0]
         as_owner = np.nonzero(o_in & ~n_in)[0]                  # physical boundary or cut face, we are the owner
         as_neigh = np.nonzero(~o_in & n_in)[0]                  # cut face, we are the neighbour: flip it
         faces, owners, neighs = [], [], []
         for f in interior:
-            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(own[f] - lo); neighs.append(nei[f] - lo)
+            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(local_cell[own[f]]); neighs.append(local_cell[nei[f]])
         for f in as_owner:
-            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(own[f] - lo)
+            faces.append(fv[fo[f]:fo[f + 1]]); owners.append(local_cell[own[f]])
         for f in as_neigh:
-            faces.append(fv[fo[f]:fo[f + 1]][::-1]); owners.append(nei[f] - lo)
+            faces.append(fv[fo[f]:fo[f + 1]][::-1]); owners.append(local_cell[nei[f]])
         used = np.unique(np.concatenate(faces)) if faces else np.zeros(0, np.int64)
         local = np.full(mesh.n_points, -1, dtype=np.int64)
         local[used] = np.arange(used.size)
@@ -246,5 +258,5 @@ def split_into_parts(mesh: "PolyMesh", n_parts: int) -> List["PolyMesh"]:
         verts = local[np.concatenate(faces)] if faces else np.zeros(0, np.int64)
         parts.append(PolyMesh(points=np.asarray(mesh.points)[used].copy(), face_offsets=offs.astype(np.int32),
                               face_verts=verts.astype(np.int32), owner=np.asarray(owners, dtype=np.int32),
-                              neighbour=np.asarray(neighs, dtype=np.int32), n_cells=hi - lo))
+                              neighbour=np.asarray(neighs, dtype=np.int32), n_cells=int((cell_part == p).sum())))
     return parts

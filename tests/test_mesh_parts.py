@@ -78,3 +78,66 @@ def test_a_baffle_inside_a_piece_stays_a_wall():
     assert merged2.n_internal == ni - 1 and merged2.n_faces == mesh.n_faces + 1
     pairs = set(zip(np.asarray(merged2.owner[:merged2.n_internal]).tolist(), np.asarray(merged2.neighbour).tolist()))
     assert (0, 1) not in pairs and (1, 2) in pairs             # the cut between the pieces WAS re-joined
+
+
+def _cell_signature(mesh):
+    """per cell: the sorted list of its faces as (frozenset of vertex coordinates, the cell across it or -1) -- what the walk
+    sees of a cell, whatever the face order, orientation or starting vertex"""
+    fo, fv, pts = np.asarray(mesh.face_offsets), np.asarray(mesh.face_verts), np.asarray(mesh.points)
+    own, nei, ni = np.asarray(mesh.owner), np.asarray(mesh.neighbour), mesh.n_internal
+    sig = [[] for _ in range(mesh.n_cells)]
+    for f in range(mesh.n_faces):
+        key = frozenset(map(tuple, pts[fv[fo[f]:fo[f + 1]]]))
+        if f < ni:
+            sig[own[f]].append((key, int(nei[f]))); sig[nei[f]].append((key, int(own[f])))
+        else:
+            sig[own[f]].append((key, -1))
+    return sig
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_arbitrary_decompositions_stitch_to_the_renumbered_mesh(seed, oracle_libs):
+    """What scotch hands the ranks, not `simple`: every cell goes to a random piece (pieces that are not connected, pieces that
+    touch every other piece, cuts along every face direction).  The stitched mesh numbers its cells piece by piece (global id =
+    cells of the lower pieces + local id): it must be the original mesh under exactly that renumbering -- every cell with the
+    same faces (as point sets) and the same cell across each --, have its interior faces upper-triangular, and carry particles
+    along the same paths (the CPU checker on both: same cells, positions to rounding -- a face the stitcher had to orient
+    the other way round has its plane from the reversed vertex loop)."""
+    rng = np.random.default_rng(seed)
+    mesh = box_mesh(*[int(v) for v in rng.integers(2, 7, size=3)])
+    n_parts = int(rng.integers(2, 7))
+    if seed % 2:
+        cell_part = rng.integers(0, n_parts, size=mesh.n_cells)                    # salt and pepper
+    else:                                                                          # blobs: nearest of n_parts random centres
+        centres, _ = mesh.cell_centres_volumes()
+        seeds_ = centres[rng.choice(mesh.n_cells, size=n_parts, replace=False)]
+        cell_part = np.argmin(((centres[:, None, :] - seeds_[None, :, :]) ** 2).sum(axis=2), axis=1)
+    cell_part[: n_parts] = np.arange(n_parts)                                      # (no empty piece)
+    parts = split_into_parts(mesh, n_parts, cell_part)
+    merged = merge_mesh_parts(parts)
+    assert merged.n_cells == mesh.n_cells and merged.n_points == mesh.n_points
+    assert merged.n_internal == mesh.n_internal and merged.n_faces == mesh.n_faces
+    assert (np.asarray(merged.owner[: merged.n_internal]) < np.asarray(merged.neighbour)).all()
+    # new id of an original cell: pieces one after the other, inside a piece by original id
+    order = np.lexsort((np.arange(mesh.n_cells), cell_part))                       # order[new] = old
+    new_of_old = np.empty(mesh.n_cells, np.int64); new_of_old[order] = np.arange(mesh.n_cells)
+    want, got = _cell_signature(mesh), _cell_signature(merged)
+    for old in range(mesh.n_cells):
+        w = sorted(((sorted(k), -1 if c < 0 else int(new_of_old[c])) for k, c in want[old]))
+        g = sorted(((sorted(k), c) for k, c in got[new_of_old[old]]))
+        assert w == g, (seed, old)
+    # the same particles through both meshes
+    cw = oracle_libs.CellWalk()
+    t0, t1 = cw.build(mesh), cw.build(merged)
+    U = rng.normal(size=(mesh.n_cells, 3)) * 0.7
+    U1 = U[order]
+    hi = np.asarray(mesh.points).max(axis=0)
+    xyz = rng.uniform([0, 0, 0], hi, size=(3000, 3))
+    a = [xyz[:, k].copy() for k in range(3)]; b = [xyz[:, k].copy() for k in range(3)]
+    ca, cb = cw.locate_initial(*a, t0), cw.locate_initial(*b, t1)
+    assert np.array_equal(new_of_old[ca], cb)
+    cw.step(*a, ca, 0.3, 12, t0, U); cw.step(*b, cb, 0.3, 12, t1, U1)
+    same_cell = new_of_old[ca] == cb
+    assert same_cell.mean() > 0.995                     # (a particle within rounding of a face may end on its other side)
+    for k in range(3):
+        assert np.abs(a[k] - b[k])[same_cell].max() < 1e-11
