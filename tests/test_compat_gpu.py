@@ -192,6 +192,38 @@ def test_random_dictionaries_parallel_equals_serial(tmp_path, pitz, seed):
         assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), (f, seed, d, n_procs, cycles, esteps)
 
 
+def test_parallel_fragments_on_an_irregular_decomposition(tmp_path, pitz):
+    """What scotch hands the ranks: every cell goes to the nearest of four random centres (pieces of unequal size with ragged
+    cuts).  The stitched mesh numbers the cells piece by piece, so cell ids come out permuted and a cut face may be oriented the
+    other way round (its plane then comes from the reversed vertex loop): the same particles as the serial run, cells equal
+    under the renumbering, positions equal to rounding."""
+    from case_dump import dump_case
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    mesh, U = pitz["mesh"], pitz["U_analytic"]
+    rng = np.random.default_rng(99)
+    n_procs = 4
+    centres, _ = mesh.cell_centres_volumes()
+    pick = centres[rng.choice(mesh.n_cells, size=n_procs, replace=False)]
+    cell_part = np.argmin(((centres[:, None, :2] - pick[None, :, :2]) ** 2).sum(axis=2), axis=1)
+    order = np.lexsort((np.arange(mesh.n_cells), cell_part))                       # order[new] = old
+    new_of_old = np.empty(mesh.n_cells, np.int64); new_of_old[order] = np.arange(mesh.n_cells)
+    case = str(tmp_path / "case")
+    dump_case(case, mesh, U, DICT, 1.0, DELTA_T)
+    ser = tmp_path / "serial"; ser.mkdir()
+    xs, cs, outs = _run("mockUncoupledFoam", case, str(ser))
+    for r, part in enumerate(split_into_parts(mesh, n_procs, cell_part)):
+        dump_case(os.path.join(case, "processor%d" % r), part, U[cell_part == r], DICT, 1.0, DELTA_T)
+    par = tmp_path / "parallel"; par.mkdir()
+    xp, cp, outp = _run("mockParallelFoam", case, str(par), extra=[str(n_procs)])
+    assert ("%d GPUs" % n_procs) in outp
+    live = cs >= 0
+    assert np.array_equal(live, cp >= 0)
+    same = new_of_old[np.maximum(cs, 0)] == cp
+    assert same[live].mean() > 0.999
+    assert np.abs(xp - xs)[live & same].max() < 1e-12
+    assert int(outp.split(" re-cuts, ")[1].split()[0]) > 0                 # particles did change hands
+
+
 def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
     """cudaAdvect -> cudaBrownianMotion -> convexTetQuery -> convexWallReflect -> cudaMoveParticles on the
     reference's AoS arrays == the fused kernel, bit for bit (D = 0 and D > 0: same counter-based stream).  The stages
