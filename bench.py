@@ -64,8 +64,10 @@ def parse(argv=None):
                          "of the cloud (discarded): an MI355X needs ~30 ms of load after an idle phase to reach its "
                          "steady clocks (tools/drift_check.py: 0.148 -> 0.119 ms per launch of the same work), and the "
                          "set-up before the timed region leaves it idle for seconds; 0 = off")
-    ap.add_argument("--timing-stride", type=int, default=4,
-                    help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms)")
+    ap.add_argument("--timing-stride", type=int, default=20,
+                    help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms).  The stamps are "
+                         "not free: measured on one box, 100 steps: every 4th launch 85.4-86.2 G, every 10th 87.1-88.5, every 25th "
+                         "88.9-90.4 -- hence 5 samples per 100 launches, not 25")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="N>1 (or --force-dist): run ONLY communicator init -> first re-cut -> one all-to-all-v with per-stage "
                          "timings, print them as the one JSON line and exit: a failing scaling run then costs seconds and "
@@ -579,7 +581,7 @@ class GpuMachine:
 
     @staticmethod
     def _timed_steps(torch, ctx, cl, dt, steps, D, bytes_per):
-        ctx.set_option("timing_stride", 4)
+        ctx.set_option("timing_stride", 10)
         ctx.timing_enable(True); ctx.timing_read()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -819,8 +821,10 @@ def run(args, M):
     counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
     ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
     n_before = cloud.global_count()
-    # live kernel timing for the roofline: HIP events around every 4th launch of the timed region (a pair around
-    # EVERY launch costs 3.5 % of the throughput it is there to measure: 0.166 vs 0.160 ms/step)
+    # live kernel timing for the roofline: HIP events around every k-th launch of the timed region (a pair around
+    # EVERY launch costs 3.5 % of the throughput it is there to measure, around every 4th still 4 %: see --timing-stride);
+    # at least five samples, and every 8th launch at most where the balancer cuts by these times (N > 1)
+    args.timing_stride = max(1, min(args.timing_stride, args.steps // 5, 8 if (args.gpus > 1 or args.force_dist) else 1 << 30))
     ctx.set_option("timing_stride", args.timing_stride)
     ctx.timing_enable(True)
     ctx.timing_read()                              # drop the warm-up launches' events
