@@ -64,10 +64,10 @@ def parse(argv=None):
                          "of the cloud (discarded): an MI355X needs ~30 ms of load after an idle phase to reach its "
                          "steady clocks (tools/drift_check.py: 0.148 -> 0.119 ms per launch of the same work), and the "
                          "set-up before the timed region leaves it idle for seconds; 0 = off")
-    ap.add_argument("--timing-stride", type=int, default=20,
+    ap.add_argument("--timing-stride", type=int, default=10,
                     help="HIP-event pair around every k-th step launch of the timed region (roofline.kernel_avg_ms).  The stamps are "
-                         "not free: measured on one box, 100 steps: every 4th launch 85.4-86.2 G, every 10th 87.1-88.5, every 25th "
-                         "88.9-90.4 -- hence 5 samples per 100 launches, not 25")
+                         "not free, by an amount that depends on the box: 100 steps, every 4th / 10th / 25th launch: 85.4-86.2 / "
+                         "87.1-88.5 / 88.9-90.4 G on one box, 87.4 against 88.0 G (4th / 20th, six alternating runs each) on another")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="N>1 (or --force-dist): run ONLY communicator init -> first re-cut -> one all-to-all-v with per-stage "
                          "timings, print them as the one JSON line and exit: a failing scaling run then costs seconds and "
@@ -822,7 +822,7 @@ def run(args, M):
     ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
     n_before = cloud.global_count()
     # live kernel timing for the roofline: HIP events around every k-th launch of the timed region (a pair around
-    # EVERY launch costs 3.5 % of the throughput it is there to measure, around every 4th still 4 %: see --timing-stride);
+    # EVERY launch costs 3.5 % of the throughput it is there to measure, around every 4th 0.6-4 %: see --timing-stride);
     # at least five samples, and every 8th launch at most where the balancer cuts by these times (N > 1)
     args.timing_stride = max(1, min(args.timing_stride, args.steps // 5, 8 if (args.gpus > 1 or args.force_dist) else 1 << 30))
     ctx.set_option("timing_stride", args.timing_stride)

@@ -637,7 +637,11 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
         if (timed) {
             auto take = [&](hipEvent_t& ev) -> hipError_t {
                 if (!ctx->eventPool.empty()) { ev = ctx->eventPool.back(); ctx->eventPool.pop_back(); return hipSuccess; }
-                return hipEventCreate(&ev);
+                // (device-scope release is all a time stamp needs; measured against the default flags: no difference)
+#ifndef CPF_TIMING_EVENT_FLAGS
+#define CPF_TIMING_EVENT_FLAGS hipEventReleaseToDevice
+#endif
+                return hipEventCreateWithFlags(&ev, CPF_TIMING_EVENT_FLAGS);
             };
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             // the streaming launcher stamps the events with the dispatch's own begin / end (cpf_device.h, StreamState);
