@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 N_TOTAL = 40_000
 
 
-@pytest.mark.parametrize("block", range(6))
+@pytest.mark.parametrize("block", range(int(os.environ.get("CPF_FUZZ_BLOCKS", "6"))))       # (a longer campaign: CPF_FUZZ_BLOCKS=60)
 def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
     import torch
     from cudaparticlesfoam_amd import _lib as L
