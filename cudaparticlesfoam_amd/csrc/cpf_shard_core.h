@@ -741,12 +741,16 @@ class ShardCore {
 
     void stats(cpf_shard_stats* o) {
         // device time of the hand-off collectives so far ("profile_comm"): completed pairs are read once; never waits
-        for (; commEventsRead < commEvents.size(); ++commEventsRead) {
+        size_t done = 0;
+        for (; done < commEvents.size(); ++done) {
             float ms = 0.f;
-            if (!dev.eventDone(commEvents[commEventsRead].second)) break;
-            if (dev.eventElapsed(commEvents[commEventsRead].first, commEvents[commEventsRead].second, &ms) != CPF_OK) break;
+            if (!dev.eventDone(commEvents[done].second)) break;
+            if (dev.eventElapsed(commEvents[done].first, commEvents[done].second, &ms) != CPF_OK) break;
             commMsRead += (double)ms;
+            dev.eventDestroy(commEvents[done].first); dev.eventDestroy(commEvents[done].second);   // (a long run does not pile them up)
         }
+        commEvents.erase(commEvents.begin(), commEvents.begin() + (std::ptrdiff_t)done);
+        commEventsRead += done;
         o->n = n; o->capacity = cap; o->stepIndex = (int64_t)stepIndex;
         o->particleSteps = particleSteps; o->handedOff = handedOff; o->exchanges = exchanges; o->rebalances = rebalances;
         o->grown = grown; o->sendGrown = sendGrown; o->kernelLaunches = kernelLaunches; o->kernelMs = kernelMs;
