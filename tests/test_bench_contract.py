@@ -78,6 +78,26 @@ def test_world_2_orchestration_over_gloo_prints_one_strong_scaling_line():
     assert "configs[3]" in c["workload"] and "strong" in c["workload"]
 
 
+def test_dry_collectives_over_gloo_prints_the_stage_timings_and_exits():
+    """`--dry-collectives`: communicator init -> first re-cut -> one all-to-all-v, the three timed, ONE JSON line, exit 0 -- what a
+    first multi-GPU run is started with so that a failing collective costs seconds and is named (here: world 2 on CPU)."""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_bench_worker.py"), "--gpus", "2",
+           "--particles", "4000", "--dry-collectives"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    dry = d["dry_collectives"]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["particles_total"] == 4000
+    assert dry["first_recut_and_handoff_s"] >= 0 and dry["second_handoff_s"] >= 0 and dry["handed_off"] >= 0
+    assert 0 < dry["particles_on_rank0"] < 4000
+
+
 def test_a_rank_that_hangs_becomes_an_error_line_within_the_limit():
     """`python bench.py --gpus 2` starts its ranks as a child process tree under a wall-clock limit.  Here rank 1 never
     reaches its first collective (the CPU stand-in over gloo sleeps instead): the parent must kill the whole tree when
@@ -157,6 +177,21 @@ def test_plain_gpus_n_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert "error" in d and "metric" not in d and d["n_gpus"] == 2 and d["stage"] in ("launch", "rccl_init")
+
+
+@pytest.mark.gpu
+def test_dry_collectives_on_a_one_rank_rccl_group():
+    """The same on the GPU: a real RCCL communicator of one rank (--force-dist), the library's all-gather / all-reduce / grouped
+    send-recv issued once each, timings printed, exit 0."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e5", "--force-dist", "--dry-collectives"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["particles_total"] == 200_000
+    assert d["dry_collectives"]["comm_init_s"] > 0 and d["dry_collectives"]["particles_on_rank0"] == 200_000
 
 
 @pytest.mark.gpu
