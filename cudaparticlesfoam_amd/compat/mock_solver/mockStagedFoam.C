@@ -6,6 +6,7 @@
 #include "cuda/DeviceTetMesh.cuh"
 #include "query/ConvexQuery.h"
 #include "query/RTQuery.h"
+#include <string>
 #include "optix/OptixQuery.h"
 
 #include "fvCFD.H"
@@ -56,15 +57,28 @@ extern "C" int main(int argc, char* argv[])
 
         int nCycles = max(ceil(runTime.deltaT().value() / dt), 1);
         double cycleDt = runTime.deltaT().value() / nCycles;
+        // argv[2] == "rtx": the reference's usingRTX branch of the cycle (src/advect.H:126-135): RTQuery in displacement mode and
+        // RTWallReflect, whose disps / vels arguments come in the OTHER order than convexWallReflect's
+        const bool usingRTX = argc > 2 && std::string(argv[2]) == "rtx";
+        cudaTimer timer;
+        timer.start();
         for (int i = 0; i < nCycles; i++) {
             cudaAdvect(d_particles, d_particles_ConvextetIDs, d_particle_vels, d_particle_disps, cycleDt, numParticles,
                        devMesh.d_indices, devMesh.d_positions, devMesh.d_velocities, "TetVelocity");
             cudaBrownianMotion(d_particles, d_particle_disps, &rand_states, cycleDt, numParticles, diffusionCoeff);
-            convexTetQuery(devMesh, d_particles, d_particle_disps, d_particles_ConvextetIDs, numParticles);
-            convexWallReflect(devMesh, d_particles_ConvextetIDs, d_particles, d_particle_vels, d_particle_disps,
-                              numParticles);
+            if (usingRTX) {
+                RTQuery(devMesh, d_particles, d_particle_disps, d_particles_ConvextetIDs, numParticles);
+                RTWallReflect(devMesh, d_particles_ConvextetIDs, d_particles, d_particle_disps, d_particle_vels, numParticles);
+            } else {
+                convexTetQuery(devMesh, d_particles, d_particle_disps, d_particles_ConvextetIDs, numParticles);
+                convexWallReflect(devMesh, d_particles_ConvextetIDs, d_particles, d_particle_vels, d_particle_disps,
+                                  numParticles);
+            }
             cudaMoveParticles(d_particles, d_particle_disps, numParticles, d_particles_ConvextetIDs);
         }
+        const double cycleMs = timer.stop();
+        std::printf("#mock: %s particles, %d cycles (%s) in %.3f ms\n", prettyNumber((std::size_t)numParticles).c_str(), nCycles,
+                    usingRTX ? "RTQuery + RTWallReflect" : "convexTetQuery + convexWallReflect", cycleMs);
         writeParticles2VTU(nCycles, d_particles, d_particle_vels, d_particles_ConvextetIDs, numParticles,
                            d_particles_ConvextetIDs);
         std::vector<double> xyzw((size_t)numParticles * 4);

@@ -243,6 +243,13 @@ def test_staged_shims_match_fused_kernel(tmp_path, pitz, gpu_ctx_factory):
         fx, fc, _ = _expected(pitz, gpu_ctx_factory, D=D)                      # the default: end point mirrored before the walk
         assert (fc == ec).mean() > 0.9995 and np.abs(fx[:, :3] - ex[:, :3])[fc == ec].max() < 1e-12
         assert os.path.exists(str(wd / "particle_0035.vtu")) and "System Kinetic Energy" in out
+        assert "#mock: 20.00K particles, 35 cycles (convexTetQuery + convexWallReflect)" in out       # (prettyNumber, cudaTimer)
+        # the reference's RTX branch of the cycle (src/advect.H:126-135): RTQuery in displacement mode + RTWallReflect -- whose disps /
+        # vels arguments come in the other order -- resolve to the same plane walk: the same bits
+        wr = tmp_path / ("rtx%g" % D); wr.mkdir()
+        rx, rc, rout = _run("mockStagedFoam", case, str(wr), extra=["rtx"])
+        assert np.array_equal(rx, xyzw) and np.array_equal(rc, cell) and "(RTQuery + RTWallReflect)" in rout
+        assert open(str(wr / "particle_0035.vtu"), "rb").read() == open(str(wd / "particle_0035.vtu"), "rb").read()
 
 
 def test_tjunction_allrun_parallel_equals_serial(tmp_path):
