@@ -1,10 +1,10 @@
 // Streaming step kernel (gfx950 / CDNA4, wave64): all-hex meshes, and meshes with a minority of other cells (mixed cell
-// records: padded, face groups, header records -- the LOOKUP 2 / 3 / 5 instantiations; DESIGN.md 5.1 has the table; LOOKUP 6:
+// records: padded, face groups, header records -- the LOOKUP 2 / 3 / 5 instantiations; docs/design_r04.md 5.1 has the table; LOOKUP 6:
 // box records, 8 / 9: the flat walk of 2-D cases).
 //
 // Same fused cycle and the same per-particle arithmetic as step_kernel_coop (cpf_kernels.hip) -- advect -> Brownian
 // kick -> plane-exit walk -> wall reflect -> move, src/advect.H:96-161 -- organised around what the measurements of
-// that kernel say bounds it: a wave that walks has no HBM request in flight, so the particle
+// that kernel say bounds it (docs/design_r04.md section 5): a wave that walks has no HBM request in flight, so the particle
 // stream and the walk ADD instead of overlapping, and every round of the walk pays an L2 round trip for its records.
 //
 //   * The grid is persistent: single-wave workgroups, as many as the chip holds.  A wave works through CHUNKS of
@@ -27,7 +27,7 @@
 // going to particles whose loads are already in flight -- is what the prefetch does at tile granularity, and the
 // sort key (cell, position in the cell's box) keeps the lanes of a tile in step.  (The per-lane version of that idea,
 // lanes running ahead into the next tile, is step_kernel_ahead in cpf_ahead.hip: fewer rounds, dearer rounds,
-// slower on every mesh -- DESIGN.md 5.4.)
+// slower on every mesh -- docs/design_r04.md 5.4.)
 #include "cpf_stream_ops.h"
 
 #include <hip/hip_ext.h>
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     //   five waves per SIMD.  2.1e6-cell box: 1.25e6 particles (one rank's share of BASELINE configs[4]) 0.187 -> 0.141 ms,
     //   1e7 particles 0.673 / 0.631 -> 0.641 / 0.607; in the dense regime the same change costs 6 % (0.259 -> 0.277)
     //   5 = as 3 (mixed records without header records) with the LOOP lookup and six slots: a refined mesh that still holds
-    //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see DESIGN.md 5.6)
+    //   hundreds of particles per cell (pitzDaily with a 2:1 patch: 0.157 -> see docs/design_r04.md 5.6)
     //   6 = as 1 on the mesh's 128-byte BOX records (every cell an axis-aligned box: cpf_walk.h "box records") -- dense and sparse
     //   clouds alike: three candidate faces per visit, one LDS round trip per record, one cache line per gathered record
     //   8 = as 0 with the FLAT walk (cpf_walk.h): a 2-D mesh extruded straight in z, a field without a z component, no kick
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                                 asm volatile("" ::: "memory");
                                 E = {sE[0][lane], sE[1][lane], sE[2][lane]};
                                 if (kInRound) {
-                                    // reflect INSIDE the round (CPF_STREAM_INROUND; measured slower): mirror here and
+                                    // reflect INSIDE the round (CPF_STREAM_INROUND; measured slower, docs/design_r04.md 5.5): mirror here and
                                     // walk on at once instead of in the next round
                                     park_hit(S_);
                                     if (STATS) ++st.refl;

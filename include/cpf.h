@@ -231,7 +231,7 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *                   4 streaming kernel: persistent waves, next tile prefetched into LDS while the current
  *                     one is walked, per-wave record cache kept across tiles (cudaparticlesfoam_amd/csrc/cpf_stream.hip);
  *                     all-hex meshes, and meshes with a minority of other cells ("mixed_records")
- *                   1, 2, 5 experiments, measured SLOWER than 3 / 4 on every mesh: per-lane gathers,
+ *                   1, 2, 5 experiments, measured SLOWER than 3 / 4 on every mesh (docs/design_r04.md 5.4): per-lane gathers,
  *                     + scalar plane fetches, run-ahead lanes (cpf_ahead.hip).  Only in libraries built with
  *                     `make EXPERIMENTS=1`; the default build answers CPF_ERR_ARG
  *   "z_fold" (1)    with the Brownian kick on a mesh that is one cell thick in z, mirror the kicked end point about the front /
