@@ -5,7 +5,7 @@
 // reflect -> move.  The walk runs on the polyMesh cells themselves (CSR face slots with
 // precomputed inward planes), not on a 12-tets-per-cell decomposition, and needs no BVH.
 //
-// Arithmetic contract ("Oracle and numerics"): fp64 like the reference (cuda/common.h:26);
+// Arithmetic contract ("Numerics, the oracle, and what is pinned"): fp64 like the reference (cuda/common.h:26);
 // dot products and axpy use explicit fma(), nothing else may be contracted (-ffp-contract=off),
 // divisions are IEEE.  tests/ compare bit-for-bit with an independent CPU statement.
 #include "cpf_device.h"
