@@ -151,6 +151,17 @@ def test_random_worlds_on_the_gpu(block, oracle_libs, tmp_path):
                     if call["gather"]:
                         whole = cloud.gather(0)
                         assert (whole[0] is not None) == (rank == 0)
+                    extra = call.get("extra")
+                    if extra == "sort":
+                        cloud.sort()
+                    elif extra == "exchange":
+                        cloud.exchange()
+                    elif extra == "rebalance":
+                        cloud.rebalance()
+                    elif extra == "send_fraction":
+                        cloud.send_fraction = 0.02 if cloud.send_fraction > 0.5 else 1.0
+                    elif extra == "flush":
+                        cloud.flush()
                 cloud.flush()
                 total = cloud.global_count()
                 g, gx, gy, gz, gc = cloud.gather_to_numpy()

@@ -30,9 +30,12 @@ def _draw(rng):
     calls, left = [], CYCLES
     while left > 0:
         k = int(min(left, rng.integers(1, 10)))
-        kind = rng.integers(0, 10)
+        kind = rng.integers(0, 14)
         calls.append(dict(cycles=k, flags=(FUSE if rng.integers(0, 2) else 0) | (STORE_VEL if kind == 0 else 0),
-                          new_u=(kind in (1, 2)), slices=(kind == 2), gather=(kind == 3)))
+                          new_u=(kind in (1, 2)), slices=(kind == 2), gather=(kind == 3),
+                          # explicit collectives and knobs between two calls (the same on every rank): they change who holds what
+                          # and in which order, never a particle
+                          extra={4: "sort", 5: "exchange", 6: "rebalance", 7: "send_fraction", 8: "flush"}.get(int(kind))))
         left -= k
     cfg["calls"] = calls
     return cfg
@@ -134,6 +137,17 @@ def test_random_worlds_cadences_and_call_patterns(block, oracle_libs, tmp_path):
                     if call["gather"]:
                         whole = cloud.gather(0)
                         assert (whole[0] is not None) == (rank == 0)
+                    extra = call.get("extra")
+                    if extra == "sort":
+                        cloud.sort()
+                    elif extra == "exchange":
+                        cloud.exchange()
+                    elif extra == "rebalance":
+                        cloud.rebalance()
+                    elif extra == "send_fraction":
+                        cloud.send_fraction = 0.02 if cloud.send_fraction > 0.5 else 1.0
+                    elif extra == "flush":
+                        cloud.flush()
                 cloud.flush()
                 total = cloud.global_count()
                 g, gx, gy, gz, gc = cloud.gather_to_numpy()
