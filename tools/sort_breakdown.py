@@ -30,7 +30,7 @@ def main():
         if n.startswith("cpf::gather_a"):
             first = [k for k, c in enumerate(cur) if c[0] in starts]
             seq, cur = (cur[min(first):] if first else []), []
-            if not seq or (seq[-1][2] > 9e6) != case.startswith("pitz"):
+            if not seq or (seq[-1][2] > 3e6) != case.startswith("pitz"):     # (the gather takes two destinations per thread)
                 continue
             kind = "0 (hipcub)" if any("rocprim" in c[0] for c in seq) else ("2 (tile reorder)" if any("rt_scatter" in c[0] for c in seq)
                                                                              else "1 (wide digits, removed)")
