@@ -729,6 +729,10 @@ class GpuMachine:
             if not args.no_fused_tutorial:
                 cl.sort(); cl.step_index = 0
                 r["fragment_calls"] = self._fragment_calls(torch, cl, dt, args.tjunction_steps, Db, ALGO_BYTES_PER_PARTICLE_STEP + 8)
+                r["fragment_calls"]["note"] += ("; 10 cycles = one Eulerian step of the tutorial (deltaT 1e-3, dt 1e-4) with the dictionary's "
+                                                "alternative `saveInterval 1e16` (TJunction/system/cudaParticlesDict:29); with its `saveInterval 2` "
+                                                "every launch is ONE cycle and every second one writes a frame of 4e6 particles: the unfused "
+                                                "figure above, in a run that is bound by the frame writer")
             del cl
         finally:
             ctx2.close()
