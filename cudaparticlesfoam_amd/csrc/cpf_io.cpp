@@ -25,14 +25,21 @@ namespace {
 
 // Formatting dominates the output path (printf of "%.15lf": 2.4 us per particle and frame on one core, 240 ms for
 // the tutorial's 1e5 particles against 10 ms of GPU time for the 1000 cycles between two frames), so every
-// DataArray is formatted in parallel: chunks of 32768 particles, one std::thread each, the texts written in order.
-// The bytes are those of the serial loop.
-constexpr long long kChunk = 32768;
+// DataArray is formatted in parallel: chunks of 8192 particles, one std::thread each (at most 64, or the machine's cores), the
+// texts written in order.  The bytes are those of the serial loop.  (Round 5, the tutorial's 1e5 particles on a 256-core box: a
+// frame is out after 10-18 ms with 8192 x 64, 22-23 ms with round 3's 32768 x 16; at 4e6 particles the file system decides.)
+#ifndef CPF_WRITER_CHUNK
+#define CPF_WRITER_CHUNK 8192
+#endif
+constexpr long long kChunk = CPF_WRITER_CHUNK;
 
 int writer_threads(long long n) {
     const unsigned hw = std::thread::hardware_concurrency();
     const long long want = (n + kChunk - 1) / kChunk;
-    return (int)std::max<long long>(1, std::min<long long>({want, (long long)(hw ? hw : 1), 16}));
+#ifndef CPF_WRITER_MAX_THREADS
+#define CPF_WRITER_MAX_THREADS 64
+#endif
+    return (int)std::max<long long>(1, std::min<long long>({want, (long long)(hw ? hw : 1), CPF_WRITER_MAX_THREADS}));
 }
 
 // ---- "%.Nlf" without printf.  glibc prints the EXACT decimal expansion of the double, rounded half-to-even at the

@@ -6,8 +6,8 @@ import torch
 from cudaparticlesfoam_amd.api import Context
 from cudaparticlesfoam_amd.cases import pitzdaily as pz
 mesh = pz.pitzdaily_mesh(); c, _ = mesh.cell_centres_volumes()
-for n in (1_000_000, 4_000_000, 10_000_000):
-    ctx = Context(0); ctx.set_mesh(mesh); ctx.set_velocity(pz.analytic_step_u(mesh, c)); ctx.set_option("vtu_binary", 1)
+for n in [int(float(v)) for v in os.environ.get("FRAME_N", "1e6,4e6,1e7").split(",")]:
+    ctx = Context(0); ctx.set_mesh(mesh); ctx.set_velocity(pz.analytic_step_u(mesh, c)); ctx.set_option("vtu_binary", int(os.environ.get("FRAME_BINARY", "1")))
     ctx.seed_box(n, *pz.DOMAIN_BOX, 1); ctx.locate_initial()
     ctx.step(1e-4, 1.5e-5, 10, 4); ctx.synchronize()
     t0 = time.perf_counter(); ctx.step(1e-4, 1.5e-5, 10, 4); ctx.synchronize(); cyc = (time.perf_counter() - t0) / 10 * 1e3
