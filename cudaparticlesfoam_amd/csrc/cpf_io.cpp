@@ -9,6 +9,7 @@
 //   * KEs holds the kinetic energy (the reference prints 0 for every non-zero KE);
 //   * no system("pause") on NaN: the function returns CPF_ERR_STATE instead.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -26,8 +27,9 @@ namespace {
 // Formatting dominates the output path (printf of "%.15lf": 2.4 us per particle and frame on one core, 240 ms for
 // the tutorial's 1e5 particles against 10 ms of GPU time for the 1000 cycles between two frames), so every
 // DataArray is formatted in parallel: chunks of 8192 particles, one std::thread each (at most 64, or the machine's cores), the
-// texts written in order.  The bytes are those of the serial loop.  (Round 5, the tutorial's 1e5 particles on a 256-core box: a
-// frame is out after 10-18 ms with 8192 x 64, 22-23 ms with round 3's 32768 x 16; at 4e6 particles the file system decides.)
+// texts written in order.  The bytes are those of the serial loop.  (Round 5, a 256-core box: the tutorial's 1e5 particles are
+// out after 9-16 ms -- 22-23 ms with round 3's 32768 x 16 in barrier-separated groups --, TJunction's 4e6 after 140-240 ms, was
+// 250-580.)
 #ifndef CPF_WRITER_CHUNK
 #define CPF_WRITER_CHUNK 8192
 #endif
@@ -49,9 +51,20 @@ int writer_threads(long long n) {
 // 1.2 million doubles of every magnitude and the edge cases (tests/test_vtu_writer.py).  ~10x faster than printf.
 typedef unsigned __int128 u128;
 
+// "00" "01" ... "99"
+struct DigitPairs {
+    char t[200];
+    constexpr DigitPairs() : t() { for (int i = 0; i < 100; ++i) { t[2 * i] = (char)('0' + i / 10); t[2 * i + 1] = (char)('0' + i % 10); } }
+};
+constexpr DigitPairs kDigitPairTable{};
+constexpr const char* kDigitPairs = kDigitPairTable.t;
+
 inline char* put_u64(char* p, unsigned long long v) {
+    if (v < 10) { *p++ = (char)('0' + v); return p; }          // (coordinates and velocities of order one: the usual case)
     char tmp[24]; int k = 0;
-    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (v >= 100) { const unsigned d = (unsigned)(v % 100); v /= 100; tmp[k++] = kDigitPairs[2 * d + 1]; tmp[k++] = kDigitPairs[2 * d]; }
+    if (v >= 10) { tmp[k++] = kDigitPairs[2 * v + 1]; tmp[k++] = kDigitPairs[2 * v]; }
+    else tmp[k++] = (char)('0' + v);
     while (k) *p++ = tmp[--k];
     return p;
 }
@@ -93,7 +106,10 @@ inline void append_fixed(std::string& out, double x) {
     if (neg) *p++ = '-';
     p = put_u64(p, ip);
     *p++ = '.';
-    for (int k = N - 1; k >= 0; --k) { p[k] = (char)('0' + (fp % 10)); fp /= 10; }
+    // the N fractional digits, two at a time out of a table (half the divisions of the digit-by-digit loop)
+    int k = N;
+    for (; k >= 2; k -= 2) { const unsigned d = (unsigned)(fp % 100); fp /= 100; p[k - 2] = kDigitPairs[2 * d]; p[k - 1] = kDigitPairs[2 * d + 1]; }
+    if (k == 1) p[0] = (char)('0' + (fp % 10));
     p += N;
     out.append(b, (size_t)(p - b));
 }
@@ -114,32 +130,34 @@ inline void append_fixed3(std::string& out, double a, double b, double c) {
     append_fixed<N>(out, c); out.push_back('\n');
 }
 
-// item(i, buf) appends the text of element i to buf
+// item(i, buf) appends the text of element i to buf.  All chunks of the array are formatted first -- T threads taking chunk
+// numbers from a counter, each chunk into its own string (no barrier between groups of chunks, T thread starts per array
+// instead of T per group) -- and then written in order.  `bytesPerItem`: the size the strings are reserved with.
 template <typename F>
-bool write_array(FILE* fp, long long n, const F& item) {
+bool write_array(FILE* fp, long long n, int bytesPerItem, const F& item) {
     const int T = writer_threads(n);
     const long long nChunks = (n + kChunk - 1) / kChunk;
-    std::vector<std::string> text((size_t)T);
-    for (long long c0 = 0; c0 < nChunks; c0 += T) {
-        const int live = (int)std::min<long long>(T, nChunks - c0);
-        auto work = [&](int t) {
-            std::string& out = text[(size_t)t];
-            out.clear();
-            const long long i0 = (c0 + t) * kChunk, i1 = std::min(n, i0 + kChunk);
-            out.reserve((size_t)(i1 - i0) * 24);
+    std::vector<std::string> text((size_t)nChunks);
+    std::atomic<long long> next{0};
+    auto work = [&] {
+        for (;;) {
+            const long long c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= nChunks) return;
+            std::string& out = text[(size_t)c];
+            const long long i0 = c * kChunk, i1 = std::min(n, i0 + kChunk);
+            out.reserve((size_t)(i1 - i0) * (size_t)bytesPerItem);
             for (long long i = i0; i < i1; ++i) item(i, out);
-        };
-        if (live == 1) work(0);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 1; t < live; ++t) pool.emplace_back(work, t);
-            work(0);
-            for (auto& th : pool) th.join();
         }
-        for (int t = 0; t < live; ++t)
-            if (!text[(size_t)t].empty() && std::fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), fp) != text[(size_t)t].size())
-                return false;
+    };
+    if (T == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
     }
+    for (const std::string& s : text)
+        if (!s.empty() && std::fwrite(s.data(), 1, s.size(), fp) != s.size()) return false;
     return true;
 }
 
@@ -157,38 +175,38 @@ extern "C" int cpf_write_vtu_arrays(const char* path, int64_t n, const double* x
     std::fprintf(fp, "<Piece NumberOfCells='%lld' NumberOfPoints='%lld'>\n", N, N);
     std::fprintf(fp, "<Points>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='3' type='Float64' Name='Position' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) {
+    ok &= write_array(fp, N, 64, [&](long long i, std::string& o) {
         append_fixed3<15>(o, xyzw[4 * i], xyzw[4 * i + 1], xyzw[4 * i + 2]); });
     std::fprintf(fp, "</DataArray>\n</Points>\n<PointData>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='ParticleType' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, (int)xyzw[4 * i + 3]); });
+    ok &= write_array(fp, N, 4, [&](long long i, std::string& o) { append_int(o, (int)xyzw[4 * i + 3]); });
     std::fprintf(fp, "</DataArray>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='ParticleID' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i); });
+    ok &= write_array(fp, N, 12, [&](long long i, std::string& o) { append_int(o, i); });
     std::fprintf(fp, "</DataArray>\n");
     for (const char* name : {"ParticleTetID", "ConvexTetID"}) {
         std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Int32' Name='%s' format='ascii'>\n", name);
-        ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, cell[i]); });
+        ok &= write_array(fp, N, 12, [&](long long i, std::string& o) { append_int(o, cell[i]); });
         std::fprintf(fp, "</DataArray>\n");
     }
     std::fprintf(fp, "<DataArray NumberOfComponents='3' type='Float32' Name='vels' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) {
+    ok &= write_array(fp, N, 40, [&](long long i, std::string& o) {
         if (std::isnan(vel[4 * i])) append_fixed3<6>(o, 0.0, 0.0, 0.0);
         else append_fixed3<6>(o, vel[4 * i], vel[4 * i + 1], vel[4 * i + 2]); });
     std::fprintf(fp, "</DataArray>\n");
     std::fprintf(fp, "<DataArray NumberOfComponents='1' type='Float32' Name='KEs' format='ascii'>\n");
     auto keOf = [&](long long i) {
         return 0.5 * (vel[4 * i] * vel[4 * i] + vel[4 * i + 1] * vel[4 * i + 1] + vel[4 * i + 2] * vel[4 * i + 2]); };
-    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_fixed<6>(o, keOf(i)); o.push_back('\n'); });
+    ok &= write_array(fp, N, 16, [&](long long i, std::string& o) { append_fixed<6>(o, keOf(i)); o.push_back('\n'); });
     double total = 0.0;
     for (long long i = 0; i < N; ++i) total += keOf(i);              // in index order, like the reference's running sum
     std::fprintf(fp, "</DataArray>\n</PointData>\n<Cells>\n");
     std::fprintf(fp, "<DataArray type='Int32' Name='connectivity' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i); });
+    ok &= write_array(fp, N, 12, [&](long long i, std::string& o) { append_int(o, i); });
     std::fprintf(fp, "</DataArray>\n<DataArray type='Int32' Name='offsets' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long i, std::string& o) { append_int(o, i + 1); });
+    ok &= write_array(fp, N, 12, [&](long long i, std::string& o) { append_int(o, i + 1); });
     std::fprintf(fp, "</DataArray>\n<DataArray type='UInt8' Name='types' format='ascii'>\n");
-    ok &= write_array(fp, N, [&](long long, std::string& o) { o.append("1\n"); });
+    ok &= write_array(fp, N, 2, [&](long long, std::string& o) { o.append("1\n"); });
     std::fprintf(fp, "</DataArray>\n</Cells>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n");
     const bool bad = !ok || std::ferror(fp) != 0;
     std::fclose(fp);
