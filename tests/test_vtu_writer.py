@@ -70,6 +70,24 @@ def test_vtu_bytes_equal_the_reference_writer(tmp_path, oracle_libs):
     assert r == L.CPF_ERR_STATE and np.isnan(ke)                  # NaN energy is reported, not "pause"d on
 
 
+def test_a_large_frame_takes_the_parallel_path_and_keeps_the_bytes(tmp_path, oracle_libs):
+    """150 000 particles (19 chunks per array): every array of the frame is formatted from a work counter by many threads, each
+    chunk into its own string, written in order; the file must still be the reference writer's, byte for byte."""
+    ref = oracle_libs.RefLib()
+    rng = np.random.default_rng(17)
+    n = 150_000
+    xyzw = np.concatenate([rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-5, 3, size=(n, 1)), np.ones((n, 1))], 1)
+    xyzw[::11, 3] = 0.0
+    cell = rng.integers(-2, 248000, size=n).astype(np.int32)
+    vel0 = np.zeros((n, 4))
+    mine = tmp_path / "big.vtu"
+    r, ke = _write(mine, xyzw, cell, vel0)
+    assert r == 0 and ke == 0.0
+    theirs = ref.write_vtu(str(tmp_path), 3, xyzw, vel0, cell, cell)
+    got = open(mine, "rb").read()
+    assert len(got) > 12_000_000 and got == open(theirs, "rb").read()
+
+
 def test_number_formatting_is_correctly_rounded(tmp_path):
     """'%.15lf' / '%lf' without printf: exact decimal expansion, round-half-even at the last digit -- compared with
     Python's correctly rounded formatting over every binade, ties, zeros, denormals, huge and non-finite values."""
