@@ -47,8 +47,11 @@ def parse(argv=None):
     ap.add_argument("--field", choices=["uniform", "analytic"], default="uniform")
     ap.add_argument("--exchange-interval", type=int, default=0,
                     help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
-    ap.add_argument("--rebalance-interval", type=int, default=32,
-                    help="N>1: re-cut the cell ranges to equal particle counts + hand-off every that many steps")
+    ap.add_argument("--rebalance-interval", type=int, default=-1,
+                    help="N>1: re-cut the cell ranges to equal cost + hand-off every that many steps, COUNTED FROM THE FIRST TIMED "
+                         "STEP; -1 (default) = max(2, min(32, steps // 4)): whatever --steps is, the timed region holds at least "
+                         "two re-cuts + all-to-all-v hand-offs, the first of them overlapped with the step loop and completed "
+                         "inside the clock (with --steps 20: every 5 steps, four hand-offs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", choices=["time", "count"], default="time",
                     help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
@@ -121,6 +124,9 @@ def parse(argv=None):
         a.scaling = "weak" if a.gpus == 1 else "strong"
     if a.particles is None:
         a.particles = 1e7 if (a.gpus == 1 or a.scaling == "weak") else 1e8
+    a.rebalance_interval_auto = a.rebalance_interval < 0
+    if a.rebalance_interval_auto:
+        a.rebalance_interval = max(2, min(32, a.steps // 4))
     return a
 
 
@@ -837,13 +843,18 @@ def run(args, M):
     hwait0 = cloud.handoff_wait_ms
     cloud.profile_comm = True                      # keep the (start, end) events of the hand-offs' collectives
     comm0 = cloud.comm_ms()
+    if dist_on:
+        # the hand-off cadence counts from the first timed step (a hand-off the warm-up left in flight completes here, outside
+        # the clock): re-cuts fall on timed steps r, 2r, ... whatever the warm-up was.  (D = 0: no random stream sees the index.)
+        cloud.step_index = 0
     M.sync(); barrier()
     stage("timed_region")
     t0 = time.perf_counter()
     cloud.step(dt, args.steps)
     cloud.flush()                                  # a hand-off still in flight belongs to the timed region
-    M.sync(); barrier()
-    el = time.perf_counter() - t0
+    M.sync()
+    el = time.perf_counter() - t0                  # this rank's clock stops at its OWN sync; MAX over ranks below
+    barrier()
     launches, kernel_ms = ctx.timing_read()        # + what the load balancer drained during the timed region
     launches += cloud.kernel_launches - launches0; kernel_ms += cloud.kernel_ms - ms0
     psteps = cloud.particle_steps - psteps0
@@ -871,7 +882,13 @@ def run(args, M):
         brown, fused, steady, anchor, more = M.extras(cloud, dt, args, full_box)
 
     out = None
-    if rank == 0:
+    if rank == 0 and world > 1 and handoffs == 0:
+        # work skipped inside the timed region is no measurement: N > 1 without a single re-cut / all-to-all-v inside the clock
+        # would be N independent replicas
+        out = {"error": "no hand-off inside the timed region (steps %d, rebalance interval %d, exchange interval %d): "
+                        "not a measurement of the sharded path" % (args.steps, args.rebalance_interval, args.exchange_interval),
+               "stage": "timed_region", "n_gpus": world}
+    elif rank == 0:
         value = n_before * args.steps / el / 1e6
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         per_launch = psteps / max(args.steps, 1)         # rank 0's particles per launch (varies when N > 1)
@@ -902,8 +919,9 @@ def run(args, M):
                        "particles_total": n_before, "particles_after": n_after, "cells": mesh.n_cells,
                        # which shortcuts of the walk the mesh layer found live on this mesh (include/cpf.h, cpf_get_mesh_flags)
                        "mesh_flags": ctx.mesh_flags() if hasattr(ctx, "mesh_flags") else None,
-                       "exchange_interval": args.exchange_interval if world > 1 else None,
-                       "rebalance_interval": args.rebalance_interval if world > 1 else None,
+                       "exchange_interval": args.exchange_interval if dist_on else None,
+                       "rebalance_interval": args.rebalance_interval if dist_on else None,
+                       "rebalance_interval_counted_from": "the first timed step" if dist_on else None,
                        "overlap_steps": (cloud._overlap() if args.overlap_steps < 0 else args.overlap_steps) if dist_on else None,
                        "overlap_steps_auto": (args.overlap_steps < 0) if dist_on else None,
                        "balance": (("measured step time" if args.balance == "time" else "particle count")
@@ -977,6 +995,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+        if "error" in out:
+            sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -78,6 +78,46 @@ def test_world_2_orchestration_over_gloo_prints_one_strong_scaling_line():
     assert "configs[3]" in c["workload"] and "strong" in c["workload"]
 
 
+def _gloo_world_2(extra, timeout=900):
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_bench_worker.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT))
+    return r, [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_the_drivers_own_arguments_put_handoffs_inside_the_timed_region():
+    """The driver runs N > 1 as `bench.py --gpus N --steps 20 --warmup 5` and NOTHING else.  With those arguments the timed region
+    must hold re-cuts + all-to-all-v hand-offs (round-5 verdict: the old default, every 32 steps counted from step 0, put none
+    into 25 steps).  The default cadence is max(2, min(32, steps // 4)) = 5 counted from the first timed step: hand-offs after
+    timed steps 5, 10, 15, 20."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert a.rebalance_interval == 5 and a.rebalance_interval_auto and a.exchange_interval == 0
+    assert bench.parse(["--gpus", "8"]).rebalance_interval == 25                    # bench.py's own default --steps 100
+    assert bench.parse(["--gpus", "2", "--steps", "3"]).rebalance_interval == 2     # never rarer than the region is long
+    r, lines = _gloo_world_2(["--particles", "4000", "--steps", "20", "--warmup", "5"])       # (the cloud is the only thing scaled down)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert len(lines) == 1
+    d = _check(lines[0], need_cpu_baseline=False, scaling="strong")
+    c = d["config"]
+    assert d["steps"] == 20 and d["warmup"] == 5 and c["rebalance_interval"] == 5 and c["rccl_ranks"] == 2
+    assert c["ms_in_handoff"]["handoffs"] >= 2 and c["handoff_fraction_per_step"] > 0
+    assert c["particles_total"] == 4000 and c["particles_after"] == 4000
+
+
+def test_a_timed_region_without_a_handoff_is_an_error_line_not_a_value():
+    """N > 1 with no re-cut and no hand-off inside the clock = N independent replicas: rank 0 prints {"error": ...} and no value."""
+    r, lines = _gloo_world_2(["--particles", "4000", "--steps", "4", "--warmup", "1", "--rebalance-interval", "0",
+                              "--exchange-interval", "0"])
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert "value" not in d and "metric" not in d and "no hand-off inside the timed region" in d["error"] and d["n_gpus"] == 2
+
+
 def test_dry_collectives_over_gloo_prints_the_stage_timings_and_exits():
     """`--dry-collectives`: communicator init -> first re-cut -> one all-to-all-v, the three timed, ONE JSON line, exit 0 -- what a
     first multi-GPU run is started with so that a failing collective costs seconds and is named (here: world 2 on CPU)."""
@@ -192,6 +232,23 @@ def test_dry_collectives_on_a_one_rank_rccl_group():
     d = json.loads(lines[0])
     assert d["rccl_ranks"] == 1 and d["particles_total"] == 200_000
     assert d["dry_collectives"]["comm_init_s"] > 0 and d["dry_collectives"]["particles_on_rank0"] == 200_000
+
+
+@pytest.mark.gpu
+def test_the_drivers_arguments_on_a_one_rank_rccl_group_hold_handoffs():
+    """`--steps 20 --warmup 5` and no cadence flag, as the driver calls N > 1, on a real RCCL communicator of one rank: the timed
+    region holds >= 2 re-cuts + all-to-all-v's (default cadence 5, counted from the first timed step)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e5", "--steps", "20", "--warmup", "5", "--force-dist",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], need_cpu_baseline=False)
+    c = d["config"]
+    assert c["rebalance_interval"] == 5 and c["rccl_ranks"] == 1 and c["ms_in_handoff"]["handoffs"] >= 2
+    assert c["ms_in_handoff"]["collectives_device_ms_total"] > 0 and c["particles_after"] == 200_000
 
 
 @pytest.mark.gpu
