@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libcudaParticleAdvection.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "cpf.h")
 
-CPF_OK, CPF_ERR_ARG, CPF_ERR_STATE, CPF_ERR_MESH, CPF_ERR_HIP, CPF_ERR_NOMEM = range(6)
+CPF_OK, CPF_ERR_ARG, CPF_ERR_STATE, CPF_ERR_MESH, CPF_ERR_HIP, CPF_ERR_NOMEM, CPF_WARN_NAN = range(7)
 CELL_LOST, CELL_FROZEN = -1, -2
 STEP_DEFAULT, STEP_NO_REFLECT, STEP_STORE_VEL, STEP_FUSE_CYCLES, STEP_VERTEX_VELOCITY = 0, 1, 2, 4, 8
 HANDOFF_DOUBLES = 5
@@ -187,6 +187,7 @@ SIGNATURES = {
     "cpf_traj_write_vtk_arrays": (_int, [C.c_char_p, _i64, _vp, _vp]),
     "cpf_device_count": (_int, [C.POINTER(_int)]),
     "cpf_comm_unique_id": (_int, [_vp, _int]),
+    "cpf_comm_default_kind": (_int, []),
     "cpf_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(C.POINTER(Comm))]),
     "cpf_comm_destroy": (None, [C.POINTER(Comm)]),
     "cpf_comm_last_error": (C.c_char_p, []),

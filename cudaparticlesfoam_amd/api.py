@@ -226,7 +226,7 @@ class Context:
         """particle_%04d.vtu in the reference's layout, synchronously; returns the total kinetic energy."""
         ke = C.c_double()
         r = self.lib.cpf_write_vtu(self.h, str(path).encode(), C.byref(ke))
-        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+        if r not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(r)
         return ke.value
 
@@ -234,13 +234,13 @@ class Context:
         """Same frame, formatted and written by a worker thread (one frame in flight per context)."""
         ke = C.c_double()
         r = self.lib.cpf_write_vtu_async(self.h, str(path).encode(), C.byref(ke))
-        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+        if r not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(r)
         return ke.value
 
     def write_vtu_wait(self):
         r = self.lib.cpf_write_vtu_wait(self.h)
-        if r not in (L.CPF_OK, L.CPF_ERR_STATE):
+        if r not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(r)
 
     def timing_enable(self, on: bool = True):

@@ -166,7 +166,7 @@ inline void writeParticles2VTU(unsigned int ti, Particle* d_particles, vec4d* d_
     std::snprintf(name, sizeof(name), "particle_%04u.vtu", ti);
     double ke = 0.0;
     const int r = cpf_write_vtu_arrays(name, numParticles, P.data(), ids.data(), V.data(), &ke);
-    if (r != CPF_OK && r != CPF_ERR_STATE) throw Error(r, std::string("writeParticles2VTU: cannot write ") + name);
+    if (r != CPF_OK && r != CPF_WARN_NAN) throw Error(r, std::string("writeParticles2VTU: cannot write ") + name);
     std::printf("#adv: System Kinetic Energy=%lf\n", ke);
 }
 

@@ -43,22 +43,29 @@ static int rankMain(const std::string& caseDir, int rank, int nProcs, int euleri
         #include "advect.H"
     }
 
-    // the whole cloud in particle-id order on the master (collective)
+    // the whole cloud in particle-id order on the master (collective when the cloud is sharded)
     std::vector<double> xyzw; std::vector<int32_t> cells;
     if (Pstream::master()) { xyzw.resize((size_t)numParticles * 4); cells.resize((size_t)numParticles); }
-    cpfCheck(cpf_shard_gather(cpfShard, 0, Pstream::master() ? xyzw.data() : nullptr, Pstream::master() ? cells.data() : nullptr, nullptr));
+    if (cpfShard)
+        cpfCheck(cpf_shard_gather(cpfShard, 0, Pstream::master() ? xyzw.data() : nullptr, Pstream::master() ? cells.data() : nullptr, nullptr));
+    else if (cpfCtx)                       // the reference's topology: the master's one context holds everything
+        cpfCheck(cpf_get_particles(cpfCtx, xyzw.data(), cells.data(), nullptr));
     if (Pstream::master())
     {
         FILE* fp = std::fopen("particles_out.f64", "wb"); std::fwrite(xyzw.data(), 8, xyzw.size(), fp); std::fclose(fp);
         fp = std::fopen("cells_out.i32", "wb"); std::fwrite(cells.data(), 4, cells.size(), fp); std::fclose(fp);
-        cpf_shard_stats st;
-        cpfCheck(cpf_shard_get_stats(cpfShard, &st));
-        std::printf("#mock: rank 0 of %d: %lld particles, %lld hand-offs, %lld re-cuts, %lld handed off\n", nProcs, (long long)st.n,
-                    (long long)st.exchanges, (long long)st.rebalances, (long long)st.handedOff);
+        if (cpfShard)
+        {
+            cpf_shard_stats st;
+            cpfCheck(cpf_shard_get_stats(cpfShard, &st));
+            std::printf("#mock: rank 0 of %d: %lld particles, %lld hand-offs, %lld re-cuts, %lld handed off\n", nProcs, (long long)st.n,
+                        (long long)st.exchanges, (long long)st.rebalances, (long long)st.handedOff);
+        }
+        else std::printf("#mock: rank 0 of %d drives the one GPU\n", nProcs);
     }
-    cpf_shard_destroy(cpfShard);
-    cpf_comm_destroy(cpfComm);
-    cpf_destroy(cpfCtx);
+    if (cpfShard) cpf_shard_destroy(cpfShard);
+    if (cpfComm) cpf_comm_destroy(cpfComm);
+    if (cpfCtx) cpf_destroy(cpfCtx);
     return 0;
 }
 

@@ -1226,14 +1226,14 @@ int cpf_write_vtu_wait(cpf_context* ctx) {
     }
     const int r = ctx->writerStatus;
     ctx->writerStatus = CPF_OK;
-    if (r != CPF_OK && r != CPF_ERR_STATE) return fail(ctx, r, "cpf_write_vtu_async: the frame could not be written");
+    if (r != CPF_OK && r != CPF_WARN_NAN) return fail(ctx, r, "cpf_write_vtu_async: the frame could not be written");
     return r;
 }
 
 int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE) {
     CPF_REQUIRE(ctx, ctx && path, CPF_ERR_ARG, "null argument");
     int r = cpf_write_vtu_wait(ctx);                       // one frame in flight; reports the previous frame's failure
-    if (r != CPF_OK && r != CPF_ERR_STATE) return r;
+    if (r != CPF_OK && r != CPF_WARN_NAN) return r;
     int64_t n = 0;
     r = cpf_num_particles(ctx, &n);
     if (r) return r;
@@ -1254,7 +1254,7 @@ int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE) {
         ctx->writerStatus = (binary ? cpf_write_vtu_arrays_binary : cpf_write_vtu_arrays)(file.c_str(), n, ctx->wXyzw.data(), ctx->wCell.data(),
                                                                                          ctx->wVel.data(), nullptr);
     });
-    return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
+    return std::isnan(total) ? CPF_WARN_NAN : CPF_OK;
 }
 
 int cpf_timing_enable(cpf_context* ctx, int on) {

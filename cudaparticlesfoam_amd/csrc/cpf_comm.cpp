@@ -60,7 +60,11 @@ RcclApi& rccl() {
             api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (api.lib) break;
         }
-        if (!api.lib) { api.why = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return; }
+        if (!api.lib) {
+            const char* e = dlerror();                         // (once: reading the error clears it)
+            api.why = std::string("librccl.so.1 not found (") + (e ? e : "?") + ")";
+            return;
+        }
         auto sym = [&](const char* s) -> void* {
             void* p = dlsym(api.lib, s);
             if (!p && api.why.empty()) api.why = std::string("librccl: missing symbol ") + s;
@@ -285,6 +289,8 @@ int cpf_device_count(int* count) {
     *count = n;
     return CPF_OK;
 }
+
+int cpf_comm_default_kind(void) { return wantedKind(0); }
 
 int cpf_comm_unique_id(void* id, int kind) {
     if (!id) return commFail(CPF_ERR_ARG, "cpf_comm_unique_id: null id");

@@ -7,7 +7,7 @@
 //   * ParticleTetID / ConvexTetID both hold the containing CELL id (there are no tets here; the
 //     reference's ParticleTetID is uninitialised memory in its default ConvexPoly build);
 //   * KEs holds the kinetic energy (the reference prints 0 for every non-zero KE);
-//   * no system("pause") on NaN: the function returns CPF_ERR_STATE instead.
+//   * no system("pause") on NaN: the function returns CPF_WARN_NAN instead (the file is written).
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -212,7 +212,7 @@ extern "C" int cpf_write_vtu_arrays(const char* path, int64_t n, const double* x
     std::fclose(fp);
     if (totalKE) *totalKE = total;
     if (bad) return CPF_ERR_ARG;
-    return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
+    return std::isnan(total) ? CPF_WARN_NAN : CPF_OK;
 }
 
 // ---- the same frame with the arrays RAW behind the XML ("binary-appended as an option").  Same arrays, names,
@@ -282,7 +282,7 @@ extern "C" int cpf_write_vtu_arrays_binary(const char* path, int64_t n, const do
     std::fclose(fp);
     if (totalKE) *totalKE = total;
     if (bad) return CPF_ERR_ARG;
-    return std::isnan(total) ? CPF_ERR_STATE : CPF_OK;
+    return std::isnan(total) ? CPF_WARN_NAN : CPF_OK;
 }
 
 extern "C" int cpf_write_vtu(cpf_context* ctx, const char* path, double* totalKE) {

@@ -73,6 +73,7 @@ class ShardCore {
 
     // state of the step loop
     uint32_t stepIndex = 0;
+    bool velValid = false;       // `vel` holds the last cycle's velocities of the particles AS THEY ARE ORDERED NOW (round-5 advisory)
     struct Pending { bool on = false; uint32_t step = 0; } pending;
     bool sortDue = false, deferSort = false, deferRecut = false, deferExchange = false;
     bool haveArgs = false;
@@ -269,6 +270,7 @@ class ShardCore {
                         int64_t firstGid) {
         if (count < 0 || (count > 0 && (!sx || !sy || !sz))) return fail(CPF_ERR_ARG, "cpf_shard_set_particles_dev: bad arguments");
         CPF_SH(finishExchange());
+        velValid = false;
         if (count > cap) CPF_SH(grow(count, 0));
         Stream s = dev.compute();
         if (count > 0) {
@@ -286,6 +288,7 @@ class ShardCore {
         CPF_SH(finishExchange());
         const int64_t first = nTotal * rank / W, last = nTotal * (rank + 1) / W;      // (nTotal < 2^37, W <= 64: no overflow)
         const int64_t count = last - first;
+        velValid = false;
         if (count > cap) CPF_SH(grow(count, 0));
         if (count > 0) {
             CPF_SH(dev.seed(x, y, z, first, count, lower, upper, order));
@@ -335,6 +338,7 @@ class ShardCore {
         if (pending.on && haveArgs && !(argDt == dt && argD == D && argFlags == flags))
             CPF_SH(finishExchange());                     // the catch-up replays the window with ONE set of arguments
         argDt = dt; argD = D; argFlags = flags; haveArgs = true;
+        velValid = false;
         const bool dist = distOn();
         const bool storeVel = (flags & CPF_STEP_STORE_VEL) != 0, fuse = (flags & CPF_STEP_FUSE_CYCLES) != 0;
         if (storeVel && !vel) CPF_SH(dev.alloc((void**)&vel, (size_t)cap * 24));
@@ -394,6 +398,9 @@ class ShardCore {
             }
         }
         if (overlapSteps == 0 || storeVel) CPF_SH(finishExchange());
+        // from here the stored velocities line up with the particles -- until something reorders them: an explicit sort,
+        // exchange, re-cut or refill clears the flag and a frame written after that carries zero velocities, not misplaced ones
+        velValid = storeVel && nCycles > 0;
         return CPF_OK;
     }
 
@@ -427,6 +434,7 @@ class ShardCore {
     // marked inactive.  Counts and nStay stay in device memory for now.
     int beginExchange() {
         const double t0 = nowMs();
+        velValid = false;                                      // the split compacts the stayers: `vel` does not follow
         CPF_SH(dev.pack(x, y, z, cell, gid, n, d_cellLo, W, rank, sendbuf, sendCap, d_meta, d_meta + W));
         CPF_SH(dev.eventRecord(evPack, dev.compute()));
         pending.on = true; pending.step = stepIndex;
@@ -597,6 +605,7 @@ class ShardCore {
     // Into the shard's second set of arrays, which then swap roles with the first (no staging, no copy back).
     int sort() {
         if (n <= 1) return CPF_OK;
+        velValid = false;                                      // x, y, z, cell, gid are permuted, `vel` is not
         if (!ax) {
             CPF_SH(dev.alloc((void**)&ax, (size_t)cap * 8)); CPF_SH(dev.alloc((void**)&ay, (size_t)cap * 8));
             CPF_SH(dev.alloc((void**)&az, (size_t)cap * 8)); CPF_SH(dev.alloc((void**)&acell, (size_t)cap * 4));
@@ -678,7 +687,7 @@ class ShardCore {
         auto cleanup = [&] { for (void* p : {(void*)out, (void*)in, (void*)dXyzw, (void*)dVel, (void*)dCell, (void*)dBad}) if (p) dev.release(p); };
 #define CPF_SHG(call) do { rc = (call); if (rc != CPF_OK) { (void)note(rc); cleanup(); return rc; } } while (0)
         CPF_SHG(dev.alloc((void**)&out, (size_t)std::max<int64_t>(n, 1) * kRec));
-        CPF_SHG(dev.packOutput(x, y, z, cell, gid, (argFlags & CPF_STEP_STORE_VEL) ? vel : nullptr, out, n));
+        CPF_SHG(dev.packOutput(x, y, z, cell, gid, velValid ? vel : nullptr, out, n));
         std::vector<int64_t> sOff((size_t)W, 0), sBytes((size_t)W, 0), rOff((size_t)W, 0), rBytes((size_t)W, 0);
         sBytes[(size_t)root] = n * kRec;
         if (rank == root) {
@@ -724,7 +733,6 @@ class ShardCore {
         if (rank != root) return gather(root, nullptr, nullptr, nullptr, nullptr);
         wXyzw.resize((size_t)total * 4); wVel.resize((size_t)total * 4); wCell.resize((size_t)total);
         CPF_SH(gather(root, wXyzw.data(), wCell.data(), wVel.data(), nullptr));
-        if (prev != CPF_OK && prev != CPF_ERR_STATE) return fail(prev, "cpf_shard_write_vtu: the previous frame could not be written");
         double ke = 0.0;
         for (int64_t i = 0; i < total; ++i) {
             const double* v = &wVel[4 * (size_t)i];
@@ -736,7 +744,9 @@ class ShardCore {
         writer = std::thread([this, file, total] {
             writerStatus = dev.writeVtuArrays(file.c_str(), total, wXyzw.data(), wCell.data(), wVel.data(), nullptr);
         });
-        return std::isnan(ke) ? CPF_ERR_STATE : CPF_OK;
+        // (the current frame is on its way whatever happened to the previous one; a failure of that one is reported now)
+        if (prev != CPF_OK && prev != CPF_WARN_NAN) return fail(prev, "cpf_shard_write_vtu: the previous frame could not be written");
+        return std::isnan(ke) ? CPF_WARN_NAN : CPF_OK;
     }
 
     void stats(cpf_shard_stats* o) {

@@ -299,6 +299,6 @@ class ShardedCloud:
         """COLLECTIVE: one frame of the whole cloud written by ``root`` (the reference's particle_%04d.vtu layout)."""
         ke = C.c_double()
         st = self.lib.cpf_shard_write_vtu(self.h, int(root), path.encode(), C.byref(ke))
-        if st not in (L.CPF_OK, L.CPF_ERR_STATE):
+        if st not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(st)
         return ke.value

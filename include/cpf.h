@@ -43,7 +43,10 @@ typedef enum cpf_status {
     CPF_ERR_STATE = 2,  /* call order: mesh / velocity / particles not set yet */
     CPF_ERR_MESH = 3,   /* inconsistent polyMesh (owner/neighbour/face lists) */
     CPF_ERR_HIP = 4,    /* HIP runtime error (no device, allocation, launch) */
-    CPF_ERR_NOMEM = 5
+    CPF_ERR_NOMEM = 5,
+    CPF_WARN_NAN = 6    /* NOT a failure: the frame writers' "total kinetic energy is NaN" (the reference stops in
+                           system("pause") there, cuda/utils.cpp:255); the frame has been written / queued like any other.
+                           Nothing else returns it, so a caller may ignore exactly this code */
 } cpf_status;
 
 /* flags for cpf_step / cpf_step_device */
@@ -380,6 +383,9 @@ int cpf_device_count(int* count);
  * process (any devices, also the same one -- which RCCL refuses): device-to-device copies and a barrier, for
  * single-process hosts and for tests.  kind 0: the environment variable CPF_COMM ("rccl" / "inprocess"), else RCCL. */
 int cpf_comm_unique_id(void* id /* [CPF_COMM_ID_BYTES] */, int kind);
+/* What kind 0 means in this process: CPF_COMM_INPROCESS if the environment says CPF_COMM=inprocess, else CPF_COMM_RCCL.
+ * (A host deciding whether its ranks may share a device asks this: RCCL refuses two ranks on one GPU.) */
+int cpf_comm_default_kind(void);
 /* Joins the communicator `id` names as rank `rank` of `nRanks` on HIP device `device` (collective: returns when
  * every rank has joined).  RCCL is loaded at run time (librccl.so.1): a single-GPU host needs none. */
 int cpf_comm_create(const void* id, int rank, int nRanks, int device, cpf_comm** out);

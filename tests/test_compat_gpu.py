@@ -28,10 +28,10 @@ def _expected(pitz, gpu_ctx_factory, D=0.0, cycles=35, z_fold=1):
     return xyzw, cell, n_out
 
 
-def _run(binary, case, cwd, n=None, extra=()):
+def _run(binary, case, cwd, n=None, extra=(), env=None):
     subprocess.run(["make", "-C", COMPAT, "-s"], check=True)
     r = subprocess.run([os.path.join(COMPAT, "bin", binary), case] + list(extra), cwd=cwd, capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     n = DICT["numParticles"] if n is None else n
     xyzw = np.fromfile(os.path.join(cwd, "particles_out.f64")).reshape(n, 4)
@@ -123,6 +123,43 @@ def test_parallel_fragments_equal_the_serial_run(tmp_path, pitz, n_procs):
     assert handed > 0                                                     # particles did change hands between the ranks
     frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
     assert frames == ["particle_%04d.vtu" % k for k in (0, 1, 11, 21, 31)]
+    for f in frames:
+        assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
+
+
+@pytest.mark.parametrize("how", ["more ranks than GPUs", "rankPerGPU false"])
+def test_more_ranks_than_gpus_fall_back_to_the_reference_topology(tmp_path, pitz, how):
+    """Round-5 advisory (high): `mpirun -np N` with N > the GPUs of a host must not abort in ncclCommInitRank ("Duplicate GPU").
+    The fragments count ranks and GPUs per host (hostName + cpf_device_count over gatherList) and, when a host has fewer GPUs
+    than ranks -- here 3 rank-threads with the RCCL kind on this box's GPUs, or the dictionary key `rankPerGPU false` -- fall
+    back to the reference's own parallel topology (src/initCuda.H:207-484, src/advect.H:59-89): the master stitches the pieces
+    and drives ONE GPU with the whole cloud, the other ranks contribute their mesh piece and, every Eulerian step, their U
+    slice through gatherList.  Two Eulerian steps of a transient field with the tutorial's diffusion: particles and frames
+    equal the serial run's byte for byte."""
+    import torch
+    from case_dump import dump_case
+    from cudaparticlesfoam_amd.cases import split_into_parts
+    n_procs = torch.cuda.device_count() + 2
+    mesh, U = pitz["mesh"], pitz["U_analytic"]
+    d = dict(DICT, diffusionCoeff=1.5e-5)
+    env = {"CPF_COMM": "rccl"}
+    if how == "rankPerGPU false":
+        d["rankPerGPU"] = 0
+        env = {"CPF_COMM": "inprocess"}             # (would allow rank-threads to share the device: the key must win)
+    case = str(tmp_path / "case")
+    dump_case(case, mesh, U, d, 1.0, DELTA_T)
+    ser = tmp_path / "serial"; ser.mkdir()
+    xs, cs, outs = _run("mockUncoupledFoam", case, str(ser), extra=["2"])
+    first = 0
+    for r, part in enumerate(split_into_parts(mesh, n_procs)):
+        dump_case(os.path.join(case, "processor%d" % r), part, U[first:first + part.n_cells], d, 1.0, DELTA_T)
+        first += part.n_cells
+    par = tmp_path / "parallel"; par.mkdir()
+    xp, cp, outp = _run("mockParallelFoam", case, str(par), extra=[str(n_procs), "2"], env=env)
+    assert "the master drives one GPU" in outp and "drives the one GPU" in outp and "GPUs)" not in outp
+    assert np.array_equal(xp, xs) and np.array_equal(cp, cs)
+    frames = sorted(os.path.basename(p) for p in glob.glob(str(par / "particle_*.vtu")))
+    assert frames == sorted(os.path.basename(p) for p in glob.glob(str(ser / "particle_*.vtu"))) and len(frames) >= 8
     for f in frames:
         assert open(str(par / f), "rb").read() == open(str(ser / f), "rb").read(), f
 

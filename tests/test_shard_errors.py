@@ -98,3 +98,27 @@ def test_a_rank_that_fails_breaks_the_collective_for_everybody(case, oracle_libs
     [t_.start() for t_ in th]; [t_.join(timeout=120) for t_ in th]
     assert all(not t_.is_alive() for t_ in th)
     assert errors[0] and errors[1] and all("all_gather" in e for e in errors), errors
+
+
+def test_stored_velocities_do_not_outlive_a_reordering(case):
+    """Round-5 advisory: after a cycle with CPF_STEP_STORE_VEL the frame's velocities line up with the particles -- until an
+    explicit cpf_shard_sort / exchange / refill reorders x, y, z, cell, gid without `vel`.  A frame gathered after that must
+    not pair velocities with the wrong particles: it carries none (zeros), like a frame of a cycle that stored none."""
+    from cudaparticlesfoam_amd import _lib as L
+    H, mesh, hc = case
+    U = np.zeros((mesh.n_cells, 3)); U[:, 0] = 1.0 + np.arange(mesh.n_cells)          # a velocity that names the cell
+    cl = H.cloud(hc, None, 500)
+    cl.set_velocity(U)
+    n = 300
+    xyz = np.random.default_rng(7).uniform([0.05, 0.05, 0.05], [5.95, 2.95, 1.95], size=(n, 3))
+    cl.set_particles(xyz[::-1, 0].copy(), xyz[::-1, 1].copy(), xyz[::-1, 2].copy(), None, None)   # (unsorted on purpose)
+    cl.step(0.0, 1, flags=L.STEP_STORE_VEL)                                             # the frame-0 idiom: nothing moves
+    xyzw, cell, vel = cl.gather(0, want_vel=True)
+    assert np.array_equal(vel[:, 0], U[cell, 0]) and vel[:, 0].min() >= 1.0              # aligned: every particle has ITS cell's U
+    cl.sort()
+    xyzw2, cell2, vel2 = cl.gather(0, want_vel=True)
+    assert np.array_equal(xyzw2, xyzw) and np.array_equal(cell2, cell)                  # (gather is in particle-id order)
+    assert not vel2[:, :3].any()                                                        # no velocities rather than misplaced ones
+    cl.step(0.0, 1, flags=L.STEP_STORE_VEL)
+    assert np.array_equal(cl.gather(0, want_vel=True)[2][:, 0], U[cell, 0])             # the next storing cycle restores them
+    cl.close()

@@ -1,6 +1,6 @@
 """GPU box: what one frame costs the step loop (the blocking part of cpf_write_vtu_async) against a cycle."""
 import ctypes as C, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from cudaparticlesfoam_amd.api import Context
