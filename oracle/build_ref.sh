@@ -78,3 +78,14 @@ g++ -std=c++14 -O2 -fPIC -shared -fopenmp -ffp-contract=off -w \
     -I"$RTX" -I"$RTX/owl/owl/include" -I"$TMP" \
     "$HERE/ref_driver.cpp" -o "$OUT/libref_rtxadvect.so"
 echo "built $OUT/libref_rtxadvect.so"
+
+# The same splices once more, CONTRACTING: nvcc fuses a*b+c into one fma by default (--fmad=true) and the reference's CMake
+# does not switch that off, so the binary its authors ran rounds differently from the strict build above.  g++'s
+# -ffp-contract=fast -mfma fuses in the same spirit (every multiply whose only use is an add, also across statements after
+# inlining) but not necessarily at the same places as nvcc: this is A contracting build of the reference's own functions,
+# used to MEASURE how far contraction moves particles (tests/test_fma_sensitivity.py, tests/golden/*_fma.npz), not a
+# bit-replica of the CUDA binary.
+g++ -std=c++14 -O2 -fPIC -shared -fopenmp -ffp-contract=fast -mfma -w \
+    -I"$RTX" -I"$RTX/owl/owl/include" -I"$TMP" \
+    "$HERE/ref_driver.cpp" -o "$OUT/libref_rtxadvect_fma.so"
+echo "built $OUT/libref_rtxadvect_fma.so"

@@ -32,7 +32,8 @@ def build(force: bool = False) -> None:
         a, b = os.path.join(HERE, so), os.path.join(HERE, src)
         if os.path.exists(a) and os.path.getmtime(b) > os.path.getmtime(a):
             src_newer = True
-    ref_missing = (not os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect.so"))
+    ref_missing = (not (os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect.so"))
+                        and os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect_fma.so")))
                    and os.path.isdir(os.environ.get("CPF_REFERENCE", "/root/reference")))
     if need or src_newer or ref_missing:
         subprocess.run(["make", "-C", HERE, "-s"] + (["-B"] if force else []), check=True)
@@ -47,6 +48,11 @@ def usable_threads(hw_threads: int) -> int:
 
 def have_ref() -> bool:
     return os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect.so"))
+
+
+def have_ref_fma() -> bool:
+    """The CONTRACTING build of the same splices (oracle/build_ref.sh: -ffp-contract=fast -mfma, as nvcc fuses by default)."""
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_rtxadvect_fma.so"))
 
 
 def _c(a, dt):
@@ -99,8 +105,9 @@ class _TetApi:
 class RefLib(_TetApi):
     prefix = "ref_"
 
-    def __init__(self):
-        super().__init__(os.path.join(HERE, "_ref", "libref_rtxadvect.so"))
+    def __init__(self, fma: bool = False):
+        """fma=True: the contracting build (libref_rtxadvect_fma.so) -- same functions, multiply-adds fused."""
+        super().__init__(os.path.join(HERE, "_ref", "libref_rtxadvect_fma.so" if fma else "libref_rtxadvect.so"))
         L = self.lib
         L.ref_init_particles.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int]
         L.ref_advect.argtypes = [_dp, _ip, _dp, _dp, C.c_double, C.c_int, _ip, _dp, _dp, C.c_int]

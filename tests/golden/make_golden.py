@@ -15,7 +15,14 @@ ConvexPoly build, diffusionCoeff 0):
                                  advect arrays and checkpoints after 1, 20, 60 cycles of advect -> locate -> reflect -> move
   face_table_box               : getBoundaryMesh tables of createBoxMesh(3,2,2)
   init_particles               : cudaInitParticles LCG<16> stream (g++ argument evaluation order)
-Usage: python tests/golden/make_golden.py   (from the repo root, in the container with /root/reference)
+  *_fma                        : `python tests/golden/make_golden.py fma` -- pitz_uniform / pitz_analytic / box_random once
+                                 more (2048 / 2048 / 1024 particles, same seeds and checkpoints; positions and tet ids only)
+                                 from the CONTRACTING build of the same reference functions (oracle/_ref/
+                                 libref_rtxadvect_fma.so: -ffp-contract=fast -mfma, the way nvcc's default --fmad=true
+                                 fuses), plus profiles/r06_fma_sensitivity.json: strict vs contracting build on 400 000
+                                 particles (cells that differ, max and 99.99-percentile |dx|/L per checkpoint).  Does NOT
+                                 rewrite the files above.
+Usage: python tests/golden/make_golden.py [fma]   (from the repo root, in the container with /root/reference)
 """
 import hashlib
 import os
@@ -56,6 +63,71 @@ def run_case(ref, mesh, centres, U, xyz, cell0, dt, checkpoints):
         done = k
         out["P_%d" % k] = P.copy(); out["tet_%d" % k] = ids.copy(); out["vel_%d" % k] = vels.copy()
     return out
+
+
+FMA_CASES = (("pitz_uniform", 2048, 1e-4, (1, 10, 100, 1000)), ("pitz_analytic", 2048, 1e-4, (1, 10, 100, 1000)),
+             ("box_random", 1024, 0.3, (1, 20, 100)))
+
+
+def fma_case_inputs(name, n, cw):
+    """(mesh, centres, U, xyz, cell0, L) of an fma case: the seeds of the strict goldens, n particles."""
+    if name.startswith("pitz"):
+        mesh = pz.pitzdaily_mesh()
+        centres, _ = mesh.cell_centres_volumes()
+        U = pz.uniform_u(mesh) if name == "pitz_uniform" else pz.analytic_step_u(mesh, centres)
+        xyz = pz.uniform_points(12345, n, *pz.INLET_BOX)
+    else:
+        mesh = box_mesh(10, 9, 8)
+        centres, _ = mesh.cell_centres_volumes()
+        rng = np.random.default_rng(11)
+        U = rng.normal(size=(mesh.n_cells, 3))
+        xyz = rng.uniform([0, 0, 0], [10, 9, 8], size=(n, 3))
+    t = cw.build(mesh)
+    cell0 = cw.locate_initial(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), t, nthreads=cw.max_threads)
+    assert (cell0 >= 0).all()
+    lo, hi = mesh.bounds()
+    return mesh, centres, U, xyz, cell0, float(np.linalg.norm(hi - lo))
+
+
+def compare_builds(a, b, L, checkpoints):
+    """Per checkpoint: particles whose tet / cell differs between two runs, max and 99.99-percentile |dx|/L, count beyond 1e-5."""
+    rows = []
+    for k in checkpoints:
+        d = np.sqrt(((a["P_%d" % k][:, :3] - b["P_%d" % k][:, :3]) ** 2).sum(1)) / L
+        ta, tb = a["tet_%d" % k], b["tet_%d" % k]
+        rows.append(dict(cycles=int(k), particles=int(d.size), tets_differ=int((ta != tb).sum()),
+                         cells_differ=int((ta // 12 != tb // 12).sum()), max_rel=float(d.max()),
+                         p9999_rel=float(np.quantile(d, 0.9999)), beyond_1e5=int((d > 1e-5).sum())))
+    return rows
+
+
+def main_fma(n_sensitivity=400000):
+    import json
+    O.build()
+    if not (O.have_ref() and O.have_ref_fma()):
+        sys.exit("oracle/_ref (strict and contracting builds) is not built (needs /root/reference)")
+    strict, fma, cw = O.RefLib(), O.RefLib(fma=True), O.CellWalk()
+    report = {"what": "the reference's own functions (oracle/build_ref.sh splices) built strict (-ffp-contract=off) against the "
+                      "same splices built contracting (-ffp-contract=fast -mfma, as nvcc's default --fmad=true fuses): same "
+                      "seeded inputs, ConvexPoly cycle advect -> locate -> reflect -> move, D = 0",
+              "rel": "|dx| / L, L = bounding-box diagonal of the mesh", "cases": {}}
+    for name, n, dt, cps in FMA_CASES:
+        mesh, centres, U, xyz, cell0, L = fma_case_inputs(name, n, cw)
+        g = run_case(fma, mesh, centres, U, xyz, cell0, dt, cps)
+        keep = {k: v for k, v in g.items() if not k.startswith("vel_")}
+        for k in cps:
+            keep["P_%d" % k] = np.ascontiguousarray(g["P_%d" % k][:, :3])       # (w stays 1: every boundary reflects)
+        if name == "box_random":
+            keep["U"] = U
+        np.savez_compressed(os.path.join(HERE, name + "_fma.npz"), **keep)
+        mesh, centres, U, xyz, cell0, L = fma_case_inputs(name, n_sensitivity, cw)
+        a = run_case(strict, mesh, centres, U, xyz, cell0, dt, cps)
+        b = run_case(fma, mesh, centres, U, xyz, cell0, dt, cps)
+        report["cases"][name] = compare_builds(a, b, L, cps)
+        print(name, report["cases"][name][-1])
+    with open(os.path.join(ROOT, "profiles", "r06_fma_sensitivity.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("fma goldens written to", HERE)
 
 
 def main():
@@ -129,4 +201,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_fma() if sys.argv[1:] == ["fma"] else main()
