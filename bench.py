@@ -114,6 +114,15 @@ def parse(argv=None):
                          "particles from the seeding box, D = 1.5e-5, on the 248 000-cell TJunction mesh -- that many steps, "
                          "reported as config.tjunction_as_run; 0 = skip")
     ap.add_argument("--tjunction-particles", type=float, default=4e6)
+    ap.add_argument("--vertex-steps", type=int, default=20,
+                    help="after the timed region (N = 1): that many cycles with the reference's \"VertexVelocity\" advect (velocity "
+                         "interpolated at the particle from tet-vertex values, cuda/particles.cu:244-313; CPF_STEP_VERTEX_VELOCITY) on "
+                         "pitzDaily with the analytic field sampled at the vertices, reported as config.vertex_velocity; 0 = skip")
+    ap.add_argument("--polyhedral-steps", type=int, default=50,
+                    help="after the timed region (N = 1): the non-hex share of BASELINE configs[4] -- a 114 540-cell 3-D mesh with a "
+                         "2:1-refined block (9-faced cells, face groups), D = 1.5e-5, a new U uploaded every 10 cycles -- that many "
+                         "cycles, reported as config.polyhedral_as_run; 0 = skip")
+    ap.add_argument("--polyhedral-particles", type=float, default=1e7)
     ap.add_argument("--anchor-particles", type=float, default=1e8,
                     help="after the timed region (N = 1): the strong-scaling experiment's total cloud (what --gpus N > 1 "
                          "shards) stepped on this ONE GPU, reported as config.strong_anchor_1e8 -- the N = 1 point of "
@@ -558,7 +567,9 @@ class GpuMachine:
         more = {}
         for key, fn in (("brownian_steady", lambda: self._brownian_steady(cloud, dt, args, box)),
                         ("analytic_field", lambda: self._analytic_field(cloud, dt, args, box)),
-                        ("tjunction_as_run", lambda: self._tjunction_as_run(dt, args))):
+                        ("tjunction_as_run", lambda: self._tjunction_as_run(dt, args)),
+                        ("vertex_velocity", lambda: self._vertex_velocity(cloud, dt, args, box)),
+                        ("polyhedral_as_run", lambda: self._polyhedral_as_run(dt, args))):
             try:
                 more[key] = fn()
             except Exception as e:                                   # noqa: BLE001
@@ -743,6 +754,116 @@ class GpuMachine:
         finally:
             ctx2.close()
         return r
+
+    def _vertex_velocity(self, cloud, dt, args, box):
+        """the cycle with the reference's "VertexVelocity" advect (cuda/particles.cu:244-313, dispatch :428-437) --
+        the velocity interpolated at the particle's position from values on the vertices of the cell's tets (src/initCuda.H:86-124:
+        12 per hex) -- as ONE launch per cycle of step_kernel_vertex (the generic CSR walk; no streaming instantiation).  No solver
+        sets the mode (src/initCuda.H:72); pitzDaily, the analytic step-flow field sampled at the tet-mesh vertices."""
+        if args.vertex_steps <= 0:
+            return None
+        from cudaparticlesfoam_amd import _lib as L
+        from cudaparticlesfoam_amd.cases import pitzdaily as pz
+        torch, ctx = self.torch, self.ctx
+        mesh, _ = self._case
+        centres, _ = mesh.cell_centres_volumes()
+        pos, tets = mesh.tet_decomposition(centres)            # what the fragment builds: points ++ centres, 12 tets per hex
+        ctx.set_tets(pos, tets, 12)
+        ctx.set_vertex_velocity(pz.analytic_step_u(mesh, pos))
+        n = cloud.n
+        x, y, z, c = seed_in_fluid(ctx, torch, n, box, 2028, self.device)
+        g = torch.arange(n, dtype=torch.int64, device=self.device)
+        p = lambda a: a.data_ptr()   # noqa: E731
+        ctx.sort_by_cell_dev(p(x), p(y), p(z), p(c), p(g), n)
+        fl = L.STEP_VERTEX_VELOCITY
+        ctx.set_option("stats", 1); c0 = ctx.counters()
+        ctx.step_dev(p(x), p(y), p(z), p(c), p(g), None, n, dt, 0.0, 0, 3, fl)
+        torch.cuda.synchronize(); c1 = ctx.counters(); ctx.set_option("stats", 0)
+        ctx.set_option("timing_stride", 1)
+        ctx.timing_enable(True); ctx.timing_read()
+        t0 = time.perf_counter()
+        ctx.step_dev(p(x), p(y), p(z), p(c), p(g), None, n, dt, 0.0, 3, args.vertex_steps, fl)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / args.vertex_steps * 1e3
+        launches, ms = ctx.timing_read(); ctx.timing_enable(False)
+        k = ms / max(launches, 1)
+        alive = int((c >= 0).sum())
+        return {"steps": args.vertex_steps, "particles": n, "particles_after": alive, "ms_per_step": round(per, 4),
+                "kernel_avg_ms": round(k, 4), "kernel": ctx.step_kernel_name(0.0, fl),
+                "Mparticle_steps_per_s": round(n / per / 1e3, 1), "algorithmic_bytes_per_particle_step": ALGO_BYTES_PER_PARTICLE_STEP,
+                "frac": round(ALGO_BYTES_PER_PARTICLE_STEP * n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel_frac": round(ALGO_BYTES_PER_PARTICLE_STEP * n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k > 0 else None,
+                "tets": int(tets.shape[0]), "tet_vertices": int(pos.shape[0]),
+                "cells_visited_per_particle_step": round((c1["cells_visited"] - c0["cells_visited"]) /
+                                                         max(1, c1["particle_steps"] - c0["particle_steps"]), 3),
+                "field": "analytic step-flow sampled at the tet-mesh vertices (points ++ cell centres)",
+                "note": "56 B x particles / time, like the cell-constant cycle (config.analytic_field is that cycle on the same "
+                        "field at the cell centres); the tet and vertex tables (%.1f MB) stay in L2"
+                        % ((tets.nbytes + pos.nbytes * 2) / 1e6)}
+
+    def _polyhedral_as_run(self, dt, args):
+        """The non-hex ("polyMesh") share of BASELINE configs[4] on one GPU: a graded 40 x 40 x 40 box whose central block is refined
+        2 x 2 x 2 -- 114 540 cells, 2 242 of them with 9 faces, split faces as face groups: a mesh the reference cannot run
+        (src/initCuda.H:64) -- with the tutorials' diffusion and a transient solver's field: a new U uploaded every 10 cycles
+        (src/advect.H:44-57), the upload timed by itself; the fragments' sort cadence for diffusing clouds inside the clock."""
+        if args.polyhedral_steps <= 0:
+            return None
+        from cudaparticlesfoam_amd.api import Context
+        from cudaparticlesfoam_amd.cases import refined_box
+        torch = self.torch
+        lo3, hi3 = (0.0, 0.0, 0.0), (0.3, 0.05, 0.05)
+        mesh, _ = refined_box(40, 40, 40, lo3, hi3, ((0.075, 0.0125, 0.0125), (0.225, 0.0375, 0.0375)), grading=(2.0, 1.0, 0.5))
+        cc, _ = mesh.cell_centres_volumes()
+        field = lambda a, b: np.ascontiguousarray(np.stack([10.0 + 0 * cc[:, 0], a * np.sin(40 * cc[:, 2]), b * np.cos(40 * cc[:, 1])], 1))   # noqa: E731
+        ctx2 = Context(self.device.index or 0)
+        ctx2.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            ctx2.set_mesh(mesh)
+            ctx2.set_velocity(field(4.0, 4.0))
+            n, interval, Db, per_u = int(args.polyhedral_particles), 25, 1.5e-5, 10
+            cl = self._fresh_cloud(n, (lo3, hi3), 2029, ctx=ctx2, sort_interval=interval)
+            ctx2.set_option("stats", 1); c0 = ctx2.counters()
+            cl.step(dt, 10, D=Db)
+            torch.cuda.synchronize(); c1 = ctx2.counters(); ctx2.set_option("stats", 0)
+            cl.sort(); cl.step_index = 0
+            fields = [field(4.0 - 0.1 * e, 3.0 + 0.1 * e) for e in range(4)]
+            ctx2.set_option("timing_stride", 5)
+            ctx2.timing_enable(True); ctx2.timing_read()
+            torch.cuda.synchronize()
+            upload_s, done, e = 0.0, 0, 0
+            t0 = time.perf_counter()
+            while done < args.polyhedral_steps:
+                torch.cuda.synchronize()                               # (the cycles queued so far are not the upload's time)
+                tu = time.perf_counter()
+                cl.set_velocity(fields[e % len(fields)])           # (cpf_shard_set_velocity: 24 B per cell, host -> device)
+                torch.cuda.synchronize()
+                upload_s += time.perf_counter() - tu
+                k = min(per_u, args.polyhedral_steps - done)
+                cl.step(dt, k, D=Db)
+                done += k; e += 1
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            launches, ms = ctx2.timing_read(); ctx2.timing_enable(False)
+            kk = ms / max(launches, 1)
+            per = (el - upload_s) / args.polyhedral_steps * 1e3
+            bytes_per = ALGO_BYTES_PER_PARTICLE_STEP + 8
+            nf = np.diff(mesh.cell_faces()[0])
+            return {"steps": args.polyhedral_steps, "particles": n, "particles_after": cl.global_count(), "cells": mesh.n_cells,
+                    "cells_with_9_faces": int((nf == 9).sum()), "D": Db, "sort_interval": interval,
+                    "sorts_inside": args.polyhedral_steps // interval, "kernel": ctx2.step_kernel_name(Db, 0),
+                    "mesh_flags": ctx2.mesh_flags(), "ms_per_step": round(per, 4), "kernel_avg_ms": round(kk, 4),
+                    "Mparticle_steps_per_s": round(n / per / 1e3, 1), "algorithmic_bytes_per_particle_step": bytes_per,
+                    "frac": round(bytes_per * n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_frac": round(bytes_per * n / (kk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kk > 0 else None,
+                    "velocity_uploads": e, "cycles_per_upload": per_u, "upload_ms_each": round(upload_s / max(e, 1) * 1e3, 4),
+                    "upload_bytes_each": int(24 * mesh.n_cells),
+                    "ms_per_step_with_uploads": round(el / args.polyhedral_steps * 1e3, 4),
+                    "cells_visited_per_particle_step": round((c1["cells_visited"] - c0["cells_visited"]) /
+                                                             max(1, c1["particle_steps"] - c0["particle_steps"]), 3),
+                    "note": "ms_per_step: the cycles with their sorts, uploads taken out; upload_ms_each: cpf_shard_set_velocity "
+                            "between two syncs (24 B per cell + the record rebuild on the device)"}
+        finally:
+            ctx2.close()
 
     def finish(self):
         if self.control:
@@ -943,6 +1064,8 @@ def run(args, M):
                        # what the tutorials actually run, after the timed region (never `value`)
                        "brownian_steady": more.get("brownian_steady"), "analytic_field": more.get("analytic_field"),
                        "tjunction_as_run": more.get("tjunction_as_run"),
+                       # what is built but had no number in the driver-run line until round 6
+                       "vertex_velocity": more.get("vertex_velocity"), "polyhedral_as_run": more.get("polyhedral_as_run"),
                        "cells_visited_per_particle_step": round(counters["cells_visited"] / max(1, counters["particle_steps"]), 3),
                        "reflections_per_particle_step": round(counters["reflections"] / max(1, counters["particle_steps"]), 4),
                        "sorted_by_cell": not args.no_sort, "sort_interval": 0 if args.no_sort else args.sort_interval, "visit_stats_from": "the %d warm-up steps" % args.warmup},

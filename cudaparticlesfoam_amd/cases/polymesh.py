@@ -129,6 +129,35 @@ class PolyMesh:
         ctr = np.where((np.abs(vol) > 1e-300)[:, None], ctr / np.where(vol == 0, 1, vol)[:, None], est)
         return ctr, vol / 3.0
 
+    def tet_decomposition(self, cell_centres: np.ndarray | None = None) -> Tuple[np.ndarray, np.ndarray]:
+        """What the reference's init fragment hands its library for the "VertexVelocity" mode (``src/initCuda.H:86-124``):
+        tet-mesh vertices = ``mesh.points()`` ++ ``mesh.C()`` and, per cell in ``mesh.cells()`` order, one tet per face
+        triangle -- apex = the cell's centre vertex, base = the fan (f[0], f[k], f[k+1]), k = 1 .. n-2, of each face, turned
+        so that it is seen counter-clockwise from outside the cell (``tetIndices::faceTriIs`` with base point 0).  A hex
+        gives 12 tets.  Returns (positions [nPoints + nCells][3], tets [nTets][4] int32) for ``cpf_set_tets``; every cell
+        must yield the same number of tets (the reference: hexes only)."""
+        if cell_centres is None:
+            cell_centres, _ = self.cell_centres_volumes()
+        off, faces = self.cell_faces()
+        fo = self.face_offsets.astype(np.int64)
+        fv = self.face_verts.astype(np.int64)
+        tets = []
+        cells_of_slots = np.repeat(np.arange(self.n_cells, dtype=np.int64), np.diff(off))
+        face_sizes = np.diff(fo)[faces]
+        for nverts in np.unique(face_sizes):                      # faces of one size at a time: a dense (slots, n) vertex table
+            sel = np.nonzero(face_sizes == nverts)[0]
+            f = faces[sel].astype(np.int64)
+            loops = fv[fo[f][:, None] + np.arange(nverts)[None, :]]
+            inward = self.owner[f] != cells_of_slots[sel]           # the loop is outward for the owner: turn it for the neighbour
+            for k in range(1, int(nverts) - 1):
+                a, b = loops[:, k], loops[:, k + 1]
+                a, b = np.where(inward, b, a), np.where(inward, a, b)
+                tets.append(np.stack([sel, np.full(sel.size, k), self.n_points + cells_of_slots[sel], loops[:, 0], a, b], 1))
+        t = np.concatenate(tets)
+        t = t[np.lexsort((t[:, 1], t[:, 0]))]                      # cell order, then the cell's face order, then the fan
+        return (np.ascontiguousarray(np.concatenate([self.points, cell_centres]), dtype=np.float64),
+                np.ascontiguousarray(t[:, 2:], dtype=np.int32))
+
     def bounds(self) -> Tuple[np.ndarray, np.ndarray]:
         return self.points.min(0), self.points.max(0)
 

@@ -259,7 +259,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e5", "--steps", "6", "--warmup", "2",
            "--no-cpu-baseline", "--rebalance-interval", "3", "--overlap-steps", "1", "--anchor-particles", "4e5",
            "--anchor-steps", "3", "--brownian-steady-steps", "30", "--analytic-extra", "4", "--tjunction-steps", "30",
-           "--tjunction-particles", "3e5"] + extra
+           "--tjunction-particles", "3e5", "--vertex-steps", "3", "--polyhedral-steps", "20", "--polyhedral-particles", "3e5"] + extra
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -294,5 +294,12 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert tj["particles"] == 300_000 and tj["cells"] == 248_000 and tj["D"] == 1.5e-5 and tj["records_bytes_once"] == 128 * 248_000      # (box records)
         assert tj["kernel"].startswith("cpf::step_kernel_stream<true, true, false, false,") and 0 < tj["frac"] < 1
         assert tj["mesh_flags"]["all_hex"] == 1 and tj["mesh_flags"]["z_thin"] == 0
+        # what is built and had no number in the driver-run line before round 6: the VertexVelocity cycle, the non-hex mesh of configs[4]
+        vv, ph = d["config"]["vertex_velocity"], d["config"]["polyhedral_as_run"]
+        assert "step_kernel_vertex<false, true, false>" in vv["kernel"] and vv["steps"] == 3 and vv["particles_after"] == 200_000
+        assert vv["tets"] == 12 * 12225 and 0 < vv["frac"] <= vv["kernel_frac"] * 1.02 < 1
+        assert ph["cells"] == 114540 and ph["cells_with_9_faces"] == 2242 and ph["particles_after"] == 300_000 and ph["D"] == 1.5e-5
+        assert ph["velocity_uploads"] == 2 and ph["upload_ms_each"] > 0 and ph["ms_per_step_with_uploads"] >= ph["ms_per_step"]
+        assert ph["kernel"].startswith("cpf::step_kernel_stream<true, true, false, false,") and 0 < ph["frac"] < 1
         a = d["config"]["strong_anchor_1e8"]               # the N = 1 point of the strong-scaling curve (here: 4e5)
         assert a["particles"] == 400_000 and a["particles_after"] == 400_000 and a["steps"] == 3 and a["Mparticle_steps_per_s"] > 0
