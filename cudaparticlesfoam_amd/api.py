@@ -230,13 +230,15 @@ class Context:
             self._ck(r)
         return ke.value
 
-    def write_vtu_async(self, path: str) -> float:
-        """Same frame, formatted and written by a worker thread (one frame in flight per context)."""
+    def write_vtu_async(self, path: str, want_ke: bool = True):
+        """Same frame behind the caller's back: a device-side snapshot (one kernel), then copy, energy sum, formatting and file
+        I/O on a worker thread (one frame in flight per context).  want_ke=False: returns None at once -- the step loop is not
+        held up by PCIe; True: waits for the copy and returns the total kinetic energy."""
         ke = C.c_double()
-        r = self.lib.cpf_write_vtu_async(self.h, str(path).encode(), C.byref(ke))
+        r = self.lib.cpf_write_vtu_async(self.h, str(path).encode(), C.byref(ke) if want_ke else None)
         if r not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(r)
-        return ke.value
+        return ke.value if want_ke else None
 
     def write_vtu_wait(self):
         r = self.lib.cpf_write_vtu_wait(self.h)

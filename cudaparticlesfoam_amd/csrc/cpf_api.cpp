@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -82,8 +83,14 @@ struct cpf_context {
     std::thread writer;
     bool writerLive = false;
     int writerStatus = CPF_OK;
-    std::vector<double> wXyzw, wVel;
-    std::vector<int32_t> wCell;
+    // the frame's snapshot: packed in particle-id order on the compute stream into `snapDev`, copied to pinned host memory on
+    // `ioStream` behind an event, read by the worker thread only -- the step loop's stream never waits for PCIe (round 6)
+    void* snapDev = nullptr; void* snapHost = nullptr;
+    size_t snapBytes = 0;
+    hipStream_t ioStream = nullptr;
+    hipEvent_t evSnap = nullptr, evCopied = nullptr;
+    double frameKE = 0.0;                       // of the frame the worker wrote last (valid after its join)
+    std::mutex keMutex; std::condition_variable keCv; bool keReady = false;
     // timing
     int timingStride = 1;                       // "timing_stride": bracket every k-th step launch only
     uint64_t timingLaunch = 0;
@@ -361,6 +368,11 @@ int cpf_destroy(cpf_context* ctx) {
     if (ctx->evFieldFlag) { (void)hipEventDestroy(ctx->evFieldFlag); ctx->evFieldFlag = nullptr; }
     if (ctx->h_occupied) { (void)hipHostFree(ctx->h_occupied); ctx->h_occupied = nullptr; ctx->streamState.occupiedHost = nullptr; }
     freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
+    freeDev(ctx->snapDev);
+    if (ctx->snapHost) { (void)hipHostFree(ctx->snapHost); ctx->snapHost = nullptr; }
+    if (ctx->evSnap) (void)hipEventDestroy(ctx->evSnap);
+    if (ctx->evCopied) (void)hipEventDestroy(ctx->evCopied);
+    if (ctx->ioStream) (void)hipStreamDestroy(ctx->ioStream);
     for (auto& p : ctx->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto& ev : ctx->eventPool) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -1234,27 +1246,62 @@ int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE) {
     CPF_REQUIRE(ctx, ctx && path, CPF_ERR_ARG, "null argument");
     int r = cpf_write_vtu_wait(ctx);                       // one frame in flight; reports the previous frame's failure
     if (r != CPF_OK && r != CPF_WARN_NAN) return r;
-    int64_t n = 0;
-    r = cpf_num_particles(ctx, &n);
-    if (r) return r;
-    ctx->wXyzw.resize((size_t)n * 4); ctx->wVel.resize((size_t)n * 4); ctx->wCell.resize((size_t)n);
-    r = cpf_get_particles(ctx, ctx->wXyzw.data(), ctx->wCell.data(), ctx->wVel.data());   // the snapshot (D2H)
-    if (r) return r;
-    double total = 0.0;                                    // known now, so callers can print it in the reference's order
-    for (int64_t i = 0; i < n; ++i) {
-        const double* v = &ctx->wVel[4 * (size_t)i];
-        total += 0.5 * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    CPF_REQUIRE(ctx, ctx->n > 0, CPF_ERR_STATE, "cpf_write_vtu_async: no particles");
+    CPF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t offC = al(n * 32), offV = offC + al(n * 4), need = offV + al(n * 32);
+    if (!ctx->ioStream) {
+        CPF_HIP(ctx, hipStreamCreateWithFlags(&ctx->ioStream, hipStreamNonBlocking));
+        CPF_HIP(ctx, hipEventCreateWithFlags(&ctx->evSnap, hipEventDisableTiming));
+        CPF_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied, hipEventDisableTiming));
     }
-    if (totalKE) *totalKE = total;
+    if (need > ctx->snapBytes) {                           // (the previous frame's worker has been joined: nobody reads these)
+        if (ctx->snapDev) { (void)hipFree(ctx->snapDev); ctx->snapDev = nullptr; }
+        if (ctx->snapHost) { (void)hipHostFree(ctx->snapHost); ctx->snapHost = nullptr; }
+        ctx->snapBytes = 0;
+        const size_t want = need + need / 8;
+        hipError_t e = hipMalloc(&ctx->snapDev, want);
+        if (e == hipSuccess) e = hipHostMalloc(&ctx->snapHost, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            if (ctx->snapDev) { (void)hipFree(ctx->snapDev); ctx->snapDev = nullptr; }
+            return fail(ctx, e == hipErrorOutOfMemory ? CPF_ERR_NOMEM : CPF_ERR_HIP, std::string("cpf_write_vtu_async: snapshot buffers: ") + hipGetErrorString(e));
+        }
+        ctx->snapBytes = want;
+    }
+    // ---- the snapshot: ONE kernel on the compute stream (particle-id order, the layouts the writer reads); everything else --
+    // PCIe, the energy sum, formatting, the file -- happens behind the caller's back
+    char* d = (char*)ctx->snapDev;
+    CPF_HIP(ctx, cpf::launch_pack_by_gid(ctx->stream, ctx->x, ctx->y, ctx->z, ctx->cell, ctx->gid, ctx->vel, (double*)d, (int32_t*)(d + offC),
+                                         (double*)(d + offV), ctx->n));
+    CPF_HIP(ctx, hipEventRecord(ctx->evSnap, ctx->stream));
+    CPF_HIP(ctx, hipStreamWaitEvent(ctx->ioStream, ctx->evSnap, 0));
+    CPF_HIP(ctx, hipMemcpyAsync(ctx->snapHost, ctx->snapDev, need, hipMemcpyDeviceToHost, ctx->ioStream));
+    CPF_HIP(ctx, hipEventRecord(ctx->evCopied, ctx->ioStream));
     const std::string file(path);
     { std::lock_guard<std::mutex> lk(g_mutex); g_writers.live.push_back(ctx); }
     ctx->writerLive = true;
+    ctx->keReady = false;
     const bool binary = ctx->vtuBinary;
-    ctx->writer = std::thread([ctx, file, n, binary] {
-        ctx->writerStatus = (binary ? cpf_write_vtu_arrays_binary : cpf_write_vtu_arrays)(file.c_str(), n, ctx->wXyzw.data(), ctx->wCell.data(),
-                                                                                         ctx->wVel.data(), nullptr);
+    ctx->writer = std::thread([ctx, file, n, binary, offC, offV] {
+        (void)hipSetDevice(ctx->device);
+        const hipError_t e = hipEventSynchronize(ctx->evCopied);
+        const char* h = (const char*)ctx->snapHost;
+        const double* xyzw = (const double*)h; const int32_t* cell = (const int32_t*)(h + offC); const double* vel = (const double*)(h + offV);
+        double total = 0.0;                                // in index order, like the reference's running sum
+        if (e == hipSuccess)
+            for (size_t i = 0; i < n; ++i) total += 0.5 * (vel[4 * i] * vel[4 * i] + vel[4 * i + 1] * vel[4 * i + 1] + vel[4 * i + 2] * vel[4 * i + 2]);
+        { std::lock_guard<std::mutex> lk(ctx->keMutex); ctx->frameKE = total; ctx->keReady = true; }
+        ctx->keCv.notify_all();
+        ctx->writerStatus = e != hipSuccess ? CPF_ERR_HIP
+                                            : (binary ? cpf_write_vtu_arrays_binary : cpf_write_vtu_arrays)(file.c_str(), (int64_t)n, xyzw, cell, vel, nullptr);
     });
-    return std::isnan(total) ? CPF_WARN_NAN : CPF_OK;
+    if (!totalKE) return CPF_OK;                           // the caller is back in its step loop after the one kernel launch
+    // the energy at once (a host that prints it where the reference does): that host waits for the copy and one pass over it
+    std::unique_lock<std::mutex> lk(ctx->keMutex);
+    ctx->keCv.wait(lk, [ctx] { return ctx->keReady; });
+    *totalKE = ctx->frameKE;
+    return std::isnan(ctx->frameKE) ? CPF_WARN_NAN : CPF_OK;
 }
 
 int cpf_timing_enable(cpf_context* ctx, int on) {

@@ -21,10 +21,12 @@ struct HipDev {
     cpf_context* ctx = nullptr;
     int device = 0;
     hipStream_t sideStream = nullptr;
+    hipStream_t ioStream = nullptr;                  // device-to-host copies of output frames (made on first use)
     std::string err;
 
     ~HipDev() {
         if (sideStream) { (void)hipSetDevice(device); (void)hipStreamDestroy(sideStream); }
+        if (ioStream) { (void)hipSetDevice(device); (void)hipStreamDestroy(ioStream); }
     }
 
     int hip(hipError_t e, const char* what) {
@@ -42,6 +44,13 @@ struct HipDev {
     int bind() { err.clear(); return CPF_DH(hipSetDevice(device)); }
     Stream compute() const { return (hipStream_t)cpf::context_stream(ctx); }     // (read per call: cpf_set_stream may change it)
     Stream side() const { return sideStream; }
+    Stream io() {                                    // (on failure: the side stream -- correct, merely shared with the hand-offs)
+        if (!ioStream && hipStreamCreateWithFlags(&ioStream, hipStreamNonBlocking) != hipSuccess) ioStream = nullptr;
+        return ioStream ? ioStream : sideStream;
+    }
+    // for the frame's worker thread: no access to `err` (the caller's thread owns it)
+    int bindThread() const { return hipSetDevice(device) == hipSuccess ? CPF_OK : CPF_ERR_HIP; }
+    int eventSyncQuiet(Event e) const { return hipEventSynchronize(e) == hipSuccess ? CPF_OK : CPF_ERR_HIP; }
     int64_t nCells() const { return cpf::context_cells(ctx); }
 
     // memory

@@ -12,7 +12,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -97,8 +99,16 @@ class ShardCore {
     std::thread writer;
     bool writerLive = false;
     int writerStatus = CPF_OK;
-    std::vector<double> wXyzw, wVel;
-    std::vector<int32_t> wCell;
+    // the frame in flight (round 6: nothing of a frame is copied or summed on the caller's thread, and the step loop's stream
+    // does not wait for PCIe): the gathered cloud stays in device buffers that live as long as the shard, goes to pinned host
+    // memory on the `io` stream behind an event, and the worker thread takes it from there
+    double *fOut = nullptr, *fIn = nullptr, *fXyzw = nullptr, *fVel = nullptr;
+    int32_t* fCell = nullptr; int64_t* fBad = nullptr;
+    int64_t fOutCap = 0, fInCap = 0;                       // records
+    char* fHost = nullptr; size_t fHostBytes = 0;          // pinned: xyzw | vel | cell | bad
+    Event evFrame = Event(), evFrameCopied = Event();
+    double frameKE = 0.0;
+    std::mutex keMutex; std::condition_variable keCv; bool keReady = false;
 
     // statistics
     int64_t particleSteps = 0, handedOff = 0, exchanges = 0, rebalances = 0, grown = 0, sendGrown = 0, kernelLaunches = 0;
@@ -179,8 +189,12 @@ class ShardCore {
                         (void*)agid, (void*)d_cellLo, (void*)sendbuf, (void*)recvbuf, (void*)d_meta, (void*)d_table, (void*)d_weights,
                         (void*)d_scalar, (void*)d_Ufull})
             if (p) dev.release(p);
-        for (void* p : {(void*)h_cellLo, (void*)h_table, (void*)h_want, (void*)h_scalar})
+        for (void* p : {(void*)fOut, (void*)fIn, (void*)fXyzw, (void*)fVel, (void*)fCell, (void*)fBad})
+            if (p) dev.release(p);
+        for (void* p : {(void*)h_cellLo, (void*)h_table, (void*)h_want, (void*)h_scalar, (void*)fHost})
             if (p) dev.hostRelease(p);
+        for (Event e : {evFrame, evFrameCopied})
+            if (e != Event()) dev.eventDestroy(e);
         for (Event e : {evPack, evGot, evDone, evRepack})
             if (e != Event()) dev.eventDestroy(e);
         for (auto& p : commEvents) { dev.eventDestroy(p.first); dev.eventDestroy(p.second); }
@@ -719,34 +733,105 @@ class ShardCore {
         return CPF_OK;
     }
 
-    // COLLECTIVE: every rank counts (one all-reduce), the root sizes its host arrays, every rank gathers.  On the root the frame is
-    // then formatted and written BEHIND the caller's back, like cpf_write_vtu_async (1e5 particles: 0.1 s of formatting against
-    // milliseconds of GPU time between two frames): the total kinetic energy is returned at once, one frame is in flight, the
-    // next call (or cpf_shard_destroy) waits for it and reports its failure.
+    // COLLECTIVE: the cloud is gathered to the root's DEVICE (pack, counts all-gather, all-to-all-v, scatter into particle-id
+    // order -- all on the compute stream, in buffers that live as long as the shard), an event is recorded, and the call returns:
+    // the copy to pinned host memory runs on the io stream behind that event, and the root's worker thread sums the energy,
+    // formats and writes (1e5 particles: 0.1 s of formatting against milliseconds of GPU time between two frames).  One frame is
+    // in flight; the next call (or cpf_shard_write_vtu_wait / cpf_shard_destroy) waits for it and reports its failure.  totalKE
+    // non-null: the root waits for the copy and the sum (a host that prints the energy where the reference does).
     int writeVtu(int root, const char* path, double* totalKE) {
         if (!path) return fail(CPF_ERR_ARG, "cpf_shard_write_vtu: null path");
         if (root < 0 || root >= W) return fail(CPF_ERR_ARG, "cpf_shard_write_vtu: root out of range");
-        const int prev = writerWait();
-        int64_t total = 0;
-        CPF_SH(globalCount(&total));
+        const int prev = writerWait();                    // (its buffers are free again)
         if (totalKE) *totalKE = 0.0;
-        if (rank != root) return gather(root, nullptr, nullptr, nullptr, nullptr);
-        wXyzw.resize((size_t)total * 4); wVel.resize((size_t)total * 4); wCell.resize((size_t)total);
-        CPF_SH(gather(root, wXyzw.data(), wCell.data(), wVel.data(), nullptr));
-        double ke = 0.0;
-        for (int64_t i = 0; i < total; ++i) {
-            const double* v = &wVel[4 * (size_t)i];
-            ke += 0.5 * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        CPF_SH(finishExchange());
+        Stream s = dev.compute();
+        // how many particles every rank holds: one small all-gather and the call's only wait for the compute stream
+        h_scalar[0] = (double)n;
+        CPF_SH(dev.copy(d_scalar, h_scalar, 8, s));
+        if (haveComm) CPF_SH_COMM(comm.all_gather(comm.self, d_scalar, d_scalar + 1, 8, s));
+        else CPF_SH(dev.copy(d_scalar + 1, d_scalar, 8, s));
+        CPF_SH(dev.copy(h_scalar + 1, d_scalar + 1, (size_t)W * 8, s));
+        CPF_SH(dev.streamSync(s));
+        std::vector<int64_t> counts((size_t)W);
+        int64_t total = 0;
+        for (int r = 0; r < W; ++r) { counts[(size_t)r] = (int64_t)h_scalar[1 + r]; total += counts[(size_t)r]; }
+        constexpr int64_t kRec = 8 * 8;                   // kOutputDoubles doubles
+        auto room = [&](void** p, int64_t& cap, int64_t want, size_t unit) -> int {
+            if (want <= cap && *p) return CPF_OK;
+            if (*p) { dev.release(*p); *p = nullptr; }
+            cap = 0;
+            const int64_t c = std::max<int64_t>(want + want / 8, 1);
+            CPF_SH(dev.alloc(p, (size_t)c * unit));
+            cap = c;
+            return CPF_OK;
+        };
+        CPF_SH(room((void**)&fOut, fOutCap, n, (size_t)kRec));
+        CPF_SH(dev.packOutput(x, y, z, cell, gid, velValid ? vel : nullptr, fOut, n));
+        std::vector<int64_t> sOff((size_t)W, 0), sBytes((size_t)W, 0), rOff((size_t)W, 0), rBytes((size_t)W, 0);
+        sBytes[(size_t)root] = n * kRec;
+        if (rank == root) {
+            if (total > fInCap || !fIn) {
+                for (void** q : {(void**)&fIn, (void**)&fXyzw, (void**)&fVel, (void**)&fCell})
+                    if (*q) { dev.release(*q); *q = nullptr; }
+                fInCap = 0;
+                const int64_t c = std::max<int64_t>(total + total / 8, 1);
+                CPF_SH(dev.alloc((void**)&fIn, (size_t)c * kRec)); CPF_SH(dev.alloc((void**)&fXyzw, (size_t)c * 32));
+                CPF_SH(dev.alloc((void**)&fVel, (size_t)c * 32)); CPF_SH(dev.alloc((void**)&fCell, (size_t)c * 4));
+                fInCap = c;
+            }
+            if (!fBad) CPF_SH(dev.alloc((void**)&fBad, 8));
+            int64_t off = 0;
+            for (int r = 0; r < W; ++r) { rOff[(size_t)r] = off * kRec; rBytes[(size_t)r] = counts[(size_t)r] * kRec; off += counts[(size_t)r]; }
         }
-        if (totalKE) *totalKE = ke;
+        if (haveComm) CPF_SH_COMM(comm.all_to_all_v(comm.self, fOut, sOff.data(), sBytes.data(), fIn, rOff.data(), rBytes.data(), s));
+        else if (n > 0) CPF_SH(dev.copy(fIn, fOut, (size_t)(n * kRec), s));
+        if (rank != root) {
+            if (prev != CPF_OK && prev != CPF_WARN_NAN) return fail(prev, "cpf_shard_write_vtu: the previous frame could not be written");
+            return CPF_OK;
+        }
+        // ---- root: into particle-id order on the device, then off to the host behind the caller's back
+        const size_t offV = ((size_t)total * 32 + 255) & ~(size_t)255, offC = offV + (((size_t)total * 32 + 255) & ~(size_t)255);
+        const size_t offB = offC + (((size_t)total * 4 + 255) & ~(size_t)255), needHost = offB + 8;
+        if (needHost > fHostBytes) {
+            if (fHost) { dev.hostRelease(fHost); fHost = nullptr; }
+            fHostBytes = 0;
+            CPF_SH(dev.hostAlloc((void**)&fHost, needHost + needHost / 8));
+            fHostBytes = needHost + needHost / 8;
+        }
+        if (evFrame == Event()) { CPF_SH(dev.eventCreate(&evFrame, false)); CPF_SH(dev.eventCreate(&evFrameCopied, false)); }
+        CPF_SH(dev.fill(fBad, 0, 8, s));
+        if (total > 0) CPF_SH(dev.scatterOutput(fIn, total, total, fXyzw, fCell, fVel, fBad));
+        CPF_SH(dev.eventRecord(evFrame, s));
+        Stream io = dev.io();
+        CPF_SH(dev.streamWait(io, evFrame));
+        CPF_SH(dev.copy(fHost, fXyzw, (size_t)total * 32, io)); CPF_SH(dev.copy(fHost + offV, fVel, (size_t)total * 32, io));
+        CPF_SH(dev.copy(fHost + offC, fCell, (size_t)total * 4, io)); CPF_SH(dev.copy(fHost + offB, fBad, 8, io));
+        CPF_SH(dev.eventRecord(evFrameCopied, io));
         const std::string file(path);
         writerLive = true;
-        writer = std::thread([this, file, total] {
-            writerStatus = dev.writeVtuArrays(file.c_str(), total, wXyzw.data(), wCell.data(), wVel.data(), nullptr);
+        keReady = false;
+        writer = std::thread([this, file, total, offV, offC, offB] {
+            int st = dev.bindThread();
+            if (st == CPF_OK) st = dev.eventSyncQuiet(evFrameCopied);
+            const double* xyzw = (const double*)fHost; const double* v = (const double*)(fHost + offV);
+            double ke = 0.0;                              // in index order, like the reference's running sum
+            if (st == CPF_OK)
+                for (int64_t i = 0; i < total; ++i) ke += 0.5 * (v[4 * i] * v[4 * i] + v[4 * i + 1] * v[4 * i + 1] + v[4 * i + 2] * v[4 * i + 2]);
+            { std::lock_guard<std::mutex> lk(keMutex); frameKE = ke; keReady = true; }
+            keCv.notify_all();
+            int64_t bad = 0;
+            if (st == CPF_OK) std::memcpy(&bad, fHost + offB, 8);
+            if (st == CPF_OK && bad != 0) st = CPF_ERR_STATE;        // particle ids are not 0 .. nGlobal-1: no frame
+            writerStatus = st != CPF_OK ? st : dev.writeVtuArrays(file.c_str(), total, xyzw, (const int32_t*)(fHost + offC), v, nullptr);
         });
         // (the current frame is on its way whatever happened to the previous one; a failure of that one is reported now)
         if (prev != CPF_OK && prev != CPF_WARN_NAN) return fail(prev, "cpf_shard_write_vtu: the previous frame could not be written");
-        return std::isnan(ke) ? CPF_WARN_NAN : CPF_OK;
+        if (!totalKE) return CPF_OK;
+        std::unique_lock<std::mutex> lk(keMutex);
+        keCv.wait(lk, [this] { return keReady; });
+        *totalKE = frameKE;
+        return std::isnan(frameKE) ? CPF_WARN_NAN : CPF_OK;
     }
 
     void stats(cpf_shard_stats* o) {

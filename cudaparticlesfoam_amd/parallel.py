@@ -295,10 +295,12 @@ class ShardedCloud:
                                            None if vel is None else vel.ctypes.data_as(C.c_void_p)))
         return xyzw, cell, vel
 
-    def write_vtu(self, path: str, root: int = 0) -> float:
-        """COLLECTIVE: one frame of the whole cloud written by ``root`` (the reference's particle_%04d.vtu layout)."""
+    def write_vtu(self, path: str, root: int = 0, want_ke: bool = True):
+        """COLLECTIVE: one frame of the whole cloud written by ``root`` (the reference's particle_%04d.vtu layout): gathered to
+        the root's GPU, copied, summed, formatted and written by its worker thread.  want_ke=False: returns None after the
+        device-side gather; True: the root waits for the copy and returns the total kinetic energy (0.0 elsewhere)."""
         ke = C.c_double()
-        st = self.lib.cpf_shard_write_vtu(self.h, int(root), path.encode(), C.byref(ke))
+        st = self.lib.cpf_shard_write_vtu(self.h, int(root), path.encode(), C.byref(ke) if want_ke else None)
         if st not in (L.CPF_OK, L.CPF_WARN_NAN):
             self._ck(st)
-        return ke.value
+        return ke.value if want_ke else None

@@ -452,9 +452,12 @@ int cpf_shard_cell_ranges(cpf_shard* s, int32_t* cellLo /* [nRanks + 1] */);
 /* COLLECTIVE: the whole cloud in particle-id order on rank `root` (ids must be 0 .. nGlobal-1, as seeded):
  * xyzw [nGlobal][4], cell [nGlobal], vel [nGlobal][4] as cpf_get_particles; other ranks pass NULLs. */
 int cpf_shard_gather(cpf_shard* s, int root, double* xyzw, int32_t* cell, double* vel);
-/* COLLECTIVE: cpf_shard_gather + the frame writer of cpf_write_vtu_async on `root` (option "vtu_binary" of the context): the
- * cloud is gathered now, totalKE is returned at once, formatting and file I/O run on a worker thread of the root; one frame is
- * in flight, the next call, cpf_shard_write_vtu_wait or cpf_shard_destroy waits for it and reports its failure. */
+/* COLLECTIVE: the frame writer of cpf_write_vtu_async for the sharded cloud (option "vtu_binary" of the context): the cloud is
+ * gathered to `root`'s GPU in particle-id order (pack, counts all-gather, all-to-all-v, scatter: on the compute stream) and the
+ * call returns; the copy to pinned host memory (a stream of its own), the energy sum, formatting and file I/O run on a worker
+ * thread of the root.  totalKE NULL: no rank waits for PCIe; non-NULL: the root waits for the copy and the sum and returns the
+ * energy (other ranks: 0).  One frame is in flight: the next call, cpf_shard_write_vtu_wait or cpf_shard_destroy waits for it
+ * and reports its failure (ids that are not 0 .. nGlobal-1: CPF_ERR_STATE, no file). */
 int cpf_shard_write_vtu(cpf_shard* s, int root, const char* path, double* totalKE);
 int cpf_shard_write_vtu_wait(cpf_shard* s);
 typedef struct cpf_shard_stats {
@@ -529,11 +532,15 @@ int cpf_stage_move(cpf_context* ctx, double* particles, double* disps, int64_t n
 /* writeParticles2VTU (cuda/utils.cpp:144-283): D2H of the context-owned cloud in particle-id
  * order + ASCII particle_%04d.vtu layout.  totalKE (nullable) = "System Kinetic Energy". */
 int cpf_write_vtu(cpf_context* ctx, const char* path, double* totalKE);
-/* The same frame, written behind the caller's back: snapshots the cloud (the device-to-host copy), returns the
- * total kinetic energy at once (so a host can print it where the reference does), and leaves formatting and file
- * I/O -- 1e5 particles: 0.1 s, three orders of magnitude more than the GPU needs for the cycles between two
- * frames -- to a worker thread.  One frame is in flight per context: the next call (or cpf_write_vtu_wait, or
- * cpf_destroy) waits for it and reports its status. */
+/* The same frame, written behind the caller's back.  The call snapshots the cloud ON THE DEVICE -- one kernel on the context's
+ * stream that packs it in particle-id order into a second buffer -- and returns; the device-to-host copy (pinned memory, a stream
+ * of its own, behind an event), the energy sum, formatting and file I/O -- 1e5 particles: 0.1 s, three orders of magnitude more
+ * than the GPU needs for the cycles between two frames -- belong to a worker thread, and the step loop's stream never waits for
+ * PCIe (round 6: a 1e7-particle frame used to hold the loop for 20 ms, now for the launch of one kernel).
+ * totalKE NULL: returns at once.  totalKE non-NULL (a host that prints the energy where the reference does, cuda/utils.cpp:250):
+ * the call waits until the copy has arrived and been summed -- the frame is still written behind the caller's back.
+ * One frame is in flight per context: the next call (or cpf_write_vtu_wait, or cpf_destroy) waits for it and reports its status
+ * (CPF_WARN_NAN included when the energy was not asked for here). */
 int cpf_write_vtu_async(cpf_context* ctx, const char* path, double* totalKE);
 int cpf_write_vtu_wait(cpf_context* ctx);
 /* same formatter on host arrays: xyzw [n][4], cell [n], vel [n][4] */

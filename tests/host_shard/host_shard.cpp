@@ -49,6 +49,9 @@ struct HostDev {
     int bind() { err.clear(); return CPF_OK; }
     Stream compute() const { return nullptr; }
     Stream side() const { return nullptr; }
+    Stream io() { return nullptr; }
+    int bindThread() const { return CPF_OK; }
+    int eventSyncQuiet(Event) const { return CPF_OK; }
     int64_t nCells() const { return hc->nCells; }
 
     int alloc(void** p, size_t bytes) { *p = std::calloc(std::max<size_t>(bytes, 16), 1); return *p ? CPF_OK : CPF_ERR_NOMEM; }
