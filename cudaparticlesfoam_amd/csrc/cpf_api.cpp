@@ -79,6 +79,9 @@ struct cpf_context {
     // "VertexVelocity" advect only: the tet decomposition and one velocity per tet-mesh vertex
     double* d_tetPos = nullptr; int32_t* d_tets = nullptr; double* d_vertVel = nullptr;
     int64_t nTetVerts = 0, nTets = 0; int tetsPerCell = 0; bool haveVertVel = false;
+    double* d_vertCone = nullptr;               // cone-locate tables (cpf_kernels.hip, VertexField), if the decomposition admits them
+    bool vertexFast = true;                     // cpf_set_option("vertex_fast")
+    std::string vertConeWhy;                    // why the tables were not built (cpf_step_kernel_name says so)
     // asynchronous output (cpf_write_vtu_async): one frame in flight
     std::thread writer;
     bool writerLive = false;
@@ -279,6 +282,60 @@ int64_t context_cells(const cpf_context* ctx) { return ctx->haveMesh ? ctx->host
 }  // namespace cpf
 
 namespace {
+// Is the tet decomposition of every cell a FAN about one apex that covers every direction exactly once?  (What the reference's
+// fragment builds: apex = the cell centre, one tet per face triangle, src/initCuda.H:99-105.)  Then no two tets of a cell
+// overlap, which is what makes the cone locate of the "VertexVelocity" advect exact (cpf_kernels.hip).  Checked per cell: every
+// tet starts at the same vertex; all determinants have one sign and none is flat beyond a condition of 1e5 (weights then carry
+// rounding errors below 1e-10, two orders inside the locate's margin); the base triangles form a closed oriented surface (every
+// directed edge once, its reverse once); the solid angles the tets subtend at the apex (Van Oosterom-Strackee) add up to
+// 4 pi -- a closed surface seen from its inner side everywhere that winds round the apex once projects one-to-one onto the
+// sphere of directions, i.e. the cones do not overlap.
+// Returns "" or the first defect.
+std::string tetFanDefect(const double* pos, const int32_t* tets, int64_t nCells, int tetsPerCell) {
+    auto P = [&](int32_t v, int k) { return pos[3 * (int64_t)v + k]; };
+    const double fourPi = 12.566370614359172;
+    std::vector<uint64_t> edges;
+    for (int64_t c = 0; c < nCells; ++c) {
+        const int32_t* t0 = tets + 4 * c * tetsPerCell;
+        const int32_t apex = t0[0];
+        double omega = 0.0;
+        int sign = 0;
+        for (int k = 0; k < tetsPerCell; ++k) {
+            const int32_t* ix = t0 + 4 * k;
+            if (ix[0] != apex) return "cell " + std::to_string(c) + ": its tets do not share their first vertex";
+            double e[3][3], len[3];
+            for (int j = 0; j < 3; ++j) {
+                for (int q = 0; q < 3; ++q) e[j][q] = P(ix[j + 1], q) - P(apex, q);
+                len[j] = std::sqrt(e[j][0] * e[j][0] + e[j][1] * e[j][1] + e[j][2] * e[j][2]);
+            }
+            const double det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                               e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+            const double scale = len[0] * len[1] * len[2];
+            if (!(std::fabs(det) * 1e5 > scale)) return "cell " + std::to_string(c) + ": a flat (or badly conditioned) tet";
+            const int sg = det > 0 ? 1 : -1;
+            if (sign == 0) sign = sg;
+            else if (sg != sign) return "cell " + std::to_string(c) + ": tets of both orientations";
+            auto dot = [&](int i, int j) { return e[i][0] * e[j][0] + e[i][1] * e[j][1] + e[i][2] * e[j][2]; };
+            omega += 2.0 * std::atan2(std::fabs(det), scale + dot(0, 1) * len[2] + dot(0, 2) * len[1] + dot(1, 2) * len[0]);
+        }
+        if (std::fabs(omega - fourPi) > 1e-6) return "cell " + std::to_string(c) + ": the tets' solid angles at the apex do not add up to 4 pi";
+        // the base triangles form a closed oriented surface: every directed edge once, its reverse once (a tet listed twice in
+        // place of its mirror image keeps the angles' sum and is caught here)
+        edges.clear();
+        for (int k = 0; k < tetsPerCell; ++k) {
+            const int32_t* ix = t0 + 4 * k;
+            for (int j = 0; j < 3; ++j) edges.push_back(((uint64_t)(uint32_t)ix[1 + j] << 32) | (uint32_t)ix[1 + (j + 1) % 3]);
+        }
+        std::sort(edges.begin(), edges.end());
+        for (size_t i = 0; i < edges.size(); ++i) {
+            const uint64_t rev = (edges[i] << 32) | (edges[i] >> 32);
+            if ((i > 0 && edges[i] == edges[i - 1]) || !std::binary_search(edges.begin(), edges.end(), rev))
+                return "cell " + std::to_string(c) + ": the tets' base triangles do not form a closed surface";
+        }
+    }
+    return "";
+}
+
 // U[nCells][3] (device) -> the padded field and the cell records; on a mesh that qualifies for the flat walk (cpf_walk.h) the
 // kernel also notes whether any cell has a z component, and the note is read back behind it (8 bytes, asynchronous)
 hipError_t layOutField(cpf_context* ctx, const double* dU3, int64_t nCells) {
@@ -367,7 +424,7 @@ int cpf_destroy(cpf_context* ctx) {
     freeDev(ctx->d_occupied);
     if (ctx->evFieldFlag) { (void)hipEventDestroy(ctx->evFieldFlag); ctx->evFieldFlag = nullptr; }
     if (ctx->h_occupied) { (void)hipHostFree(ctx->h_occupied); ctx->h_occupied = nullptr; ctx->streamState.occupiedHost = nullptr; }
-    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone);
     freeDev(ctx->snapDev);
     if (ctx->snapHost) { (void)hipHostFree(ctx->snapHost); ctx->snapHost = nullptr; }
     if (ctx->evSnap) (void)hipEventDestroy(ctx->evSnap);
@@ -658,7 +715,8 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             // the streaming launcher stamps the events with the dispatch's own begin / end (cpf_device.h, StreamState);
             // any other kernel is bracketed by two event records
-            stamped = !vertexU && cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
+            stamped = vertexU ? cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState, cycPerLaunch)
+                              : cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
             if (stamped) { ctx->streamState.evStart = e0; ctx->streamState.evStop = e1; }
             else CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
         }
@@ -666,7 +724,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
         const hipError_t le = vertexU
             ? cpf::launch_step_vertex(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed, reflect,
                                       storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->d_tetPos, ctx->d_tets, ctx->tetsPerCell,
-                                      ctx->d_vertVel)
+                                      ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState)
             : cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
                                &ctx->streamState);
@@ -862,6 +920,11 @@ int cpf_set_option(cpf_context* ctx, const char* key, double value) {
         ctx->stepVariant = (int)value;
         return CPF_OK;
     }
+    if (k == "vertex_fast") {
+        CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "vertex_fast must be 0 or 1");
+        ctx->vertexFast = value != 0;
+        return CPF_OK;
+    }
     if (k == "z_fold") {
         CPF_REQUIRE(ctx, value == 0 || value == 1, CPF_ERR_ARG, "z_fold must be 0 or 1");
         ctx->zFold = value != 0;
@@ -983,8 +1046,15 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
                                               ctx->streamState.coopMaxCells);
     const char* b[2] = {"false", "true"};
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
-    char tmp[160];
-    if (flags & CPF_STEP_VERTEX_VELOCITY) snprintf(tmp, sizeof tmp, "cpf::step_kernel_vertex<%s, %s, %s>", b[brown], b[reflect], b[sv]);
+    char tmp[192];
+    if ((flags & CPF_STEP_VERTEX_VELOCITY) &&
+        cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState,
+                                 (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1))
+        snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream_vertex<%s, %s, %s, %s, %d> (cone locate)", b[brown], b[reflect], b[sv],
+                 b[ctx->stats ? 1 : 0], cpf::stream_vertex_lookup_mode(ctx->lastStepN > 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState));
+    else if (flags & CPF_STEP_VERTEX_VELOCITY)
+        snprintf(tmp, sizeof tmp, "cpf::step_kernel_vertex<%s, %s, %s> (%s)", b[brown], b[reflect], b[sv],
+                 (ctx->vertexFast && ctx->d_vertCone) ? "cone locate" : (ctx->d_vertCone || ctx->vertConeWhy.empty() ? "all tets" : ("all tets: " + ctx->vertConeWhy).c_str()));
     else if (v == 5 && !brown && !sv && !(flags & CPF_STEP_FUSE_CYCLES))
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_ahead<%s, %s>", b[reflect], b[ctx->stats]);
     else if (v == 4 || v == 5) {
@@ -1167,7 +1237,7 @@ int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, cons
         CPF_REQUIRE(ctx, tets[k] >= 0 && tets[k] < nVerts, CPF_ERR_MESH, "cpf_set_tets: tet vertex out of range");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel);
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone);
     ctx->haveVertVel = false;
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tetPos, (size_t)nVerts * 24));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tets, (size_t)nTets * 16));
@@ -1176,6 +1246,13 @@ int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, cons
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_tets, tets, (size_t)nTets * 16, hipMemcpyHostToDevice, ctx->stream));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->nTetVerts = nVerts; ctx->nTets = nTets; ctx->tetsPerCell = tetsPerCell;
+    // the cone locate (cpf_kernels.hip, VertexField) is exact only on a decomposition whose tets cannot overlap: decided here
+    ctx->vertConeWhy = tetFanDefect(positions, tets, ctx->host.nCells, tetsPerCell);
+    if (ctx->vertConeWhy.empty()) {
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_vertCone, (size_t)nTets * 80));
+        CPF_HIP(ctx, cpf::launch_vertex_cone_tables(ctx->stream, ctx->d_tetPos, ctx->d_tets, nTets, ctx->d_vertCone));
+        CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return CPF_OK;
 }
 int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVerts) {
@@ -1195,7 +1272,7 @@ int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* 
                 "cpf_stage_advect_vertex: call cpf_set_tets and cpf_set_vertex_velocity (for the current mesh) first");
     CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect_vertex: null array");
     CPF_HIP(ctx, cpf::launch_stage_advect_vertex(ctx->stream, particles, ids, vels, disps, dt, n, ctx->d_tetPos, ctx->d_tets,
-                                                 ctx->tetsPerCell, ctx->d_vertVel));
+                                                 ctx->tetsPerCell, ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr));
     return CPF_OK;
 }
 int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,

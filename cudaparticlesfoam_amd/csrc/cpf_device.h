@@ -91,7 +91,18 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
 hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                               bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
-                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel);
+                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel, const double* cone,
+                              int variant, StreamState* ss);
+// does launch_step_vertex stream (step_kernel_stream_vertex) or run step_kernel_vertex, for these arguments?
+bool step_vertex_streams(const MeshView& m, const double* cone, int variant, const StreamState* ss, int nCyc);
+struct VertexField;                  // cpf_walk.h
+// the "VertexVelocity" cycle on the streaming kernel (all-hex meshes with cone-locate tables; else launch_step_vertex's own kernel)
+bool stream_vertex_capable(const MeshView& m);
+int stream_vertex_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss);
+hipError_t launch_step_stream_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                                     double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
+                                     bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                                     StreamState& ss, const VertexField& vf);
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
                               bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
@@ -120,7 +131,9 @@ hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* i
                                      int64_t n);
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                       int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
-                                      const double* vertVel);
+                                      const double* vertVel, const double* cone);
+// cone-locate tables of the "VertexVelocity" advect: cone[nTets][10] (cpf_kernels.hip, VertexField)
+hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, double* cone);
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,
                                  uint32_t step, uint32_t seed);
 hipError_t launch_stage_locate(hipStream_t st, const double* P, const double* disps, int32_t* ids, int64_t n,

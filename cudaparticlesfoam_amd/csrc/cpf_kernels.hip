@@ -23,38 +23,6 @@ namespace cpf {
 // structure; >1 keeps the particle in registers between cycles)
 // ------------------------------------------------------------------------------------------------
 
-// "VertexVelocity" advect mode (cuda/particles.cu:244-313, 428-437): the velocity at P is the barycentric interpolation of
-// VERTEX velocities in a tet of the particle's cell -- the tet whose smallest barycentric weight of P is largest (the product
-// tracks cells, and the interpolant is continuous across the tets of a cell), then weighed exactly like the reference
-// (w_X = det(tet with X := P) * (1 / det(tet))).  Shared by the staged advect and the fused cycle: same bits.
-struct VertexField { const double* pos; const int32_t* tets; const double* vel; int tetsPerCell; };
-__device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
-    const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
-    const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
-    return d.x * c.x + d.y * c.y + d.z * c.z;
-}
-__device__ __forceinline__ bool vertex_velocity(const VertexField& f, const D3& Pp, int c, D3& v) {
-    auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
-    int best = -1;
-    double bestMin = 0.0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    for (int k = 0; k < f.tetsPerCell; ++k) {
-        const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + k);
-        const D3 A = ld(f.pos, ix[0]), B = ld(f.pos, ix[1]), C = ld(f.pos, ix[2]), D = ld(f.pos, ix[3]);
-        const double den = det4(A, B, C, D);
-        if (den == 0.0) continue;                                 // a bad tet (particles.cu:275-278) cannot hold P
-        const double a = det4(Pp, B, C, D) * (1. / den), b = det4(A, Pp, C, D) * (1. / den);
-        const double cc = det4(A, B, Pp, D) * (1. / den), d = det4(A, B, C, Pp) * (1. / den);
-        const double m = fmin(fmin(a, b), fmin(cc, d));
-        if (best < 0 || m > bestMin) { best = k; bestMin = m; w0 = a; w1 = b; w2 = cc; w3 = d; }
-    }
-    if (best < 0) return false;
-    const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + best);
-    const D3 vA = ld(f.vel, ix[0]), vB = ld(f.vel, ix[1]), vC = ld(f.vel, ix[2]), vD = ld(f.vel, ix[3]);
-    v = {((w0 * vA.x + w1 * vB.x) + w2 * vC.x) + w3 * vD.x, ((w0 * vA.y + w1 * vB.y) + w2 * vC.y) + w3 * vD.y,
-         ((w0 * vA.z + w1 * vB.z) + w2 * vC.z) + w3 * vD.z};
-    return true;
-}
-
 template <class TRACER, bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool VERTEX = false>
 __device__ __forceinline__ void particle_cycles(const TRACER& tr, const MeshView& m, D3& P, int& cur, D3& v,
                                                 uint64_t id, double dt, double sigma, uint32_t step0, int nCyc,
@@ -499,15 +467,25 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
     return hipGetLastError();
 }
 
+// the streaming kernel takes the cycle where it would take the cell-constant one (variant 4: -1 on a mesh with cell records),
+// the decomposition is admitted to the cone locate (its advect never fails there) and the mesh is all-hex
+bool step_vertex_streams(const MeshView& m, const double* cone, int variant, const StreamState* ss, int nCyc) {
+    return cone != nullptr && ss != nullptr && stream_vertex_capable(m) &&
+           effective_step_variant(variant, m, true, nCyc, ss->coopMaxCells) == kVariantStream;
+}
+
 hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                               double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                               bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
-                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel) {
+                              const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel, const double* cone,
+                              int variant, StreamState* ss) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
-    const VertexField vf{pos, tets, vertVel, tetsPerCell};
+    const VertexField vf{pos, tets, vertVel, tetsPerCell, cone};
+    if (step_vertex_streams(m, cone, variant, ss, nCyc))
+        return launch_step_stream_vertex(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m, counters, *ss, vf);
 #define CPF_VTX(B, R, SV) hipLaunchKernelGGL((step_kernel_vertex<B, R, SV>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, vf, counters)
     if (brown) {
         if (reflect) { if (storeVel) CPF_VTX(true, true, true); else CPF_VTX(true, true, false); }
@@ -682,10 +660,37 @@ hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* i
 }
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                       int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
-                                      const double* vertVel) {
+                                      const double* vertVel, const double* cone) {
     if (n > 0)
         hipLaunchKernelGGL(stage_advect_vertex_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels,
-                           (double4*)disps, dt, n, VertexField{pos, tets, vertVel, tetsPerCell});
+                           (double4*)disps, dt, n, VertexField{pos, tets, vertVel, tetsPerCell, cone});
+    return hipGetLastError();
+}
+
+// the cone-locate tables of the "VertexVelocity" advect (see VertexField): per tet the rows of the inverse of [B-A C-A D-A] --
+// (B-A, C-A, D-A) coordinates of P - A, a guess only -- and 1 / det4(A, B, C, D) by the expressions vertex_velocity() itself uses
+__global__ __launch_bounds__(kBlock) void vertex_cone_tables_kernel(const double* __restrict__ pos, const int32_t* __restrict__ tets,
+                                                                    int64_t nTets, double* __restrict__ cone) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nTets) return;
+    auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
+    const int32_t* ix = tets + 4 * t;
+    const D3 A = ld(pos, ix[0]), B = ld(pos, ix[1]), C = ld(pos, ix[2]), D = ld(pos, ix[3]);
+    const double den = det4(A, B, C, D);
+    const D3 b = {B.x - A.x, B.y - A.y, B.z - A.z}, c = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
+    const D3 cd = {c.y * d.z - c.z * d.y, c.z * d.x - c.x * d.z, c.x * d.y - c.y * d.x};
+    const D3 db = {d.y * b.z - d.z * b.y, d.z * b.x - d.x * b.z, d.x * b.y - d.y * b.x};
+    const D3 bc = {b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x};
+    const double vol = b.x * cd.x + b.y * cd.y + b.z * cd.z;
+    const double s = vol != 0.0 ? 1.0 / vol : 0.0;
+    double* g = cone + kConeDoubles * t;
+    g[0] = cd.x * s; g[1] = cd.y * s; g[2] = cd.z * s;
+    g[3] = db.x * s; g[4] = db.y * s; g[5] = db.z * s;
+    g[6] = bc.x * s; g[7] = bc.y * s; g[8] = bc.z * s;
+    g[9] = den == 0.0 ? 0.0 : 1. / den;        // (a mesh with a flat tet is not admitted to the cone locate: cpf_set_tets)
+}
+hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, double* cone) {
+    if (nTets > 0) hipLaunchKernelGGL(vertex_cone_tables_kernel, grid_of(nTets), dim3(kBlock), 0, st, pos, tets, nTets, cone);
     return hipGetLastError();
 }
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,

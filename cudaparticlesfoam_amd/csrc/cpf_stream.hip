@@ -142,11 +142,15 @@ struct StreamOccupancy {
     static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : CPF_STREAM_WAVES_B0))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
 };
 
-template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
-__global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
-    double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,   // read through kernarg_cloud_ptrs()
+// The kernel's body.  VERTEX: the advect takes the velocity INTERPOLATED at the particle from tet-vertex values (the reference's
+// "VertexVelocity" mode, cuda/particles.cu:244-313; vertex_velocity() in cpf_walk.h, per-lane reads of the tet tables from L2)
+// instead of the record's cell-constant one; everything else -- the record cache, the walk, the prefetch -- is the same code.
+// Two kernels wrap it (below): step_kernel_stream, whose name and parameter list every profile and test of rounds 2-5 knows,
+// and step_kernel_stream_vertex, which appends the VertexField to the same parameter list (the kernarg offsets stay valid).
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP, bool VERTEX>
+__device__ __forceinline__ void stream_body(
     const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
-    int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
+    int nCyc, uint32_t seed, const MeshView& m, unsigned long long* __restrict__ counters, const StreamArgs& sa, const VertexField& vf) {
     // (with the kick the landing zone and the hit pool are larger: 7 slots keep the sixth wave, 6600 of 6826 bytes)
 #ifndef CPF_STREAM_SLOTS_BROWN
 #define CPF_STREAM_SLOTS_BROWN 10
@@ -567,11 +571,19 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
                 const bool gatherRound = __popcll(missLanes) >= kStreamGatherLanes;
                 // advect (particles.cu:355-362) with the record's velocity: end point E, parked in the lane's E slot
                 auto advect = [&](const double4* rec) __attribute__((always_inline)) -> D3 {
-                    double4 u;
-                    if (BOX) { const double2 uxy = reinterpret_cast<const double2*>(rec)[5]; u = {uxy.x, uxy.y, reinterpret_cast<const double*>(rec)[12], 0.0}; }
-                    else u = rec[6];
-                    v = {u.x, u.y, u.z};
-                    const D3 Pn = axpy(dt, v, S_);
+                    D3 Pn;
+                    if (VERTEX) {
+                        // (a decomposition admitted to the cone locate always yields a tet: cpf_set_tets; multiply, round, add --
+                        // what the staged advect and step_kernel_vertex do, cpf_kernels.hip particle_cycles)
+                        (void)vertex_velocity(vf, S_, cur, v);
+                        Pn = {S_.x + dt * v.x, S_.y + dt * v.y, S_.z + dt * v.z};
+                    } else {
+                        double4 u;
+                        if (BOX) { const double2 uxy = reinterpret_cast<const double2*>(rec)[5]; u = {uxy.x, uxy.y, reinterpret_cast<const double*>(rec)[12], 0.0}; }
+                        else u = rec[6];
+                        v = {u.x, u.y, u.z};
+                        Pn = axpy(dt, v, S_);
+                    }
                     D3 disp = {Pn.x - S_.x, Pn.y - S_.y, Pn.z - S_.z};           // not yet walked in this cycle: S_ is the position
                     if (BROWNIAN) {                                               // the deviates drawn in the cycle's first round
                         const D3 xi = {sE[0][lane], sE[1][lane], sE[2][lane]};
@@ -860,23 +872,47 @@ __global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LO
     if (STATS) flush_stats(st, counters, sCnt);
 }
 
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
+__global__ __launch_bounds__(64, (StreamOccupancy<BROWNIAN, STORE_VEL, STATS, LOOKUP>::waves)) void step_kernel_stream(
+    double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,   // read through kernarg_cloud_ptrs()
+    const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
+    int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa) {
+    stream_body<BROWNIAN, REFLECT, STORE_VEL, STATS, LOOKUP, false>(gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa, VertexField{});
+}
+
+// the "VertexVelocity" cycle (CPF_STEP_VERTEX_VELOCITY) on the streaming kernel: all-hex meshes, loop / fixed lookup; the tet
+// tables add ~40 vector registers to the advect: four waves per SIMD
+#ifndef CPF_STREAM_WAVES_VERTEX
+#define CPF_STREAM_WAVES_VERTEX 4
+#endif
+template <bool BROWNIAN, bool REFLECT, bool STORE_VEL, bool STATS, int LOOKUP>
+__global__ __launch_bounds__(64, ((STORE_VEL || STATS) ? 1 : CPF_STREAM_WAVES_VERTEX)) void step_kernel_stream_vertex(
+    double* __restrict__ /* x */, double* __restrict__ /* y */, double* __restrict__ /* z */, int32_t* __restrict__ /* cell */,
+    const int64_t* __restrict__ gid, double* __restrict__ vel, int64_t n, double dt, double sigma, uint32_t step0,
+    int nCyc, uint32_t seed, MeshView m, unsigned long long* __restrict__ counters, StreamArgs sa, VertexField vf) {
+    stream_body<BROWNIAN, REFLECT, STORE_VEL, STATS, LOOKUP, true>(gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa, vf);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launcher: persistent grid sized by the occupancy of the instantiation
 // ------------------------------------------------------------------------------------------------
-template <bool B, bool R_, bool SV, bool ST, int LF>
+template <bool B, bool R_, bool SV, bool ST, int LF, bool VX = false>
 static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
                                      double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc,
-                                     uint32_t seed, const MeshView& m, unsigned long long* counters, StreamState& ss) {
+                                     uint32_t seed, const MeshView& m, unsigned long long* counters, StreamState& ss,
+                                     const VertexField* vf = nullptr) {
     static int wavesPerCU = 0;                       // per instantiation; benign race (same value)
     if (wavesPerCU == 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream<B, R_, SV, ST, LF>, 64, 0);
+        hipError_t e;
+        if constexpr (VX) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream_vertex<B, R_, SV, ST, LF>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_kernel_stream<B, R_, SV, ST, LF>, 64, 0);
         if (e != hipSuccess) return e;
         wavesPerCU = nb < 1 ? 1 : (nb > 32 ? 32 : nb);
     }
     const int64_t nTiles = (n + 63) >> 6;
     if (nTiles >= ((int64_t)1 << 31)) return hipErrorInvalidValue;      // the kernel numbers tiles and chunks in 32 bits
-    const int64_t slotsOnChip = (int64_t)(ss.wavesPerCU > 0 ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
+    const int64_t slotsOnChip = (int64_t)((ss.wavesPerCU > 0 && !VX) ? ss.wavesPerCU : wavesPerCU) * ss.numCU;
     // small clouds: shorter chunks, so that every wave slot still gets several
     // dealing knobs, by lookup method unless set: few particles per cell = slower tiles (more rounds, record misses), so
     // finer chunks and a longer tile-by-tile tail (tools/sweep3d_opts.sh: 3 / 0.2 against 4 / 0.1 on the 3-D box 0.2632 /
@@ -898,6 +934,17 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     if (R * kStreamGroups > ss.hitSpillWaves) R = ss.hitSpillWaves / kStreamGroups;      // (never: the area is sized for the chip)
     if (R < 1 || ss.d_hitSpill == nullptr) return hipErrorInvalidValue;
     StreamArgs sa = {cur, nxt, (int)R, tpc, (unsigned)bigChunks, ss.debug, ss.d_hitSpill};
+    if constexpr (VX) {
+        if (vf == nullptr) return hipErrorInvalidValue;
+        if (ss.evStart != nullptr && ss.evStop != nullptr) {
+            hipExtLaunchKernelGGL((step_kernel_stream_vertex<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, ss.evStart,
+                                  ss.evStop, 0, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa, *vf);
+            ss.evStart = ss.evStop = nullptr;
+        } else
+        hipLaunchKernelGGL((step_kernel_stream_vertex<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
+                           gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa, *vf);
+        return stream_launch_done(st, ss);
+    } else {
     if (ss.evStart != nullptr && ss.evStop != nullptr) {
         hipExtLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, ss.evStart,
                               ss.evStop, 0, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
@@ -906,6 +953,7 @@ static hipError_t launch_stream_inst(hipStream_t st, double* x, double* y, doubl
     hipLaunchKernelGGL((step_kernel_stream<B, R_, SV, ST, LF>), dim3((unsigned)(R * kStreamGroups)), dim3(64), 0, st, x, y, z, cell,
                        gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, sa);
     return stream_launch_done(st, ss);
+    }
 }
 
 // few particles per cell => many distinct cells per 64-particle tile => the fixed tag compare
@@ -931,6 +979,39 @@ int stream_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss, bool
     const bool flat = !brown && ss.flat && ss.flatField && m.zSide0 != 0;
     if (n < 128 * cells) return flat ? 9 : 1;
     return flat ? 8 : 0;
+}
+
+// the "VertexVelocity" cycle streams on all-hex meshes with the loop or the fixed lookup on the 256-byte records (no flat walk:
+// the interpolated velocity may have a z component whatever the cell field says; mixed meshes keep step_kernel_vertex)
+bool stream_vertex_capable(const MeshView& m) { return m.mixed == 0 && m.cellRec != nullptr; }
+int stream_vertex_lookup_mode(int64_t n, const MeshView& m, const StreamState& ss) {
+    int64_t cells = m.nCells;
+    if (ss.densityLookup && ss.occupiedHost != nullptr) {
+        const int64_t occ = (int64_t)ss.occupiedHost[0], live = (int64_t)ss.occupiedHost[1];
+        if (occ > 0 && occ <= cells && live > 0 && live <= 2 * n && n <= 2 * live) cells = occ;
+    }
+    return n < 128 * cells ? 1 : 0;
+}
+
+hipError_t launch_step_stream_vertex(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,
+                                     double* vel, int64_t n, double dt, double sigma, uint32_t step0, int nCyc, uint32_t seed,
+                                     bool brown, bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
+                                     StreamState& ss, const VertexField& vf) {
+    const int lf = stream_vertex_lookup_mode(n, m, ss);
+#define CPF_STREAM_VGO(B, R, SV, ST)                                                                                         \
+    do {                                                                                                                     \
+        if (lf == 1) return launch_stream_inst<B, R, SV, ST, 1, true>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss, &vf);  \
+        return launch_stream_inst<B, R, SV, ST, 0, true>(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, counters, ss, &vf);               \
+    } while (0)
+#define CPF_STREAM_VSV(B, R)                                                                     \
+    do {                                                                                        \
+        if (storeVel) { if (counters) CPF_STREAM_VGO(B, R, true, true); else CPF_STREAM_VGO(B, R, true, false); } \
+        else { if (counters) CPF_STREAM_VGO(B, R, false, true); else CPF_STREAM_VGO(B, R, false, false); }        \
+    } while (0)
+    if (brown) { if (reflect) CPF_STREAM_VSV(true, true); else CPF_STREAM_VSV(true, false); }
+    else { if (reflect) CPF_STREAM_VSV(false, true); else CPF_STREAM_VSV(false, false); }
+#undef CPF_STREAM_VSV
+#undef CPF_STREAM_VGO
 }
 
 hipError_t launch_step_stream(hipStream_t st, double* x, double* y, double* z, int32_t* cell, const int64_t* gid,

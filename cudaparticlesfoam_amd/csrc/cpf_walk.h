@@ -554,6 +554,84 @@ __device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const doub
     return next;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "VertexVelocity" advect mode (cuda/particles.cu:244-313, 428-437): the velocity at P is the barycentric interpolation of
+// VERTEX velocities in a tet of the particle's cell -- the tet whose smallest barycentric weight of P is largest (the product
+// tracks cells, and the interpolant is continuous across the tets of a cell), then weighed exactly like the reference
+// (w_X = det(tet with X := P) * (1 / det(tet))).  Shared by the staged advect and the fused cycle: same bits.
+//
+// CONE LOCATE (round 6; VertexField::cone != nullptr).  Evaluating all tetsPerCell tets costs 12 x 5 determinants per particle
+// and cycle: 7.8 x the cell-constant cycle on pitzDaily (BENCH: config.vertex_velocity).  When the cell's tets are a FAN about one
+// apex -- the cell centre, src/initCuda.H:99-105 -- that covers every direction exactly once (checked on the host at
+// cpf_set_tets: shared apex, determinants of one sign, solid angles adding up to 4 pi, bounded condition), the tets' interiors
+// are disjoint.  So if ONE tet holds P with every weight above a margin far beyond the determinants' rounding errors, every
+// other tet of the cell has a negative weight in exact arithmetic -- a computed minimum of at most a rounding error -- and the
+// arg-max of the full evaluation is that tet: its weights, computed with the very same expressions, ARE the full evaluation's
+// result, bit for bit.  The candidate comes from a cheap approximate test (P - apex in the tet's cone: three dot products with
+// precomputed rows, 9 FMAs per tet); how good that guess is affects only the speed.  A particle within the margin of a tet's
+// face, edge or the apex, or outside its cell by a rounding, takes the full evaluation as before.
+struct VertexField { const double* pos; const int32_t* tets; const double* vel; int tetsPerCell; const double* cone; };
+constexpr double kVertexMargin = 1e-8;          // on barycentric weights (O(1)); the host admits meshes whose weights carry errors < 1e-10
+constexpr int kConeDoubles = 10;                // per tet: three rows of the inverse of [B-A C-A D-A] (approximate), then 1 / det (exact)
+__device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
+    const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
+    const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+    return d.x * c.x + d.y * c.y + d.z * c.z;
+}
+__device__ __forceinline__ bool vertex_velocity(const VertexField& f, const D3& Pp, int c, D3& v) {
+    auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
+    int best = -1;
+    double bestMin = 0.0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (f.cone != nullptr) {
+        const int64_t t0 = (int64_t)c * f.tetsPerCell;
+        int cand = 0;
+        // The candidate: the tet in whose cone about the apex P lies best.  The tables of ONE cell are 80 bytes a tet; the lanes of a
+        // wave of a sorted cloud mostly share their cell, and then the rows come through the scalar cache as operands of the
+        // FMAs -- one fetch per wave instead of 64 (the vector path's 5 x 16-byte loads per tet and lane are what bounded the
+        // first streaming version: 0.49 ms against 0.12 for the cell-constant cycle).  Same arithmetic either way.
+        auto pick = [&](const double* __restrict__ g0, const D3& apex, int nT) __attribute__((always_inline)) {
+            const D3 r = {Pp.x - apex.x, Pp.y - apex.y, Pp.z - apex.z};
+            double candMin = -1e300;
+            for (int k = 0; k < nT; ++k) {
+                const double2* g = reinterpret_cast<const double2*>(g0 + kConeDoubles * k);      // (80-byte rows of a 256-byte-aligned table)
+                const double2 g01 = g[0], g23 = g[1], g45 = g[2], g67 = g[3], g89 = g[4];
+                const double cb = fma(g23.x, r.z, fma(g01.y, r.y, g01.x * r.x)), cc = fma(g45.y, r.z, fma(g45.x, r.y, g23.y * r.x));
+                const double cd = fma(g89.x, r.z, fma(g67.y, r.y, g67.x * r.x));
+                const double m = fmin(cb, fmin(cc, cd));
+                if (m > candMin) { candMin = m; cand = k; }
+            }
+        };
+        const int uc = __builtin_amdgcn_readfirstlane(c);
+        if (ballot64(c != uc) == 0ull) {                        // every active lane in one cell: wave-uniform addresses
+            const int64_t u0 = (int64_t)uc * f.tetsPerCell;
+            pick(f.cone + kConeDoubles * u0, ld(f.pos, f.tets[4 * u0]), f.tetsPerCell);
+        } else pick(f.cone + kConeDoubles * t0, ld(f.pos, f.tets[4 * t0]), f.tetsPerCell);
+        const int32_t* ix = f.tets + 4 * (t0 + cand);
+        const D3 A = ld(f.pos, ix[0]), B = ld(f.pos, ix[1]), C = ld(f.pos, ix[2]), D = ld(f.pos, ix[3]);
+        const double inv = f.cone[kConeDoubles * (t0 + cand) + 9];              // 1. / det4(A, B, C, D), computed on the device
+        const double a = det4(Pp, B, C, D) * inv, b = det4(A, Pp, C, D) * inv;
+        const double cc = det4(A, B, Pp, D) * inv, d = det4(A, B, C, Pp) * inv;
+        if (fmin(fmin(a, b), fmin(cc, d)) > kVertexMargin) { best = cand; w0 = a; w1 = b; w2 = cc; w3 = d; }
+    }
+    const bool full = best < 0;                                   // no cone tables, or the candidate is not clear of its tet's boundary
+    for (int k = 0; full && k < f.tetsPerCell; ++k) {
+        const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + k);
+        const D3 A = ld(f.pos, ix[0]), B = ld(f.pos, ix[1]), C = ld(f.pos, ix[2]), D = ld(f.pos, ix[3]);
+        const double den = det4(A, B, C, D);
+        if (den == 0.0) continue;                                 // a bad tet (particles.cu:275-278) cannot hold P
+        const double a = det4(Pp, B, C, D) * (1. / den), b = det4(A, Pp, C, D) * (1. / den);
+        const double cc = det4(A, B, Pp, D) * (1. / den), d = det4(A, B, C, Pp) * (1. / den);
+        const double m = fmin(fmin(a, b), fmin(cc, d));
+        if (best < 0 || m > bestMin) { best = k; bestMin = m; w0 = a; w1 = b; w2 = cc; w3 = d; }
+    }
+    if (best < 0) return false;
+    const int32_t* ix = f.tets + 4 * ((int64_t)c * f.tetsPerCell + best);
+    const D3 vA = ld(f.vel, ix[0]), vB = ld(f.vel, ix[1]), vC = ld(f.vel, ix[2]), vD = ld(f.vel, ix[3]);
+    v = {((w0 * vA.x + w1 * vB.x) + w2 * vC.x) + w3 * vD.x, ((w0 * vA.y + w1 * vB.y) + w2 * vC.y) + w3 * vD.y,
+         ((w0 * vA.z + w1 * vB.z) + w2 * vC.z) + w3 * vD.z};
+    return true;
+}
+
 // step-kernel variants (cpf_set_option "step_variant"); all give bit-identical results
 enum { kVariantAuto = -1, kVariantGeneric = 0, kVariantFixed = 1, kVariantFixedScalar = 2, kVariantCoop = 3, kVariantStream = 4, kVariantAhead = 5 };
 

@@ -240,6 +240,11 @@ int cpf_set_seed(cpf_context* ctx, uint32_t seed);
  *   "z_fold" (1)    with the Brownian kick on a mesh that is one cell thick in z, mirror the kicked end point about the front /
  *                   back plane before the walk instead of at the hit (same trajectory, fewer cell visits; 0 = the reference's
  *                   order of operations, what the staged entry points always use)
+ *   "vertex_fast" (1) the "VertexVelocity" advect finds the particle's tet by a cone test about the cell's apex and evaluates
+ *                   that ONE tet, instead of all tetsPerCell -- the same result, bit for bit, whenever the tet holds the particle
+ *                   with a margin (else all tets, as with 0).  Only on decompositions that are fans about one apex per cell
+ *                   covering every direction once (checked at cpf_set_tets; the reference's 12 tets per hex are);
+ *                   cpf_step_kernel_name says which of the two runs
  *   "mixed_records" (1; set BEFORE cpf_set_mesh) on a mesh that is not all-hex, build cell records anyway if at most a
  *                   quarter of the cells have more than TWELVE distinct planes: cells with fewer than six get padded records,
  *                   cells with seven to twelve a second record (a visit there takes two rounds of kernel 4, both tests from
@@ -505,7 +510,8 @@ int cpf_stage_advect(cpf_context* ctx, double* particles, const int32_t* ids, do
  * d_positions / d_indices (cuda/DeviceTetMesh.cuh:59-72); cpf_set_vertex_velocity replaces d_velocities for this mode
  * (one vector per tet-mesh vertex).  ids are CELL ids: the kernel takes the tet of that cell whose smallest barycentric
  * weight of P is largest (the interpolant is continuous across the tets of a cell), then weighs exactly like the
- * reference (w_X = det(tet with X := P) * (1 / det(tet)); vel = wA*velA + wB*velB + wC*velC + wD*velD). */
+ * reference (w_X = det(tet with X := P) * (1 / det(tet)); vel = wA*velA + wB*velB + wC*velC + wD*velD).  Option
+ * "vertex_fast": that tet is found without evaluating the others where that is provably the same thing. */
 int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, const int32_t* tets, int64_t nTets,
                  int tetsPerCell);
 int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVerts);

@@ -296,7 +296,7 @@ def test_bench_runs_and_prints_one_json_line(extra):
         assert tj["mesh_flags"]["all_hex"] == 1 and tj["mesh_flags"]["z_thin"] == 0
         # what is built and had no number in the driver-run line before round 6: the VertexVelocity cycle, the non-hex mesh of configs[4]
         vv, ph = d["config"]["vertex_velocity"], d["config"]["polyhedral_as_run"]
-        assert "step_kernel_vertex<false, true, false>" in vv["kernel"] and vv["steps"] == 3 and vv["particles_after"] == 200_000
+        assert vv["kernel"] == "cpf::step_kernel_stream_vertex<false, true, false, false, 1> (cone locate)" and vv["steps"] == 3 and vv["particles_after"] == 200_000
         assert vv["tets"] == 12 * 12225 and 0 < vv["frac"] <= vv["kernel_frac"] * 1.02 < 1
         assert ph["cells"] == 114540 and ph["cells_with_9_faces"] == 2242 and ph["particles_after"] == 300_000 and ph["D"] == 1.5e-5
         assert ph["velocity_uploads"] == 2 and ph["upload_ms_each"] > 0 and ph["ms_per_step_with_uploads"] >= ph["ms_per_step"]

@@ -26,4 +26,10 @@ def test_step_kernel_resources():
     for name, r in rows.items():
         if "step_kernel_stream" in name or "step_kernel_coop" in name:
             assert int(r[4]) == 0 and int(r[7]) == 0, (name, r)            # no scratch, no VGPR spills
-    assert len([n for n in rows if "step_kernel_stream" in n]) == 144
+    assert len([n for n in rows if "step_kernel_stream<" in n]) == 144
+    # the "VertexVelocity" cycle on the streaming kernel (round 6): loop and fixed lookup only; the tet tables of its advect cost
+    # it half the occupancy (<= 128 VGPRs: 4 waves), not a byte of scratch
+    vertex = {n: r for n, r in rows.items() if "step_kernel_stream_vertex<" in n}
+    assert len(vertex) == 32 and all(n.endswith((", 0>", ", 1>")) for n in vertex)
+    v0 = vertex["void cpf::step_kernel_stream_vertex<false, true, false, false, 0>"]
+    assert int(v0[1]) <= 128 and int(v0[4]) == 0 and int(v0[8]) <= 160 * 1024 // 16, v0

@@ -204,13 +204,19 @@ def test_fused_vertex_velocity_cycle_equals_the_staged_calls(gpu_ctx_factory):
     P0 = np.ones((n, 4)); P0[:, :3] = g["xyz0"]
     sc = StagedCloud(staged_ctx, n)
     fused = []
-    for mode in ("per cycle", "fused launches", "sorted"):
+    for mode in ("per cycle", "fused launches", "sorted", "generic walk", "generic walk, all tets"):
         c = ctx_with_field()
+        if mode.startswith("generic walk"):
+            c.set_option("step_variant", 0)                    # step_kernel_vertex: one thread per particle, CSR walk
+            c.set_option("vertex_fast", 0 if mode.endswith("all tets") else 1)
         c.set_particles(g["xyz0"], cell0)
         if mode == "sorted":
             c.sort_by_cell()
         fused.append((mode, c))
-    assert "step_kernel_vertex<false, true, false>" in fused[0][1].step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY)
+    # since round 6 the cycle streams (all-hex mesh, a tet fan per cell): the streaming kernel with the interpolated advect
+    assert fused[0][1].step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY) == "cpf::step_kernel_stream_vertex<false, true, false, true, 1> (cone locate)"
+    assert fused[3][1].step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY) == "cpf::step_kernel_vertex<false, true, false> (cone locate)"
+    assert fused[4][1].step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY) == "cpf::step_kernel_vertex<false, true, false> (all tets)"
     try:
         sc.set(P0, cell0)
         done = 0
@@ -218,7 +224,7 @@ def test_fused_vertex_velocity_cycle_equals_the_staged_calls(gpu_ctx_factory):
             for _ in range(int(k) - done):
                 sc.cudaAdvect(dt, "VertexVelocity"); sc.convexTetQuery(); sc.convexWallReflect(); sc.cudaMoveParticles()
             for mode, c in fused:
-                fl = L.STEP_VERTEX_VELOCITY | (L.STEP_FUSE_CYCLES if mode == "fused launches" else 0)
+                fl = L.STEP_VERTEX_VELOCITY | (L.STEP_FUSE_CYCLES if mode in ("fused launches", "generic walk") else 0)
                 c.step(dt, 0.0, int(k) - done, fl)
                 xyzw, cell = c.get_particles()
                 assert np.array_equal(cell, sc.ids), (mode, int(k))
