@@ -79,7 +79,8 @@ struct cpf_context {
     // "VertexVelocity" advect only: the tet decomposition and one velocity per tet-mesh vertex
     double* d_tetPos = nullptr; int32_t* d_tets = nullptr; double* d_vertVel = nullptr;
     int64_t nTetVerts = 0, nTets = 0; int tetsPerCell = 0; bool haveVertVel = false;
-    double* d_vertCone = nullptr;               // cone-locate tables (cpf_kernels.hip, VertexField), if the decomposition admits them
+    double* d_vertCone = nullptr;               // cone-locate tet records (cpf_walk.h, VertexField), if the decomposition admits them
+    double* d_vertApex = nullptr;               // ... and the cells' apexes
     bool vertexFast = true;                     // cpf_set_option("vertex_fast")
     std::string vertConeWhy;                    // why the tables were not built (cpf_step_kernel_name says so)
     // asynchronous output (cpf_write_vtu_async): one frame in flight
@@ -424,7 +425,7 @@ int cpf_destroy(cpf_context* ctx) {
     freeDev(ctx->d_occupied);
     if (ctx->evFieldFlag) { (void)hipEventDestroy(ctx->evFieldFlag); ctx->evFieldFlag = nullptr; }
     if (ctx->h_occupied) { (void)hipHostFree(ctx->h_occupied); ctx->h_occupied = nullptr; ctx->streamState.occupiedHost = nullptr; }
-    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone);
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone); freeDev(ctx->d_vertApex);
     freeDev(ctx->snapDev);
     if (ctx->snapHost) { (void)hipHostFree(ctx->snapHost); ctx->snapHost = nullptr; }
     if (ctx->evSnap) (void)hipEventDestroy(ctx->evSnap);
@@ -724,7 +725,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
         const hipError_t le = vertexU
             ? cpf::launch_step_vertex(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed, reflect,
                                       storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->d_tetPos, ctx->d_tets, ctx->tetsPerCell,
-                                      ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState)
+                                      ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->d_vertApex, ctx->stepVariant, &ctx->streamState)
             : cpf::launch_step(ctx->stream, x, y, z, cell, gid, vel, n, dt, D, step0 + (uint32_t)c, cycPerLaunch, ctx->seed,
                                reflect, storeVel, m, ctx->stats ? ctx->d_counters : nullptr, ctx->stepVariant,
                                &ctx->streamState);
@@ -1237,7 +1238,7 @@ int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, cons
         CPF_REQUIRE(ctx, tets[k] >= 0 && tets[k] < nVerts, CPF_ERR_MESH, "cpf_set_tets: tet vertex out of range");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone);
+    freeDev(ctx->d_tetPos); freeDev(ctx->d_tets); freeDev(ctx->d_vertVel); freeDev(ctx->d_vertCone); freeDev(ctx->d_vertApex);
     ctx->haveVertVel = false;
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tetPos, (size_t)nVerts * 24));
     CPF_HIP(ctx, hipMalloc((void**)&ctx->d_tets, (size_t)nTets * 16));
@@ -1249,8 +1250,9 @@ int cpf_set_tets(cpf_context* ctx, const double* positions, int64_t nVerts, cons
     // the cone locate (cpf_kernels.hip, VertexField) is exact only on a decomposition whose tets cannot overlap: decided here
     ctx->vertConeWhy = tetFanDefect(positions, tets, ctx->host.nCells, tetsPerCell);
     if (ctx->vertConeWhy.empty()) {
-        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_vertCone, (size_t)nTets * 80));
-        CPF_HIP(ctx, cpf::launch_vertex_cone_tables(ctx->stream, ctx->d_tetPos, ctx->d_tets, nTets, ctx->d_vertCone));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_vertCone, (size_t)nTets * 256));
+        CPF_HIP(ctx, hipMalloc((void**)&ctx->d_vertApex, (size_t)ctx->host.nCells * 32));
+        CPF_HIP(ctx, cpf::launch_vertex_cone_tables(ctx->stream, ctx->d_tetPos, ctx->d_tets, nTets, tetsPerCell, ctx->d_vertCone, ctx->d_vertApex));
         CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return CPF_OK;
@@ -1261,6 +1263,7 @@ int cpf_set_vertex_velocity(cpf_context* ctx, const double* vertexU, int64_t nVe
     CPF_REQUIRE(ctx, nVerts == ctx->nTetVerts, CPF_ERR_ARG, "cpf_set_vertex_velocity: one velocity per tet-mesh vertex");
     CPF_HIP(ctx, hipSetDevice(ctx->device));
     CPF_HIP(ctx, hipMemcpyAsync(ctx->d_vertVel, vertexU, (size_t)nVerts * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->d_vertCone) CPF_HIP(ctx, cpf::launch_vertex_record_velocity(ctx->stream, ctx->d_tets, ctx->d_vertVel, ctx->nTets, ctx->d_vertCone));
     CPF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->haveVertVel = true;
     return CPF_OK;
@@ -1272,7 +1275,7 @@ int cpf_stage_advect_vertex(cpf_context* ctx, double* particles, const int32_t* 
                 "cpf_stage_advect_vertex: call cpf_set_tets and cpf_set_vertex_velocity (for the current mesh) first");
     CPF_REQUIRE(ctx, n == 0 || (particles && ids && vels && disps), CPF_ERR_ARG, "cpf_stage_advect_vertex: null array");
     CPF_HIP(ctx, cpf::launch_stage_advect_vertex(ctx->stream, particles, ids, vels, disps, dt, n, ctx->d_tetPos, ctx->d_tets,
-                                                 ctx->tetsPerCell, ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr));
+                                                 ctx->tetsPerCell, ctx->d_vertVel, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->d_vertApex));
     return CPF_OK;
 }
 int cpf_stage_brownian(cpf_context* ctx, const double* particles, double* disps, double dt, int64_t n, double D,

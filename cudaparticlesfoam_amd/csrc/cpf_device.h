@@ -92,7 +92,7 @@ hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, i
                               double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                               bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
                               const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel, const double* cone,
-                              int variant, StreamState* ss);
+                              const double* apex, int variant, StreamState* ss);
 // does launch_step_vertex stream (step_kernel_stream_vertex) or run step_kernel_vertex, for these arguments?
 bool step_vertex_streams(const MeshView& m, const double* cone, int variant, const StreamState* ss, int nCyc);
 struct VertexField;                  // cpf_walk.h
@@ -131,9 +131,12 @@ hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* i
                                      int64_t n);
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                       int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
-                                      const double* vertVel, const double* cone);
-// cone-locate tables of the "VertexVelocity" advect: cone[nTets][10] (cpf_kernels.hip, VertexField)
-hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, double* cone);
+                                      const double* vertVel, const double* cone, const double* apex);
+// tet records of the "VertexVelocity" advect's cone locate: cone[nTets][32], apex[nCells][4] (cpf_walk.h, VertexField); the
+// velocity part of the records follows every cpf_set_vertex_velocity
+hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, int tetsPerCell, double* cone,
+                                     double* apex);
+hipError_t launch_vertex_record_velocity(hipStream_t st, const int32_t* tets, const double* vel, int64_t nTets, double* cone);
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,
                                  uint32_t step, uint32_t seed);
 hipError_t launch_stage_locate(hipStream_t st, const double* P, const double* disps, int32_t* ids, int64_t n,

@@ -478,12 +478,12 @@ hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, i
                               double* vel, int64_t n, double dt, double D, uint32_t step0, int nCyc, uint32_t seed,
                               bool reflect, bool storeVel, const MeshView& m, unsigned long long* counters,
                               const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel, const double* cone,
-                              int variant, StreamState* ss) {
+                              const double* apex, int variant, StreamState* ss) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
-    const VertexField vf{pos, tets, vertVel, tetsPerCell, cone};
+    const VertexField vf{pos, tets, vertVel, tetsPerCell, cone, reinterpret_cast<const double4*>(apex)};
     if (step_vertex_streams(m, cone, variant, ss, nCyc))
         return launch_step_stream_vertex(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m, counters, *ss, vf);
 #define CPF_VTX(B, R, SV) hipLaunchKernelGGL((step_kernel_vertex<B, R, SV>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, vf, counters)
@@ -660,17 +660,18 @@ hipError_t launch_stage_advect_const(hipStream_t st, double* P, const int32_t* i
 }
 hipError_t launch_stage_advect_vertex(hipStream_t st, double* P, const int32_t* ids, double* vels, double* disps, double dt,
                                       int64_t n, const double* pos, const int32_t* tets, int tetsPerCell,
-                                      const double* vertVel, const double* cone) {
+                                      const double* vertVel, const double* cone, const double* apex) {
     if (n > 0)
         hipLaunchKernelGGL(stage_advect_vertex_kernel, grid_of(n), dim3(kBlock), 0, st, (double4*)P, ids, (double4*)vels,
-                           (double4*)disps, dt, n, VertexField{pos, tets, vertVel, tetsPerCell, cone});
+                           (double4*)disps, dt, n, VertexField{pos, tets, vertVel, tetsPerCell, cone, reinterpret_cast<const double4*>(apex)});
     return hipGetLastError();
 }
 
 // the cone-locate tables of the "VertexVelocity" advect (see VertexField): per tet the rows of the inverse of [B-A C-A D-A] --
 // (B-A, C-A, D-A) coordinates of P - A, a guess only -- and 1 / det4(A, B, C, D) by the expressions vertex_velocity() itself uses
 __global__ __launch_bounds__(kBlock) void vertex_cone_tables_kernel(const double* __restrict__ pos, const int32_t* __restrict__ tets,
-                                                                    int64_t nTets, double* __restrict__ cone) {
+                                                                    int64_t nTets, int tetsPerCell, double* __restrict__ cone,
+                                                                    double4* __restrict__ apex) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= nTets) return;
     auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
@@ -688,9 +689,28 @@ __global__ __launch_bounds__(kBlock) void vertex_cone_tables_kernel(const double
     g[3] = db.x * s; g[4] = db.y * s; g[5] = db.z * s;
     g[6] = bc.x * s; g[7] = bc.y * s; g[8] = bc.z * s;
     g[9] = den == 0.0 ? 0.0 : 1. / den;        // (a mesh with a flat tet is not admitted to the cone locate: cpf_set_tets)
+    g[10] = B.x; g[11] = B.y; g[12] = B.z; g[13] = C.x; g[14] = C.y; g[15] = C.z; g[16] = D.x; g[17] = D.y; g[18] = D.z;
+    g[31] = 0.0;
+    if (t % tetsPerCell == 0) apex[t / tetsPerCell] = make_double4(A.x, A.y, A.z, 0.0);
 }
-hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, double* cone) {
-    if (nTets > 0) hipLaunchKernelGGL(vertex_cone_tables_kernel, grid_of(nTets), dim3(kBlock), 0, st, pos, tets, nTets, cone);
+// the velocity part of the tet records: [19..30] = the velocities of the tet's four vertices (every cpf_set_vertex_velocity)
+__global__ __launch_bounds__(kBlock) void vertex_record_velocity_kernel(const int32_t* __restrict__ tets, const double* __restrict__ vel,
+                                                                        int64_t nTets, double* __restrict__ cone) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 4 * nTets) return;
+    const int64_t t = i >> 2;
+    const int k = (int)(i & 3);
+    const int64_t vtx = tets[i];
+    double* g = cone + kConeDoubles * t + 19 + 3 * k;
+    g[0] = vel[3 * vtx]; g[1] = vel[3 * vtx + 1]; g[2] = vel[3 * vtx + 2];
+}
+hipError_t launch_vertex_cone_tables(hipStream_t st, const double* pos, const int32_t* tets, int64_t nTets, int tetsPerCell, double* cone,
+                                     double* apex) {
+    if (nTets > 0) hipLaunchKernelGGL(vertex_cone_tables_kernel, grid_of(nTets), dim3(kBlock), 0, st, pos, tets, nTets, tetsPerCell, cone, (double4*)apex);
+    return hipGetLastError();
+}
+hipError_t launch_vertex_record_velocity(hipStream_t st, const int32_t* tets, const double* vel, int64_t nTets, double* cone) {
+    if (nTets > 0) hipLaunchKernelGGL(vertex_record_velocity_kernel, grid_of(4 * nTets), dim3(kBlock), 0, st, tets, vel, nTets, cone);
     return hipGetLastError();
 }
 hipError_t launch_stage_brownian(hipStream_t st, const double* P, double* disps, double dt, int64_t n, double D,

@@ -70,6 +70,8 @@ constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a
 #ifndef CPF_STREAM_HIT_POOL
 #define CPF_STREAM_HIT_POOL 40
 #endif
+constexpr int kVertexTets = 12;        // the decomposition the staged locate knows (src/initCuda.H:64: 12 tets per hex); others: per lane
+constexpr int kVertexBlocks = 3;       // distinct cells staged per pass
 constexpr int kStreamSparsePerCell = 8;                      // fewer particles per cell than this: the sparse instantiation (LOOKUP 4)
 constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
@@ -104,6 +106,10 @@ constexpr int kKernArgStep0 = (int)offsetof(StreamKernArgs, step0), kKernArgSeed
 // the zero-denominator vote per face in the flat walk: off -- a 2-D mesh whose side faces are exactly parallel to everybody's
 // displacement is a mesh of boxes in axis-aligned flow; pitzDaily's trapezoids never are, and the vote costs the headline 2.3 %
 // (0.1048-0.1063 -> 0.1032-0.1033 ms, analytic field 0.0986-0.0999 -> 0.0985-0.0986).  Same results either way.
+// the flat walk under the Brownian kick (cpf_walk.h, trace_lds4_flat_z): 0 = off (A/B builds)
+#ifndef CPF_STREAM_FLAT_KICK
+#define CPF_STREAM_FLAT_KICK 0
+#endif
 #ifndef CPF_STREAM_FLAT_ZERO_SKIP
 #define CPF_STREAM_FLAT_ZERO_SKIP 0
 #endif
@@ -190,6 +196,8 @@ __device__ __forceinline__ void stream_body(
     __shared__ unsigned sPoolUsed;
     // landing zone of the next tile: x[64] | y[64] | z[64] | cell[64] (int32) | gid[64] (Brownian only)
     __shared__ double sPre[BROWNIAN ? 288 : 224];
+    // (VERTEX) the cone rows + 1/det of the 12 tets of up to three cells: 80 bytes a tet, staged once per cycle and distinct cell of the wave
+    __shared__ double sCone[VERTEX ? kVertexBlocks : 1][VERTEX ? kVertexTets * 10 : 1];
     double(*sE)[64] = sLane;
     const int lane = threadIdx.x;
     const unsigned ul = threadIdx.x;                 // unsigned lane index: scalar base + 32-bit lane offset addressing
@@ -218,6 +226,9 @@ __device__ __forceinline__ void stream_body(
     constexpr int kGatherAhead = LOOKUP == 4 ? 3 : 0;
     const bool zFold = !BOX && BROWNIAN && REFLECT && m.zThin != 0;      // (stream_lookup_mode: no box records on a mesh one cell thick)
     const bool zLast = !FLAT && !BROWNIAN && m.zPairLast != 0;   // (with the kick every particle moves in z: the test would be wasted)
+    // the kick on a one-cell-thick mesh whose side faces have nz == 0 exactly: the four side faces with two-term dot products
+    // whenever every lane's mirrored end point is clear of the z planes (cpf_walk.h, trace_lds4_flat_z)
+    const bool flatKick = zFold && m.zSide0 != 0;
     // tile and chunk numbers are 32-bit (the launcher refuses clouds of 2^31 tiles = 1.4e11 particles): half the scalar
     // registers and none of the 64-bit multiply sequences of the first version.  Chunk numbers past the end of the cloud
     // (a group's counter keeps counting) saturate instead of wrapping.
@@ -427,6 +438,67 @@ __device__ __forceinline__ void stream_body(
                 if (!HIT_IN_REGS && REFLECT) { hitAt = -1; if (lane == 0) sPoolUsed = 0u; }
                 zUnclear = false;
                 if (STATS && busy) ++st.steps;
+                if (VERTEX) {
+                    // ---- the cycle's velocities, HERE where the wave is whole: the interpolated velocity depends on the position
+                    // and the cell the particle begins the cycle with, nothing else.  The distinct cells of the wave (a sorted
+                    // cloud: one to three) get an LDS block each, three per pass; the lanes fetch the blocks' cone rows together
+                    // -- lane l the l-th 16 bytes of each, ONE L2 round trip for all tets of all three cells instead of one per
+                    // tet and lane --, every lane picks its tet from its cell's block (broadcast reads) and evaluates that ONE
+                    // tet's record.  vertex_velocity() (cpf_walk.h) states the rule and takes the lanes the shortcut does not
+                    // cover, and every lane of a decomposition that is not twelve tets a cell.  (The first streaming version
+                    // called it per lane in the advect: twelve dependent round trips per particle, 0.50 ms against the
+                    // cell-constant cycle's 0.11; one cell per pass with the pick inside: 0.40.)
+                    bool slow = busy;
+#if defined(CPF_VERTEX_AB) && CPF_VERTEX_AB == 1        // A/B builds only (WRONG results): nothing of the interpolation, the cell's own U
+                    if (busy) { const double4 u = m.U[cur]; v = {u.x, u.y, u.z}; slow = false; }
+#endif
+                    if (vf.tetsPerCell == kVertexTets) {
+                        unsigned long long todo = ballot64(slow);
+                        while (todo != 0ull) {
+                            int myBlock = -1;
+                            __syncthreads();                                   // (one wave: orders the LDS traffic of two passes)
+#pragma unroll
+                            for (int q = 0; q < kVertexBlocks; ++q) {
+                                if (todo != 0ull) {
+                                    const int ck = __builtin_amdgcn_readlane(cur, __ffsll((long long)todo) - 1);
+                                    const bool mine = slow && cur == ck;
+                                    if (mine) myBlock = q;
+                                    if (lane < 5 * kVertexTets) {
+                                        const int tk = lane / 5, piece = lane - 5 * tk;
+                                        const double2 row = reinterpret_cast<const double2*>(vf.cone + kConeDoubles * ((int64_t)ck * kVertexTets + tk))[piece];
+                                        reinterpret_cast<double2*>(&sCone[q][0] + 10 * tk)[piece] = row;
+                                    }
+                                    todo &= ~ballot64(mine);
+                                }
+                            }
+                            __syncthreads();
+                            if (myBlock >= 0) {
+                                const double4 ap = vf.apex[cur];
+                                const D3 A = {ap.x, ap.y, ap.z};
+                                const D3 r = {S_.x - A.x, S_.y - A.y, S_.z - A.z};
+                                int cand = 0;
+                                double candMin = -1e300;
+                                const double* blk = &sCone[myBlock][0];
+#pragma unroll 4
+                                for (int k = 0; k < kVertexTets; ++k) {
+                                    const double2* g = reinterpret_cast<const double2*>(blk + 10 * k);
+                                    const double2 g01 = g[0], g23 = g[1], g45 = g[2], g67 = g[3], g89 = g[4];
+                                    const double cb = fma(g23.x, r.z, fma(g01.y, r.y, g01.x * r.x)), cc = fma(g45.y, r.z, fma(g45.x, r.y, g23.y * r.x));
+                                    const double cd = fma(g89.x, r.z, fma(g67.y, r.y, g67.x * r.x));
+                                    const double mm = fmin(cb, fmin(cc, cd));
+                                    if (mm > candMin) { candMin = mm; cand = k; }
+                                }
+#if defined(CPF_VERTEX_AB) && CPF_VERTEX_AB == 2        // A/B builds only (WRONG results): staging + pick, no evaluation; the cell's own U moves the particle
+                                { const double4 u = m.U[cur]; v = {u.x + 1e-300 * cand, u.y, u.z}; slow = false; }
+#else
+                                D3 vv;
+                                if (vertex_velocity_in_tet(vf, S_, A, (int64_t)cur * kVertexTets + cand, vv)) { v = vv; slow = false; }
+#endif
+                            }
+                        }
+                    }
+                    if (slow) (void)vertex_velocity(vf, S_, cur, v);           // within the margin of a tet's boundary: all tets, as ever
+                }
             };
 
             auto round = [&](bool hookDue, bool cycleStart, int c) __attribute__((always_inline)) {
@@ -575,7 +647,7 @@ __device__ __forceinline__ void stream_body(
                     if (VERTEX) {
                         // (a decomposition admitted to the cone locate always yields a tet: cpf_set_tets; multiply, round, add --
                         // what the staged advect and step_kernel_vertex do, cpf_kernels.hip particle_cycles)
-                        (void)vertex_velocity(vf, S_, cur, v);
+                        // (v: interpolated at the cycle's start, cycle_begin)
                         Pn = {S_.x + dt * v.x, S_.y + dt * v.y, S_.z + dt * v.z};
                     } else {
                         double4 u;
@@ -655,6 +727,8 @@ __device__ __forceinline__ void stream_body(
                             // zero denominators)
                             if (BOX) next = trace_box<!BROWNIAN, mixed>(S_, E, cur, rec, token, outSlot);
                             else if (FLAT) next = trace_lds4_flat<(CPF_STREAM_FLAT_ZERO_SKIP != 0)>(S_, E, cur, rec, token, outSlot);
+                            else if (CPF_STREAM_FLAT_KICK && BROWNIAN && !mixed && flatKick && !zUnclear)
+                            next = trace_lds4_flat_z<false>(S_, E, cur, rec, token, outSlot);     // (cpf_walk.h: flat walk under the kick)
                             else
                             next = (CPF_STREAM_PAIRED && LOOKUP_FIXED && !BROWNIAN && !mixed) ? trace_lds6_paired(S_, E, cur, rec, token, outSlot, zLast)
                                                                 : trace_lds6<(!BROWNIAN && (CPF_STREAM_L1_ZERO_SKIP || LOOKUP != 1)), mixed>(S_, E, cur, rec, token, outSlot, zLast, zFold && !zUnclear);

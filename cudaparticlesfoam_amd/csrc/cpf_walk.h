@@ -359,6 +359,40 @@ __device__ __forceinline__ int trace_lds4_flat(D3& S, const D3& E, int cur, cons
     return next;
 }
 
+// FLAT WALK UNDER THE KICK (round 6).  With the Brownian kick every particle moves in z, so the flat walk above does not apply --
+// but on a one-cell-thick mesh whose side faces have nz == 0 exactly (zThin && zSide0), once fold_z has mirrored every lane's end
+// point clear of the z planes (`zFold && !zUnclear`: the condition that already drops the z pair from trace_lds6), the four
+// side faces are all that is tested, and their dropped terms are 0 * finite: den = fma(0, Pd.z, t) = t and fd = fma(-0, P0.z, u)
+// = u up to the sign of a zero, which no comparison sees (E.z and P0.z are finite: a lane with a NaN or infinite end point is
+// never `clear`).  The exit point keeps its z: S = P0 + dT * Pd with the real Pd.z.  Same bits as trace_lds6(..., zNever = true).
+template <bool ZERO_SKIP>
+__device__ __forceinline__ int trace_lds4_flat_z(D3& S, const D3& E, int cur, const double4* rec, int token, int& outSlot) {
+    const D3 P0 = S;
+    const D3 Pd = {E.x - P0.x, E.y - P0.y, E.z - P0.z};
+    int next = cur, best = -1;
+    double dTmin = 2.0;
+    const int2* nb = reinterpret_cast<const int2*>(rec + 7);
+    {
+        double4 p0 = rec[0], p1 = rec[1];
+        const int2 b = nb[0];
+        CPF_PIN_W(p0, p1)
+        face_test_flat<ZERO_SKIP>(p0, b.x, P0, Pd, token, 0, dTmin, next, best);
+        face_test_flat<ZERO_SKIP>(p1, b.y, P0, Pd, token, 1, dTmin, next, best);
+    }
+    {
+        double4 p2 = rec[2], p3 = rec[3];
+        const int2 b = nb[1];
+        CPF_PIN_W(p2, p3)
+        face_test_flat<ZERO_SKIP>(p2, b.x, P0, Pd, token, 2, dTmin, next, best);
+        face_test_flat<ZERO_SKIP>(p3, b.y, P0, Pd, token, 3, dTmin, next, best);
+    }
+    if (best >= 0) {
+        S = axpy(dTmin, Pd, P0);
+        outSlot = best;
+    }
+    return next;
+}
+
 // The same six face tests, two faces per wave-uniform decision: both denominators and both plane distances are computed
 // up front (four independent FMA chains instead of two short ones between branches), then ONE test decides whether either
 // face has a candidate lane.  No zero-denominator skip: a lane with den == 0 is a candidate only with fd >= 0, and is then
@@ -570,13 +604,35 @@ __device__ __forceinline__ int trace_csr(D3& S, const D3& E, int cur, const doub
 // result, bit for bit.  The candidate comes from a cheap approximate test (P - apex in the tet's cone: three dot products with
 // precomputed rows, 9 FMAs per tet); how good that guess is affects only the speed.  A particle within the margin of a tet's
 // face, edge or the apex, or outside its cell by a rounding, takes the full evaluation as before.
-struct VertexField { const double* pos; const int32_t* tets; const double* vel; int tetsPerCell; const double* cone; };
+// cone: one 256-byte RECORD per tet, everything the cone locate needs of it behind one address -- [0..8] the rows of the
+// inverse of [B-A C-A D-A] (approximate: the guess), [9] 1 / det4(A, B, C, D) (exact, computed by the same expressions on the
+// device), [10..18] B, C, D, [19..30] the velocities of A, B, C, D (rewritten by cpf_set_vertex_velocity), [31] spare; apex: the
+// cells' shared vertex A, one double4 per cell.  A particle's advect is two dependent fetches -- the rows of its cell's tets,
+// then the rest of ONE record -- where the index-chasing form (tet -> vertex ids -> positions -> velocities) was five.
+struct VertexField { const double* pos; const int32_t* tets; const double* vel; int tetsPerCell; const double* cone; const double4* apex; };
 constexpr double kVertexMargin = 1e-8;          // on barycentric weights (O(1)); the host admits meshes whose weights carry errors < 1e-10
-constexpr int kConeDoubles = 10;                // per tet: three rows of the inverse of [B-A C-A D-A] (approximate), then 1 / det (exact)
+constexpr int kConeDoubles = 32;                // doubles per tet record (VertexField::cone)
 __device__ __forceinline__ double det4(const D3& A, const D3& B, const D3& C, const D3& D) {
     const D3 a = {B.x - A.x, B.y - A.y, B.z - A.z}, b = {C.x - A.x, C.y - A.y, C.z - A.z}, d = {D.x - A.x, D.y - A.y, D.z - A.z};
     const D3 c = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
     return d.x * c.x + d.y * c.y + d.z * c.z;
+}
+// ONE tet of the cone locate: the reference's weights of P in tet `t` (record f.cone[t], apex A) and, if every weight clears the
+// margin, the interpolated velocity -- exactly what the evaluation of all tets returns then (see above)
+__device__ __forceinline__ bool vertex_velocity_in_tet(const VertexField& f, const D3& Pp, const D3& A, int64_t t, D3& v) {
+    const double2* R = reinterpret_cast<const double2*>(f.cone + kConeDoubles * t);
+    const double2 q4 = R[4], q5 = R[5], q6 = R[6], q7 = R[7], q8 = R[8], q9 = R[9];
+    const double2 q10 = R[10], q11 = R[11], q12 = R[12], q13 = R[13], q14 = R[14], q15 = R[15];
+    const double inv = q4.y;                                                     // 1. / det4(A, B, C, D), computed on the device
+    const D3 B = {q5.x, q5.y, q6.x}, C = {q6.y, q7.x, q7.y}, D = {q8.x, q8.y, q9.x};
+    const double a = det4(Pp, B, C, D) * inv, b = det4(A, Pp, C, D) * inv;
+    const double cc = det4(A, B, Pp, D) * inv, d = det4(A, B, C, Pp) * inv;
+    if (!(fmin(fmin(a, b), fmin(cc, d)) > kVertexMargin)) return false;
+    // P is well inside this tet: no other tet of the fan can win; its vertex velocities ride in the record
+    const D3 vA = {q9.y, q10.x, q10.y}, vB = {q11.x, q11.y, q12.x}, vC = {q12.y, q13.x, q13.y}, vD = {q14.x, q14.y, q15.x};
+    v = {((a * vA.x + b * vB.x) + cc * vC.x) + d * vD.x, ((a * vA.y + b * vB.y) + cc * vC.y) + d * vD.y,
+         ((a * vA.z + b * vB.z) + cc * vC.z) + d * vD.z};
+    return true;
 }
 __device__ __forceinline__ bool vertex_velocity(const VertexField& f, const D3& Pp, int c, D3& v) {
     auto ld = [](const double* a, int k) { return D3{a[3 * (int64_t)k], a[3 * (int64_t)k + 1], a[3 * (int64_t)k + 2]}; };
@@ -585,33 +641,22 @@ __device__ __forceinline__ bool vertex_velocity(const VertexField& f, const D3& 
     if (f.cone != nullptr) {
         const int64_t t0 = (int64_t)c * f.tetsPerCell;
         int cand = 0;
-        // The candidate: the tet in whose cone about the apex P lies best.  The tables of ONE cell are 80 bytes a tet; the lanes of a
-        // wave of a sorted cloud mostly share their cell, and then the rows come through the scalar cache as operands of the
-        // FMAs -- one fetch per wave instead of 64 (the vector path's 5 x 16-byte loads per tet and lane are what bounded the
-        // first streaming version: 0.49 ms against 0.12 for the cell-constant cycle).  Same arithmetic either way.
-        auto pick = [&](const double* __restrict__ g0, const D3& apex, int nT) __attribute__((always_inline)) {
-            const D3 r = {Pp.x - apex.x, Pp.y - apex.y, Pp.z - apex.z};
-            double candMin = -1e300;
-            for (int k = 0; k < nT; ++k) {
-                const double2* g = reinterpret_cast<const double2*>(g0 + kConeDoubles * k);      // (80-byte rows of a 256-byte-aligned table)
-                const double2 g01 = g[0], g23 = g[1], g45 = g[2], g67 = g[3], g89 = g[4];
-                const double cb = fma(g23.x, r.z, fma(g01.y, r.y, g01.x * r.x)), cc = fma(g45.y, r.z, fma(g45.x, r.y, g23.y * r.x));
-                const double cd = fma(g89.x, r.z, fma(g67.y, r.y, g67.x * r.x));
-                const double m = fmin(cb, fmin(cc, cd));
-                if (m > candMin) { candMin = m; cand = k; }
-            }
-        };
-        const int uc = __builtin_amdgcn_readfirstlane(c);
-        if (ballot64(c != uc) == 0ull) {                        // every active lane in one cell: wave-uniform addresses
-            const int64_t u0 = (int64_t)uc * f.tetsPerCell;
-            pick(f.cone + kConeDoubles * u0, ld(f.pos, f.tets[4 * u0]), f.tetsPerCell);
-        } else pick(f.cone + kConeDoubles * t0, ld(f.pos, f.tets[4 * t0]), f.tetsPerCell);
-        const int32_t* ix = f.tets + 4 * (t0 + cand);
-        const D3 A = ld(f.pos, ix[0]), B = ld(f.pos, ix[1]), C = ld(f.pos, ix[2]), D = ld(f.pos, ix[3]);
-        const double inv = f.cone[kConeDoubles * (t0 + cand) + 9];              // 1. / det4(A, B, C, D), computed on the device
-        const double a = det4(Pp, B, C, D) * inv, b = det4(A, Pp, C, D) * inv;
-        const double cc = det4(A, B, Pp, D) * inv, d = det4(A, B, C, Pp) * inv;
-        if (fmin(fmin(a, b), fmin(cc, d)) > kVertexMargin) { best = cand; w0 = a; w1 = b; w2 = cc; w3 = d; }
+        // the candidate: the tet in whose cone about the apex P lies best (per-lane reads of the records' first 72 bytes; the
+        // streaming kernel stages them in LDS once per cell instead: cpf_stream.hip, cycle_begin)
+        const double4 ap = f.apex[c];
+        const D3 A = {ap.x, ap.y, ap.z};
+        const D3 r = {Pp.x - A.x, Pp.y - A.y, Pp.z - A.z};
+        double candMin = -1e300;
+#pragma unroll 4
+        for (int k = 0; k < f.tetsPerCell; ++k) {
+            const double2* g = reinterpret_cast<const double2*>(f.cone + kConeDoubles * (t0 + k));
+            const double2 g01 = g[0], g23 = g[1], g45 = g[2], g67 = g[3], g89 = g[4];
+            const double cb = fma(g23.x, r.z, fma(g01.y, r.y, g01.x * r.x)), cc = fma(g45.y, r.z, fma(g45.x, r.y, g23.y * r.x));
+            const double cd = fma(g89.x, r.z, fma(g67.y, r.y, g67.x * r.x));
+            const double m = fmin(cb, fmin(cc, cd));
+            if (m > candMin) { candMin = m; cand = k; }
+        }
+        if (vertex_velocity_in_tet(f, Pp, A, t0 + cand, v)) return true;
     }
     const bool full = best < 0;                                   // no cone tables, or the candidate is not clear of its tet's boundary
     for (int k = 0; full && k < f.tetsPerCell; ++k) {

@@ -32,4 +32,4 @@ def test_step_kernel_resources():
     vertex = {n: r for n, r in rows.items() if "step_kernel_stream_vertex<" in n}
     assert len(vertex) == 32 and all(n.endswith((", 0>", ", 1>")) for n in vertex)
     v0 = vertex["void cpf::step_kernel_stream_vertex<false, true, false, false, 0>"]
-    assert int(v0[1]) <= 128 and int(v0[4]) == 0 and int(v0[8]) <= 160 * 1024 // 16, v0
+    assert int(v0[1]) <= 128 and int(v0[4]) == 0 and int(v0[8]) <= 160 * 1024 // 16, v0       # (LDS: + three cells' cone rows)

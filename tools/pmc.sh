@@ -40,4 +40,4 @@ d = json.load(open("gpurun_out/%s_summary.json" % sys.argv[1]))
 for k in d.get("step_kernels", []):
     print(k["kernel"][:70], "calls", k["calls"], "avg_us", round(k["avg_us"], 2), "hbm_MB", round((k.get("hbm_bytes_per_launch") or 0) / 1e6, 1))
 PY
-find "$OUT" -name "*.csv" -size +1M -delete
+find "$OUT" -name "*.csv" -size +4M -delete
