@@ -49,9 +49,10 @@ def parse(argv=None):
                     help="N>1: hand-off with FIXED cell ranges every that many steps (0 = only inside the re-cuts)")
     ap.add_argument("--rebalance-interval", type=int, default=-1,
                     help="N>1: re-cut the cell ranges to equal cost + hand-off every that many steps, COUNTED FROM THE FIRST TIMED "
-                         "STEP; -1 (default) = max(2, min(32, steps // 4)): whatever --steps is, the timed region holds at least "
-                         "two re-cuts + all-to-all-v hand-offs, the first of them overlapped with the step loop and completed "
-                         "inside the clock (with --steps 20: every 5 steps, four hand-offs)")
+                         "STEP; -1 (default) = max(2, min(32, steps // 2)): the fragments' production cadence (32) where the timed "
+                         "region is long enough for two of those, else as close to it as keeps TWO re-cuts + all-to-all-v hand-offs "
+                         "inside the clock whatever --steps is -- the first overlapped with the step loop and completed inside it, "
+                         "the second completed by the flush before the clock stops (with --steps 20: after timed steps 10 and 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", choices=["time", "count"], default="time",
                     help="N>1: re-cut the ranges to equal MEASURED step time per rank (default) or equal particle counts")
@@ -135,7 +136,7 @@ def parse(argv=None):
         a.particles = 1e7 if (a.gpus == 1 or a.scaling == "weak") else 1e8
     a.rebalance_interval_auto = a.rebalance_interval < 0
     if a.rebalance_interval_auto:
-        a.rebalance_interval = max(2, min(32, a.steps // 4))
+        a.rebalance_interval = max(2, min(32, a.steps // 2))
     return a
 
 

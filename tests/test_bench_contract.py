@@ -91,20 +91,20 @@ def _gloo_world_2(extra, timeout=900):
 def test_the_drivers_own_arguments_put_handoffs_inside_the_timed_region():
     """The driver runs N > 1 as `bench.py --gpus N --steps 20 --warmup 5` and NOTHING else.  With those arguments the timed region
     must hold re-cuts + all-to-all-v hand-offs (round-5 verdict: the old default, every 32 steps counted from step 0, put none
-    into 25 steps).  The default cadence is max(2, min(32, steps // 4)) = 5 counted from the first timed step: hand-offs after
-    timed steps 5, 10, 15, 20."""
+    into 25 steps).  The default cadence is max(2, min(32, steps // 2)) = 10 counted from the first timed step: hand-offs after
+    timed steps 10 and 20 (production cadence: 32, what a longer region gets)."""
     sys.path.insert(0, ROOT)
     import bench
     a = bench.parse(["--gpus", "8", "--steps", "20", "--warmup", "5"])
-    assert a.rebalance_interval == 5 and a.rebalance_interval_auto and a.exchange_interval == 0
-    assert bench.parse(["--gpus", "8"]).rebalance_interval == 25                    # bench.py's own default --steps 100
+    assert a.rebalance_interval == 10 and a.rebalance_interval_auto and a.exchange_interval == 0
+    assert bench.parse(["--gpus", "8"]).rebalance_interval == 32                    # bench.py's own default --steps 100: the production cadence
     assert bench.parse(["--gpus", "2", "--steps", "3"]).rebalance_interval == 2     # never rarer than the region is long
     r, lines = _gloo_world_2(["--particles", "4000", "--steps", "20", "--warmup", "5"])       # (the cloud is the only thing scaled down)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert len(lines) == 1
     d = _check(lines[0], need_cpu_baseline=False, scaling="strong")
     c = d["config"]
-    assert d["steps"] == 20 and d["warmup"] == 5 and c["rebalance_interval"] == 5 and c["rccl_ranks"] == 2
+    assert d["steps"] == 20 and d["warmup"] == 5 and c["rebalance_interval"] == 10 and c["rccl_ranks"] == 2
     assert c["ms_in_handoff"]["handoffs"] >= 2 and c["handoff_fraction_per_step"] > 0
     assert c["particles_total"] == 4000 and c["particles_after"] == 4000
 
@@ -237,7 +237,7 @@ def test_dry_collectives_on_a_one_rank_rccl_group():
 @pytest.mark.gpu
 def test_the_drivers_arguments_on_a_one_rank_rccl_group_hold_handoffs():
     """`--steps 20 --warmup 5` and no cadence flag, as the driver calls N > 1, on a real RCCL communicator of one rank: the timed
-    region holds >= 2 re-cuts + all-to-all-v's (default cadence 5, counted from the first timed step)."""
+    region holds >= 2 re-cuts + all-to-all-v's (default cadence 10, counted from the first timed step)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e5", "--steps", "20", "--warmup", "5", "--force-dist",
            "--no-cpu-baseline"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
@@ -247,7 +247,7 @@ def test_the_drivers_arguments_on_a_one_rank_rccl_group_hold_handoffs():
     assert len(lines) == 1
     d = _check(lines[0], need_cpu_baseline=False)
     c = d["config"]
-    assert c["rebalance_interval"] == 5 and c["rccl_ranks"] == 1 and c["ms_in_handoff"]["handoffs"] >= 2
+    assert c["rebalance_interval"] == 10 and c["rccl_ranks"] == 1 and c["ms_in_handoff"]["handoffs"] >= 2
     assert c["ms_in_handoff"]["collectives_device_ms_total"] > 0 and c["particles_after"] == 200_000
 
 
