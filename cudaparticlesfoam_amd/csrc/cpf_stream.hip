@@ -140,12 +140,16 @@ constexpr int kKernArgStep0 = (int)offsetof(StreamKernArgs, step0), kKernArgSeed
 #ifndef CPF_STREAM_HIT_POOL_B0
 #define CPF_STREAM_HIT_POOL_B0 18
 #endif
+// the flat walk with the loop lookup (the headline): 54 VGPRs / 84 SGPRs / 4864 B would allow an eighth wave (A/B: CPF_STREAM_WAVES_FLAT)
+#ifndef CPF_STREAM_WAVES_FLAT
+#define CPF_STREAM_WAVES_FLAT CPF_STREAM_WAVES
+#endif
 template <bool BROWNIAN, bool STORE_VEL, bool STATS, int LOOKUP>
 // LOOKUP 2 / 3 (mixed records): one wave less; LOOKUP 4 (sparse clouds: pipelined per-lane gathers, 24 more registers): 5
 struct StreamOccupancy {
     static constexpr bool kMixed = LOOKUP == 2 || LOOKUP == 3 || LOOKUP == 5 || LOOKUP == 11;
     // (LOOKUP 2 carries the state of a half-done visit of a two-record cell: 80 registers, exactly what 6 waves allow)
-    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : CPF_STREAM_WAVES_B0))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : CPF_STREAM_WAVES)))));
+    static constexpr int waves = (STORE_VEL || STATS) ? 1 : (LOOKUP == 4 ? (BROWNIAN ? 4 : 5) : (BROWNIAN ? (kMixed ? 5 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX_B : (LOOKUP == 1 ? CPF_STREAM_WAVES_B1 : CPF_STREAM_WAVES_B0))) : (LOOKUP == 2 ? CPF_STREAM_WAVES_L2 : ((kMixed && LOOKUP != 11) ? 6 : ((LOOKUP == 6 || LOOKUP == 11) ? CPF_STREAM_WAVES_BOX : (LOOKUP == 8 ? CPF_STREAM_WAVES_FLAT : CPF_STREAM_WAVES))))));
 };
 
 // The kernel's body.  VERTEX: the advect takes the velocity INTERPOLATED at the particle from tet-vertex values (the reference's

@@ -115,3 +115,22 @@ def test_tjunction_counts_patches_and_geometry():
     # the seeding box of the dict lies in the inlet duct
     lo, hi = tj.PARTICLE_DICT["seedingBox"]
     assert lo[0] >= 0 and hi[0] <= 0.2 and abs(lo[1]) <= 0.01 and abs(hi[1]) <= 0.01
+
+
+def test_tet_decomposition_is_the_fragments_fan(oracle_libs, pitz):
+    """PolyMesh.tet_decomposition -- what a host hands cpf_set_tets for the "VertexVelocity" mode -- is the decomposition the
+    reference's fragment builds (src/initCuda.H:86-124: positions = points ++ cell centres, per cell one tet per face triangle,
+    apex = the centre vertex): equal, index for index, to the oracle's independent restatement (oracle/tetmesh.py), 12 tets per hex,
+    every tet positively oriented, a closed fan."""
+    from cudaparticlesfoam_amd.cases import box_mesh
+    from oracle.tetmesh import poly_to_tets
+    for mesh in (box_mesh(5, 4, 3), pitz["mesh"]):
+        centres, vols = mesh.cell_centres_volumes()
+        pos, tets = mesh.tet_decomposition(centres)
+        opos, otets, ocell, _ = poly_to_tets(mesh, centres, None)
+        assert np.array_equal(pos, opos) and np.array_equal(tets, otets)
+        assert tets.shape == (12 * mesh.n_cells, 4) and np.array_equal(tets[:, 0], mesh.n_points + np.repeat(np.arange(mesh.n_cells), 12))
+        a, b, c, d = (pos[tets[:, k]] for k in range(4))
+        six_vol = np.einsum("ij,ij->i", b - a, np.cross(c - a, d - a))
+        assert (six_vol > 0).all()
+        assert np.allclose(six_vol.reshape(mesh.n_cells, 12).sum(1) / 6.0, vols, rtol=1e-9)       # the fan tiles its cell
