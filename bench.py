@@ -948,7 +948,14 @@ def run(args, M):
     ctx.set_option("stats", 1)
     counters0 = ctx.counters()
     stage("warmup")
+    if dist_on and args.balance == "time":
+        ctx.set_option("timing_stride", 1)
+        ctx.timing_enable(True)                    # the balancer's first cost reading comes from the warm-up steps
     cloud.step(dt, args.warmup)                    # statistics counters on: feeds the config fields below
+    if dist_on:
+        # the balancer reads the measured step times for the first time here -- its one wait for the launch queue per run
+        # (cpf_shard_core.h, measuredCost) -- and re-cuts by them: warm-up, like RCCL's first collectives above
+        cloud.rebalance(mesh.n_cells)
     M.sync(); barrier()
     counters = {k: v - counters0[k] for k, v in ctx.counters().items()}
     ctx.set_option("stats", 0)                     # diagnostics off in the timed region (the reference has none)
