@@ -716,7 +716,7 @@ int cpf_step_dev(cpf_context* ctx, double* x, double* y, double* z, int32_t* cel
             CPF_HIP(ctx, take(e0)); CPF_HIP(ctx, take(e1));
             // the streaming launcher stamps the events with the dispatch's own begin / end (cpf_device.h, StreamState);
             // any other kernel is bracketed by two event records
-            stamped = vertexU ? cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState, cycPerLaunch)
+            stamped = vertexU ? cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->tetsPerCell, ctx->stepVariant, &ctx->streamState, cycPerLaunch)
                               : cpf::effective_step_variant(ctx->stepVariant, m, true, cycPerLaunch, ctx->streamState.coopMaxCells) == 4;
             if (stamped) { ctx->streamState.evStart = e0; ctx->streamState.evStop = e1; }
             else CPF_HIP(ctx, hipEventRecord(e0, ctx->stream));
@@ -1049,7 +1049,7 @@ int cpf_step_kernel_name(cpf_context* ctx, double D, unsigned flags, char* buf, 
     const bool brown = D > 0.0, reflect = (flags & CPF_STEP_NO_REFLECT) == 0, sv = (flags & CPF_STEP_STORE_VEL) != 0;
     char tmp[192];
     if ((flags & CPF_STEP_VERTEX_VELOCITY) &&
-        cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->stepVariant, &ctx->streamState,
+        cpf::step_vertex_streams(m, ctx->vertexFast ? ctx->d_vertCone : nullptr, ctx->tetsPerCell, ctx->stepVariant, &ctx->streamState,
                                  (flags & CPF_STEP_FUSE_CYCLES) ? ctx->lastStepCycles : 1))
         snprintf(tmp, sizeof tmp, "cpf::step_kernel_stream_vertex<%s, %s, %s, %s, %d> (cone locate)", b[brown], b[reflect], b[sv],
                  b[ctx->stats ? 1 : 0], cpf::stream_vertex_lookup_mode(ctx->lastStepN > 0 ? ctx->lastStepN : ctx->n, m, ctx->streamState));

@@ -94,7 +94,7 @@ hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, i
                               const double* pos, const int32_t* tets, int tetsPerCell, const double* vertVel, const double* cone,
                               const double* apex, int variant, StreamState* ss);
 // does launch_step_vertex stream (step_kernel_stream_vertex) or run step_kernel_vertex, for these arguments?
-bool step_vertex_streams(const MeshView& m, const double* cone, int variant, const StreamState* ss, int nCyc);
+bool step_vertex_streams(const MeshView& m, const double* cone, int tetsPerCell, int variant, const StreamState* ss, int nCyc);
 struct VertexField;                  // cpf_walk.h
 // the "VertexVelocity" cycle on the streaming kernel (all-hex meshes with cone-locate tables; else launch_step_vertex's own kernel)
 bool stream_vertex_capable(const MeshView& m);

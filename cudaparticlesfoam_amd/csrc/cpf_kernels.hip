@@ -469,8 +469,9 @@ hipError_t launch_step(hipStream_t st, double* x, double* y, double* z, int32_t*
 
 // the streaming kernel takes the cycle where it would take the cell-constant one (variant 4: -1 on a mesh with cell records),
 // the decomposition is admitted to the cone locate (its advect never fails there) and the mesh is all-hex
-bool step_vertex_streams(const MeshView& m, const double* cone, int variant, const StreamState* ss, int nCyc) {
-    return cone != nullptr && ss != nullptr && stream_vertex_capable(m) &&
+// (twelve tets a cell -- the reference's only decomposition, src/initCuda.H:64 -- is what the kernel's staged locate is built for)
+bool step_vertex_streams(const MeshView& m, const double* cone, int tetsPerCell, int variant, const StreamState* ss, int nCyc) {
+    return cone != nullptr && tetsPerCell == 12 && ss != nullptr && stream_vertex_capable(m) &&
            effective_step_variant(variant, m, true, nCyc, ss->coopMaxCells) == kVariantStream;
 }
 
@@ -484,7 +485,7 @@ hipError_t launch_step_vertex(hipStream_t st, double* x, double* y, double* z, i
     const bool brown = D > 0.0;
     const double sigma = brown ? sqrt(2.00 * D * dt) : 0.0;   // particles.cu:564
     const VertexField vf{pos, tets, vertVel, tetsPerCell, cone, reinterpret_cast<const double4*>(apex)};
-    if (step_vertex_streams(m, cone, variant, ss, nCyc))
+    if (step_vertex_streams(m, cone, tetsPerCell, variant, ss, nCyc))
         return launch_step_stream_vertex(st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, brown, reflect, storeVel, m, counters, *ss, vf);
 #define CPF_VTX(B, R, SV) hipLaunchKernelGGL((step_kernel_vertex<B, R, SV>), grid, dim3(kBlock), 0, st, x, y, z, cell, gid, vel, n, dt, sigma, step0, nCyc, seed, m, vf, counters)
     if (brown) {

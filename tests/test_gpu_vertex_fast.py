@@ -108,3 +108,43 @@ def test_a_decomposition_that_is_not_a_fan_keeps_the_full_evaluation(gpu_ctx_fac
         assert "(all tets: cell" in name and what in name, name
     ctx.set_tets(pos, tets, 12); ctx.set_vertex_velocity(np.ones(pos.shape))
     assert "(cone locate)" in ctx.step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY)
+
+
+def test_a_fan_of_24_tets_per_cell_takes_the_cone_locate_on_the_generic_kernel(gpu_ctx_factory):
+    """Any fan about one apex is admitted, not only the reference's 12 tets per hex: here every quad face is cut into four
+    triangles about its centre (24 tets a cell).  The streaming kernel's staged locate is built for twelve, so this cycle runs on
+    step_kernel_vertex -- with the cone locate, and with the same bits as the evaluation of all 24 tets."""
+    from cudaparticlesfoam_amd import _lib as L
+    from cudaparticlesfoam_amd.cases import box_mesh
+    mesh = box_mesh(6, 5, 4, lower=(0.0, 0.0, 0.0), upper=(0.6, 0.4, 0.2), grading=(2.0, 1.0, 0.5))
+    centres, _ = mesh.cell_centres_volumes()
+    fc, _ = mesh.face_centres_areas()
+    off, faces = mesh.cell_faces()
+    nP, nC = mesh.n_points, mesh.n_cells
+    pos = np.concatenate([mesh.points, centres, fc])
+    tets = []
+    for c in range(nC):
+        for f in faces[off[c]:off[c + 1]]:
+            loop = mesh.face_verts[mesh.face_offsets[f]:mesh.face_offsets[f + 1]]
+            if mesh.owner[f] != c:
+                loop = loop[::-1]                                  # outward for this cell
+            for k in range(len(loop)):
+                tets.append((nP + c, nP + nC + f, loop[k], loop[(k + 1) % len(loop)]))
+    tets = np.asarray(tets, np.int32)
+    assert tets.shape[0] == 24 * nC
+    rng = np.random.default_rng(24)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh); ctx.set_velocity(np.zeros((nC, 3)))
+    ctx.set_tets(pos, tets, 24); ctx.set_vertex_velocity(rng.normal(size=pos.shape))
+    assert ctx.step_kernel_name(0.0, L.STEP_VERTEX_VELOCITY) == "cpf::step_kernel_vertex<false, true, false> (cone locate)"
+    lo, hi = mesh.bounds()
+    P = rng.uniform(lo, hi, size=(100_000, 3))
+    out = []
+    for fast in (1, 0):
+        ctx.set_option("vertex_fast", fast)
+        ctx.set_particles(P); ctx.locate_initial()
+        ctx.step(0.002, 0.0, 10, L.STEP_VERTEX_VELOCITY)
+        out.append(ctx.get_particles())
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][0][:, :3] - P).max() > 1e-3
+    ctx.set_option("vertex_fast", 1)
