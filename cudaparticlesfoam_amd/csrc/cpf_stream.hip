@@ -71,7 +71,13 @@ constexpr int kStreamGatherLanes = CPF_STREAM_GATHER_LANES;   // lanes without a
 #define CPF_STREAM_HIT_POOL 40
 #endif
 constexpr int kVertexTets = 12;        // the decomposition the staged locate knows (src/initCuda.H:64: 12 tets per hex); others: per lane
-constexpr int kVertexBlocks = 3;       // distinct cells staged per pass
+#ifndef CPF_VERTEX_BLOCKS
+#define CPF_VERTEX_BLOCKS 4
+#endif
+#ifndef CPF_VERTEX_PICK_UNROLL
+#define CPF_VERTEX_PICK_UNROLL 12
+#endif
+constexpr int kVertexBlocks = CPF_VERTEX_BLOCKS;       // distinct cells staged per pass
 constexpr int kStreamSparsePerCell = 8;                      // fewer particles per cell than this: the sparse instantiation (LOOKUP 4)
 constexpr int kSitOut = INT32_MIN + 7;                        // "next cell" of a lane that did not trace this round
 
@@ -200,7 +206,7 @@ __device__ __forceinline__ void stream_body(
     __shared__ unsigned sPoolUsed;
     // landing zone of the next tile: x[64] | y[64] | z[64] | cell[64] (int32) | gid[64] (Brownian only)
     __shared__ double sPre[BROWNIAN ? 288 : 224];
-    // (VERTEX) the cone rows + 1/det of the 12 tets of up to three cells: 80 bytes a tet, staged once per cycle and distinct cell of the wave
+    // (VERTEX) the cone rows + 1/det of the 12 tets of up to kVertexBlocks cells: 80 bytes a tet, staged once per cycle and distinct cell of the wave
     __shared__ double sCone[VERTEX ? kVertexBlocks : 1][VERTEX ? kVertexTets * 10 : 1];
     double(*sE)[64] = sLane;
     const int lane = threadIdx.x;
@@ -445,8 +451,8 @@ __device__ __forceinline__ void stream_body(
                 if (VERTEX) {
                     // ---- the cycle's velocities, HERE where the wave is whole: the interpolated velocity depends on the position
                     // and the cell the particle begins the cycle with, nothing else.  The distinct cells of the wave (a sorted
-                    // cloud: one to three) get an LDS block each, three per pass; the lanes fetch the blocks' cone rows together
-                    // -- lane l the l-th 16 bytes of each, ONE L2 round trip for all tets of all three cells instead of one per
+                    // cloud: one to three) get an LDS block each, kVertexBlocks per pass; the lanes fetch the blocks' cone rows together
+                    // -- lane l the l-th 16 bytes of each, ONE L2 round trip for all tets of all those cells instead of one per
                     // tet and lane --, every lane picks its tet from its cell's block (broadcast reads) and evaluates that ONE
                     // tet's record.  vertex_velocity() (cpf_walk.h) states the rule and takes the lanes the shortcut does not
                     // cover, and every lane of a decomposition that is not twelve tets a cell.  (The first streaming version
@@ -483,7 +489,7 @@ __device__ __forceinline__ void stream_body(
                                 int cand = 0;
                                 double candMin = -1e300;
                                 const double* blk = &sCone[myBlock][0];
-#pragma unroll 4
+#pragma unroll CPF_VERTEX_PICK_UNROLL
                                 for (int k = 0; k < kVertexTets; ++k) {
                                     const double2* g = reinterpret_cast<const double2*>(blk + 10 * k);
                                     const double2 g01 = g[0], g23 = g[1], g45 = g[2], g67 = g[3], g89 = g[4];
